@@ -1,0 +1,67 @@
+"""Synthetic 3DMatch-shaped pairs (there are no datasets in this image).
+
+Input contract of the reference's collate (dataset/common.py:50-126, dataset/tdmatch.py:50-135):
+float32 `src_points (N,3)`, `tgt_points (M,3)`, unit normals flipped toward the view point
+(dataset/common.py:312-320 `normal_redirect`, view point = origin), `feats = ones (.,1)`
+(dataset/tdmatch.py:128-129), `rot (3,3)`, `trans (3,1)` with  tgt ~= src @ rot.T + trans.T,
+`raw_src_pcd = src_points` for 3DMatch.
+
+Seed rule: numpy default_rng(1000 * config + pair_index).  Points ~ U[0,2)^3 m
+(3DMatch fragments are 2-3 m across).  The two clouds are overlapping crops of one scene so the
+matching stages have real correspondences to find.
+"""
+import numpy as np
+
+
+def random_rotation(rng):
+    q = rng.standard_normal(4)
+    q /= np.linalg.norm(q)
+    w, x, y, z = q
+    return np.array([
+        [1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+        [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+        [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)],
+    ])
+
+
+def _normals(rng, pts):
+    n = rng.standard_normal(pts.shape)
+    n /= np.linalg.norm(n, axis=1, keepdims=True)
+    flip = np.sum((0.0 - pts) * n, axis=1) < 0.0
+    n[flip] *= -1.0
+    return n
+
+
+def make_pair(n_src, n_tgt=None, config=2, pair_index=0, overlap=0.6, jitter=0.002):
+    """Returns a dict of float32 numpy arrays following the reference input contract."""
+    n_tgt = n_src if n_tgt is None else n_tgt
+    rng = np.random.default_rng(1000 * config + pair_index)
+    # one scene, two crops along x that share `overlap` of their extent
+    shift = 2.0 * (1.0 - overlap)
+    src = rng.random((n_src, 3)) * 2.0
+    tgt_scene = rng.random((n_tgt, 3)) * 2.0
+    tgt_scene[:, 0] += shift
+    # inside the shared slab, tgt re-observes jittered src points (real correspondences)
+    shared_src = np.nonzero(src[:, 0] >= shift)[0]
+    shared_tgt = np.nonzero(tgt_scene[:, 0] < 2.0)[0]
+    k = min(len(shared_src), len(shared_tgt))
+    if k > 0:
+        pick = rng.permutation(shared_src)[:k]
+        tgt_scene[shared_tgt[:k]] = src[pick] + rng.normal(0.0, jitter, (k, 3))
+    rot = random_rotation(rng)
+    trans = rng.uniform(-1.0, 1.0, (3, 1))
+    tgt = tgt_scene @ rot.T + trans.T
+    src_n = _normals(rng, src)
+    tgt_n = _normals(rng, tgt)
+    f32 = np.float32
+    return {
+        "src_points": np.ascontiguousarray(src, f32),
+        "tgt_points": np.ascontiguousarray(tgt, f32),
+        "src_normals": np.ascontiguousarray(src_n, f32),
+        "tgt_normals": np.ascontiguousarray(tgt_n, f32),
+        "src_feats": np.ones((n_src, 1), f32),
+        "tgt_feats": np.ones((n_tgt, 1), f32),
+        "rot": np.ascontiguousarray(rot, f32),
+        "trans": np.ascontiguousarray(trans, f32),
+        "raw_src_pcd": np.ascontiguousarray(src, f32),
+    }
