@@ -1,0 +1,93 @@
+/*
+ * roitr_pointops.h -- C ABI of libroitr_hip.so, part 1: the `pointops` operator boundary.
+ *
+ * Boundary B1 of SURVEY.md 8(b).  Plain pointers and sizes only; every pointer is a DEVICE pointer
+ * to contiguous fp32 / int32 memory owned by the caller; kernels write in place.
+ *
+ * Two families:
+ *  (1) the reference's own `extern "C"` launcher names and signatures, unchanged (void return,
+ *      legacy default stream) -- a maintainer can link the reference's *_cuda.cpp ATen wrappers
+ *      against this library instead of its .cu objects;
+ *  (2) `roitr_*` variants of the same operators that add a hipStream_t, return an int status
+ *      (0 = ok; roitr_last_error() has the text) and, for kNN, expose the grid-accelerated search
+ *      and the fused queryandgroup + point-pair-feature outputs.
+ *
+ * All citations are into /root/reference/cpp_wrappers/pointops/src unless stated otherwise.
+ */
+#ifndef ROITR_POINTOPS_H
+#define ROITR_POINTOPS_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ihipStream_t* roitr_stream_t; /* == hipStream_t; NULL = legacy default stream */
+
+/* ---- diagnostics ---------------------------------------------------------------------------- */
+const char* roitr_last_error(void);
+int roitr_abi_version(void);
+
+/* ---- (1) reference launcher names, verbatim ------------------------------------------------- */
+
+/* sampling/sampling_cuda_kernel.h:13.  `n` = longest cloud (selects the tie-break block size,
+ * cuda_utils.h:11-14); `tmp` (total points) must arrive filled with 1e10 (functions/pointops.py:22);
+ * idx[new_offset[i-1]] = offset[i-1] (first point of each cloud is always selected). */
+void furthestsampling_cuda_launcher(int b, int n, const float* xyz, const int* offset, const int* new_offset,
+                                    float* tmp, int* idx);
+
+/* knnquery/knnquery_cuda_kernel.h:13.  idx (m, nsample) int32 ascending by distance, dist2 SQUARED
+ * distances; nsample <= 100 (knnquery_cuda_kernel.cu:86); slots beyond the cloud size keep
+ * (offset_start, 1e10). */
+void knnquery_cuda_launcher(int m, int nsample, const float* xyz, const float* new_xyz, const int* offset,
+                            const int* new_offset, int* idx, float* dist2);
+
+/* grouping/grouping_cuda_kernel.h:13-14 */
+void grouping_forward_cuda_launcher(int m, int nsample, int c, const float* input, const int* idx, float* output);
+void grouping_backward_cuda_launcher(int m, int nsample, int c, const float* grad_output, const int* idx, float* grad_input);
+/* interpolation/interpolation_cuda_kernel.h:13-14 (output must arrive zeroed, pointops.py:199) */
+void interpolation_forward_cuda_launcher(int n, int c, int k, const float* input, const int* idx, const float* weight, float* output);
+void interpolation_backward_cuda_launcher(int n, int c, int k, const float* grad_output, const int* idx, const float* weight, float* grad_input);
+/* subtraction/subtraction_cuda_kernel.h:13-14 */
+void subtraction_forward_cuda_launcher(int n, int nsample, int c, const float* input1, const float* input2, const int* idx, float* output);
+void subtraction_backward_cuda_launcher(int n, int nsample, int c, const int* idx, const float* grad_output, float* grad_input1, float* grad_input2);
+/* aggregation/aggregation_cuda_kernel.h:13-14 (output must arrive zeroed, pointops.py:146) */
+void aggregation_forward_cuda_launcher(int n, int nsample, int c, int w_c, const float* input, const float* position, const float* weight, const int* idx, float* output);
+void aggregation_backward_cuda_launcher(int n, int nsample, int c, int w_c, const float* input, const float* position, const float* weight, const int* idx, const float* grad_output, float* grad_input, float* grad_position, float* grad_weight);
+
+/* ---- (2) stream + status variants ------------------------------------------------------------ */
+
+int roitr_furthestsampling(int b, int n_max, const float* xyz, const int* offset, const int* new_offset, float* tmp,
+                           int* idx, roitr_stream_t stream);
+
+/* Workspace for roitr_knn_build_grid / roitr_knnquery_ex: b clouds, n reference points, at most m queries. */
+size_t roitr_knn_workspace_bytes(int b, int n, int m);
+
+/* Counting-sorts the reference clouds into per-cloud uniform grids inside `ws`. */
+int roitr_knn_build_grid(int b, int n, int m_capacity, const float* xyz, const int* offset, void* ws, roitr_stream_t stream);
+
+/* Exact kNN.  Any of idx/dist2/group_idx/ppf may be NULL.
+ *   group_idx (m, nsample-1): columns 1.. of idx  == pointops.queryandgroup(nsample-1, ..., return_idx=True)
+ *                             (functions/pointops.py:88-89: kNN(k+1), drop column 0)
+ *   ppf (m, nsample-1, 4):    lib/utils.py:358-389 calc_ppf_gpu(new_xyz, query_normals, xyz[group_idx],
+ *                             ref_normals[group_idx])
+ * use_grid != 0 needs a prior roitr_knn_build_grid(b, n, m_capacity, xyz, offset, ws). */
+int roitr_knnquery_ex(int b, int n, int m, int nsample, const float* xyz, const float* new_xyz, const int* offset,
+                      const int* new_offset, int* idx, float* dist2, int* group_idx, float* ppf,
+                      const float* ref_normals, const float* query_normals, int use_grid, int m_capacity, void* ws,
+                      roitr_stream_t stream);
+
+int roitr_grouping_forward(int m, int nsample, int c, const float* input, const int* idx, float* output, roitr_stream_t stream);
+int roitr_grouping_backward(int m, int nsample, int c, const float* grad_output, const int* idx, float* grad_input, roitr_stream_t stream);
+int roitr_interpolation_forward(int n, int c, int k, const float* input, const int* idx, const float* weight, float* output, roitr_stream_t stream);
+int roitr_interpolation_backward(int n, int c, int k, const float* grad_output, const int* idx, const float* weight, float* grad_input, roitr_stream_t stream);
+int roitr_subtraction_forward(int n, int nsample, int c, const float* input1, const float* input2, const int* idx, float* output, roitr_stream_t stream);
+int roitr_subtraction_backward(int n, int nsample, int c, const int* idx, const float* grad_output, float* grad_input1, float* grad_input2, roitr_stream_t stream);
+int roitr_aggregation_forward(int n, int nsample, int c, int w_c, const float* input, const float* position, const float* weight, const int* idx, float* output, roitr_stream_t stream);
+int roitr_aggregation_backward(int n, int nsample, int c, int w_c, const float* input, const float* position, const float* weight, const int* idx, const float* grad_output, float* grad_input, float* grad_position, float* grad_weight, roitr_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ROITR_POINTOPS_H */

@@ -1,0 +1,61 @@
+"""Builds roitr_amd/lib/libroitr_hip.so for gfx950 with hipcc (cross-compiles without a GPU).
+
+One object per source under csrc/, compiled in parallel, linked into a single C-ABI shared
+library with no torch dependency.  Rebuilds only what changed (mtime of source and headers).
+"""
+import concurrent.futures
+import glob
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(HERE, "lib", "obj")
+LIB = os.path.join(HERE, "lib", "libroitr_hip.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function",
+         "-I", CSRC, "-I", os.path.join(os.path.dirname(HERE), "include")]
+
+
+def _newer(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    os.makedirs(OBJ, exist_ok=True)
+    headers = glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(os.path.dirname(HERE), "include", "*.h"))
+    srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.cpp")))
+    jobs = []
+    objs = []
+    for s in srcs:
+        o = os.path.join(OBJ, os.path.basename(s) + ".o")
+        objs.append(o)
+        if force or _newer(o, [s] + headers):
+            lang = ["-x", "hip"] if s.endswith(".hip") else []
+            jobs.append([HIPCC] + FLAGS + lang + ["-c", s, "-o", o])
+
+    def run(cmd):
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        return cmd, r
+
+    with concurrent.futures.ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
+        for cmd, r in ex.map(run, jobs):
+            if verbose or r.returncode != 0:
+                sys.stderr.write(" ".join(cmd[-3:]) + "\n" + r.stdout + r.stderr)
+            if r.returncode != 0:
+                raise RuntimeError("hipcc failed for " + cmd[-3])
+    if jobs or force or _newer(LIB, objs):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            sys.stderr.write(r.stdout + r.stderr)
+            raise RuntimeError("link failed")
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,599 @@
+// Exact k-nearest-neighbour query (+ fused point-pair features) for gfx950.
+//
+// Replaces knnquery_cuda_launcher (reference cpp_wrappers/pointops/src/knnquery/
+// knnquery_cuda_kernel.cu:65-116) and, when asked, fuses pointops.queryandgroup's "k+1 then drop
+// column 0" (functions/pointops.py:88-89) and lib/utils.py:358-389 calc_ppf_gpu into the same pass.
+//
+// Design (not a translation of the one-thread-per-query heap kernel):
+//   * ONE WAVE PER QUERY.  M is a few thousand at most, so a thread-per-query launch leaves the
+//     chip idle (5000 queries = 78 waves for 1024 SIMDs); a wave per query gives 5000 waves.
+//   * The running best list is a SORTED list DISTRIBUTED ACROSS THE 64 LANES (position p lives in
+//     lane p&63, register p>>6).  A batch of 64 candidates is evaluated with one coalesced load and
+//     one fmaf chain per lane; `__ballot(d2 < tau)` prunes the batch; survivors are inserted one by
+//     one with a scalar broadcast (v_readlane) + a one-lane shift (the list never leaves VGPRs).
+//   * Output-sensitive search: a uniform grid (counting sort by cell, x-fastest so a row of cells
+//     is one contiguous run) is built per cloud once per level; a query expands Chebyshev rings
+//     until the (k+1)-th best distance is provably below everything unseen.  Small clouds are
+//     scanned brute force in index order with the same list code.
+//   * Exactness.  Distances use the oracle's arithmetic form (common.h sqdist3).  With pairwise
+//     distinct distances among the best k+1 the reference's heap + heap_sort result is the unique
+//     ascending list, which is what the sorted list holds.  When the best k+1 contain equal
+//     distances the reference's answer depends on its heap history (reheap swaps on ==,
+//     l.21-36; strict < admission, l.97): those queries (rare) are appended to a tie list and a
+//     second kernel REPLAYS the reference algorithm for them exactly -- index-order scan, max-heap,
+//     heap_sort -- wave-cooperatively (64 distances per step, ballot-pruned against the heap root).
+#include "common.h"
+#include <math.h>
+
+#define KNN_FILL 1e10f  // knnquery_cuda_kernel.cu:89
+#define GRID_MAX_CELLS 16384
+#define GRID_MAX_DIM 255
+
+struct RoitrGrid {  // one per cloud
+    float ox, oy, oz, h, inv_h;
+    int nx, ny, nz;
+};
+
+namespace {
+
+__device__ __forceinline__ float rl_f(float v, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane)); }
+__device__ __forceinline__ int rl_i(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
+
+// ---------------------------------------------------------------- lane-distributed sorted list
+template <int NR>
+struct WaveList {
+    float d[NR];
+    int i[NR];
+    __device__ __forceinline__ void init(int fill_idx)
+    {
+#pragma unroll
+        for (int r = 0; r < NR; ++r) { d[r] = KNN_FILL; i[r] = fill_idx; }
+    }
+    // value at list position p (wave-uniform p)
+    __device__ __forceinline__ float dist_at(int p) const
+    {
+        float v = rl_f(d[0], p & 63);
+        if (NR > 1) { const float v1 = rl_f(d[NR - 1], p & 63); v = p >= 64 ? v1 : v; }
+        return v;
+    }
+    // insert wave-uniform (nd, ni) after every element <= nd; the last element falls off
+    __device__ __forceinline__ void insert(float nd, int ni, int lane)
+    {
+        float carry_d = 0.f; int carry_i = 0; bool carry_gt = false;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const bool gt = d[r] > nd;
+            float pd = __shfl_up(d[r], 1, 64);
+            int pi = __shfl_up(i[r], 1, 64);
+            bool pgt = pd > nd;
+            if (lane == 0) { pd = carry_d; pi = carry_i; pgt = carry_gt; }
+            if (NR > 1) {  // what register r+1's lane 0 will receive
+                carry_d = rl_f(d[r], 63); carry_i = rl_i(i[r], 63); carry_gt = carry_d > nd;
+            }
+            d[r] = pgt ? pd : (gt ? nd : d[r]);
+            i[r] = pgt ? pi : (gt ? ni : i[r]);
+        }
+    }
+};
+
+struct Query {
+    float x, y, z;
+};
+
+// one batch of <= 64 candidates: lane holds (cd, ci); cd = +inf for idle lanes
+template <int NR>
+__device__ __forceinline__ void consume_batch(WaveList<NR>& L, float cd, int ci, float& tau, int tau_pos, int lane)
+{
+    unsigned long long m = __ballot(cd < tau);
+    while (m) {
+        const int l = __ffsll((long long)m) - 1;
+        m &= m - 1;
+        const float nd = rl_f(cd, l);
+        if (nd < tau) {
+            L.insert(nd, rl_i(ci, l), lane);
+            tau = L.dist_at(tau_pos);
+        }
+    }
+}
+
+// PPF of (centre c with normal cn) vs (neighbour p with normal pn), lib/utils.py:358-389:
+// [ |d|, atan2(|n1 x d|, n1.d), atan2(|n2 x d|, n2.d), atan2(|n1 x n2|, n1.n2) ] with angles / pi
+__device__ __forceinline__ float ang(float ax, float ay, float az, float bx, float by, float bz)
+{
+    const float dt = ax * bx + ay * by + az * bz;
+    const float cx = ay * bz - az * by, cy = az * bx - ax * bz, cz = ax * by - ay * bx;
+    const float cn = sqrtf(cx * cx + cy * cy + cz * cz);
+    return atan2f(cn, dt) / 3.14159265358979323846f;
+}
+
+__device__ __forceinline__ float4 ppf4(float cx, float cy, float cz, float cnx, float cny, float cnz, float px, float py, float pz,
+                                       float pnx, float pny, float pnz)
+{
+    const float dx = px - cx, dy = py - cy, dz = pz - cz;
+    float4 o;
+    o.x = sqrtf(dx * dx + dy * dy + dz * dz);
+    o.y = ang(cnx, cny, cnz, dx, dy, dz);
+    o.z = ang(pnx, pny, pnz, dx, dy, dz);
+    o.w = ang(cnx, cny, cnz, pnx, pny, pnz);
+    return o;
+}
+
+struct KnnOut {
+    int* idx;          // (m, nsample) or null
+    float* dist2;      // (m, nsample) or null
+    int* group_idx;    // (m, nsample-1): columns 1.. (queryandgroup), or null
+    float* ppf;        // (m, nsample-1, 4) for columns 1.., or null
+    const float* ref_normals;    // (n, 3), needed for ppf
+    const float* query_normals;  // (m, 3), needed for ppf
+    int* tie_count;
+    int* tie_list;
+};
+
+// writes one query's result row(s) from list-position-indexed (dist, idx) held in lanes
+template <int NR>
+__device__ __forceinline__ void write_rows(const KnnOut& o, int q, int nsample, const float (&d)[NR], const int (&i)[NR], int lane,
+                                           const float* __restrict__ xyz, Query Q)
+{
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const int p = lane + 64 * r;
+        if (p < nsample) {
+            if (o.idx) o.idx[(size_t)q * nsample + p] = i[r];
+            if (o.dist2) o.dist2[(size_t)q * nsample + p] = d[r];
+            if (p >= 1) {
+                if (o.group_idx) o.group_idx[(size_t)q * (nsample - 1) + p - 1] = i[r];
+                if (o.ppf) {
+                    const float* pp = xyz + (size_t)i[r] * 3;
+                    const float* pn = o.ref_normals + (size_t)i[r] * 3;
+                    const float* qn = o.query_normals + (size_t)q * 3;
+                    const float4 f = ppf4(Q.x, Q.y, Q.z, qn[0], qn[1], qn[2], pp[0], pp[1], pp[2], pn[0], pn[1], pn[2]);
+                    reinterpret_cast<float4*>(o.ppf)[(size_t)q * (nsample - 1) + p - 1] = f;
+                }
+            }
+        }
+    }
+}
+
+// equal neighbouring distances among positions [0, nsample] (i.e. the best nsample+1)?
+template <int NR>
+__device__ __forceinline__ bool has_tie(const WaveList<NR>& L, int nsample, int lane)
+{
+    bool t = false;
+    float nxt_first = 0.f;
+    if (NR > 1) nxt_first = rl_f(L.d[NR - 1], 0);
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        float nx = __shfl_down(L.d[r], 1, 64);
+        const int p = lane + 64 * r;
+        if (lane == 63) nx = (r + 1 < NR) ? nxt_first : __int_as_float(0x7fc00000);  // NaN: never equal
+        t |= (p < nsample) && (L.d[r] == nx) && (L.d[r] < KNN_FILL);
+    }
+    return __ballot(t) != 0ull;
+}
+
+__device__ __forceinline__ void find_segment(int q, const int* __restrict__ offset, const int* __restrict__ new_offset, int& start,
+                                             int& end, int& seg)
+{
+    int bt = 0;  // get_bt_idx, knnquery_cuda_kernel.cu:51-62
+    while (!(q < new_offset[bt])) bt++;
+    start = bt == 0 ? 0 : offset[bt - 1];
+    end = offset[bt];
+    seg = bt;
+}
+
+template <int NR>
+__device__ __forceinline__ void finish_query(WaveList<NR>& L, const KnnOut& o, int q, int nsample, int lane, const float* xyz, Query Q)
+{
+    if (has_tie(L, nsample, lane)) {
+        if (lane == 0) {
+            const int slot = atomicAdd(o.tie_count, 1);
+            o.tie_list[slot] = q;
+        }
+        return;  // the replay kernel owns this query's rows
+    }
+    write_rows<NR>(o, q, nsample, L.d, L.i, lane, xyz, Q);
+}
+
+// ---------------------------------------------------------------- brute force, index order
+template <int NR>
+__global__ __launch_bounds__(256) void knn_brute_kernel(int m, int nsample, const float* __restrict__ xyz,
+                                                        const float* __restrict__ new_xyz, const int* __restrict__ offset,
+                                                        const int* __restrict__ new_offset, KnnOut o)
+{
+    const int lane = threadIdx.x & 63;
+    const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= m) return;
+    int start, end, seg;
+    find_segment(q, offset, new_offset, start, end, seg);
+    Query Q = {new_xyz[(size_t)q * 3], new_xyz[(size_t)q * 3 + 1], new_xyz[(size_t)q * 3 + 2]};
+    WaveList<NR> L;
+    L.init(start);
+    const int tau_pos = nsample;  // keep the best nsample+1 exactly (tie detection)
+    float tau = KNN_FILL;
+    for (int base = start; base < end; base += 64) {
+        const int k = base + lane;
+        float cd = INFINITY;
+        if (k < end) {
+            const float* p = xyz + (size_t)k * 3;
+            cd = sqdist3(Q.x, Q.y, Q.z, p[0], p[1], p[2]);
+        }
+        consume_batch<NR>(L, cd, k, tau, tau_pos, lane);
+    }
+    finish_query<NR>(L, o, q, nsample, lane, xyz, Q);
+}
+
+// ---------------------------------------------------------------- grid build (one workgroup per cloud)
+__global__ __launch_bounds__(1024) void grid_build_kernel(const float* __restrict__ xyz, const int* __restrict__ offset,
+                                                          RoitrGrid* __restrict__ grids, int* __restrict__ cell_start,
+                                                          float4* __restrict__ sorted, float target_occupancy)
+{
+    __shared__ int cnt[GRID_MAX_CELLS];
+    __shared__ float red[6][16];
+    __shared__ RoitrGrid G;
+    __shared__ int wave_tot[16];
+    const int c = blockIdx.x;
+    const int start = c == 0 ? 0 : offset[c - 1];
+    const int end = offset[c];
+    const int n = end - start;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int* cs = cell_start + (size_t)c * (GRID_MAX_CELLS + 1);
+
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int k = start + tid; k < end; k += 1024) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const float v = xyz[(size_t)k * 3 + a];
+            mn[a] = fminf(mn[a], v); mx[a] = fmaxf(mx[a], v);
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float lo = -wave_max(-mn[a]), hi = wave_max(mx[a]);
+        if (lane == 0) { red[a][wave] = lo; red[3 + a][wave] = hi; }
+    }
+    for (int k = tid; k < GRID_MAX_CELLS; k += 1024) cnt[k] = 0;
+    __syncthreads();
+    if (tid == 0) {
+        float lo[3], ext[3], me = 0.f;
+        for (int a = 0; a < 3; ++a) {
+            float l = red[a][0], h = red[3 + a][0];
+            for (int w = 1; w < 16; ++w) { l = fminf(l, red[a][w]); h = fmaxf(h, red[3 + a][w]); }
+            if (n == 0) { l = 0.f; h = 0.f; }
+            lo[a] = l; ext[a] = h - l; me = fmaxf(me, ext[a]);
+        }
+        if (!(me > 0.f)) me = 1.f;
+        float vol = 1.f;
+        for (int a = 0; a < 3; ++a) vol *= fmaxf(ext[a], 1e-3f * me);
+        float h = cbrtf(vol * target_occupancy / (float)(n > 0 ? n : 1));
+        h = fmaxf(h, me / (float)GRID_MAX_DIM);
+        int d[3];
+        for (;;) {
+            long tot = 1;
+            for (int a = 0; a < 3; ++a) {
+                int v = (int)floorf(ext[a] / h) + 1;
+                d[a] = v < 1 ? 1 : (v > GRID_MAX_DIM ? GRID_MAX_DIM : v);
+                tot *= d[a];
+            }
+            if (tot <= GRID_MAX_CELLS) break;
+            h *= 1.26f;
+        }
+        G.ox = lo[0]; G.oy = lo[1]; G.oz = lo[2]; G.h = h; G.inv_h = 1.0f / h; G.nx = d[0]; G.ny = d[1]; G.nz = d[2];
+        grids[c] = G;
+    }
+    __syncthreads();
+    const RoitrGrid g = G;
+    const int ncell = g.nx * g.ny * g.nz;
+    auto cell_of = [&](float x, float y, float z) {
+        int cx = (int)floorf((x - g.ox) * g.inv_h), cy = (int)floorf((y - g.oy) * g.inv_h), cz = (int)floorf((z - g.oz) * g.inv_h);
+        cx = min(max(cx, 0), g.nx - 1); cy = min(max(cy, 0), g.ny - 1); cz = min(max(cz, 0), g.nz - 1);
+        return (cz * g.ny + cy) * g.nx + cx;
+    };
+    for (int k = start + tid; k < end; k += 1024)
+        atomicAdd(&cnt[cell_of(xyz[(size_t)k * 3], xyz[(size_t)k * 3 + 1], xyz[(size_t)k * 3 + 2])], 1);
+    __syncthreads();
+    // exclusive scan of cnt[0..ncell) : 16 cells per thread
+    {
+        constexpr int PER = GRID_MAX_CELLS / 1024;
+        int loc[PER], s = 0;
+#pragma unroll
+        for (int j = 0; j < PER; ++j) { const int k = tid * PER + j; loc[j] = k < ncell ? cnt[k] : 0; s += loc[j]; }
+        int incl = s;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o, 64); if (lane >= o) incl += v; }
+        if (lane == 63) wave_tot[wave] = incl;
+        __syncthreads();
+        int wbase = 0;
+        for (int w = 0; w < wave; ++w) wbase += wave_tot[w];
+        int run = wbase + incl - s;
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            const int k = tid * PER + j;
+            if (k < ncell) { cnt[k] = run; cs[k] = start + run; }
+            run += loc[j];
+        }
+        if (tid == 0) cs[ncell] = start + n;
+    }
+    __syncthreads();
+    for (int k = start + tid; k < end; k += 1024) {
+        const float x = xyz[(size_t)k * 3], y = xyz[(size_t)k * 3 + 1], z = xyz[(size_t)k * 3 + 2];
+        const int pos = atomicAdd(&cnt[cell_of(x, y, z)], 1);
+        sorted[start + pos] = make_float4(x, y, z, __int_as_float(k));
+    }
+}
+
+// ---------------------------------------------------------------- grid query
+// Rows (fixed cz, cy; cx in [x0, x1]) of the current shell are gathered into `runs` (one run per
+// lane), prefix-summed across the wave, and the concatenated candidates are consumed 64 at a time.
+template <int NR>
+__global__ __launch_bounds__(256) void knn_grid_kernel(int m, int nsample, const float* __restrict__ xyz,
+                                                       const float* __restrict__ new_xyz, const int* __restrict__ offset,
+                                                       const int* __restrict__ new_offset, const RoitrGrid* __restrict__ grids,
+                                                       const int* __restrict__ cell_start, const float4* __restrict__ sorted, KnnOut o)
+{
+    const int lane = threadIdx.x & 63;
+    const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= m) return;
+    int start, end, seg;
+    find_segment(q, offset, new_offset, start, end, seg);
+    const RoitrGrid g = grids[seg];
+    const int* cs = cell_start + (size_t)seg * (GRID_MAX_CELLS + 1);
+    Query Q = {new_xyz[(size_t)q * 3], new_xyz[(size_t)q * 3 + 1], new_xyz[(size_t)q * 3 + 2]};
+    WaveList<NR> L;
+    L.init(start);
+    const int tau_pos = nsample;
+    float tau = KNN_FILL;
+
+    int c0[3];
+    {
+        const float t[3] = {(Q.x - g.ox) * g.inv_h, (Q.y - g.oy) * g.inv_h, (Q.z - g.oz) * g.inv_h};
+        const int dim[3] = {g.nx, g.ny, g.nz};
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            // clamp in float first: far-away queries must not overflow the int conversion
+            const float tc = fminf(fmaxf(t[a], 0.f), (float)(dim[a] - 1));
+            c0[a] = (int)tc;
+        }
+    }
+    const float margin = 2e-4f * g.h;
+    const int maxr = max(max(g.nx, g.ny), g.nz);
+    for (int r = 0; r <= maxr; ++r) {
+        const int x0 = max(c0[0] - r, 0), x1 = min(c0[0] + r, g.nx - 1);
+        const int y0 = max(c0[1] - r, 0), y1 = min(c0[1] + r, g.ny - 1);
+        const int z0 = max(c0[2] - r, 0), z1 = min(c0[2] + r, g.nz - 1);
+        const int ny = y1 - y0 + 1, nz = z1 - z0 + 1;
+        // rows of this shell: (z,y) pairs; a row on the shell's z/y faces contributes [x0,x1],
+        // an interior row contributes only the two x end cells (when they are new)
+        const int nrows = ny * nz;
+        for (int rb = 0; rb < nrows; rb += 32) {
+            // lanes 0..31 -> row rb+lane, low piece; lanes 32..63 -> same row, high piece
+            const int row = rb + (lane & 31);
+            int rs = 0, re = 0;
+            if (row < nrows) {
+                const int cy = y0 + row % ny, cz = z0 + row / ny;
+                const bool face = (r == 0) || (cy == c0[1] - r) || (cy == c0[1] + r) || (cz == c0[2] - r) || (cz == c0[2] + r);
+                const int rowbase = (cz * g.ny + cy) * g.nx;
+                if (face) {
+                    if (lane < 32) { rs = cs[rowbase + x0]; re = cs[rowbase + x1 + 1]; }
+                } else {
+                    const int cx = lane < 32 ? c0[0] - r : c0[0] + r;
+                    if (cx >= 0 && cx < g.nx) { rs = cs[rowbase + cx]; re = cs[rowbase + cx + 1]; }
+                }
+            }
+            const int len = re - rs;
+            int incl = len;
+#pragma unroll
+            for (int s = 1; s < 64; s <<= 1) { const int v = __shfl_up(incl, s, 64); if (lane >= s) incl += v; }
+            const int total = rl_i(incl, 63);
+            const int excl = incl - len;
+            for (int b = 0; b < total; b += 64) {
+                const int e = b + lane;
+                // run holding element e = first lane whose inclusive prefix exceeds e (all lanes
+                // run the same 6 probe steps so the cross-lane reads stay convergent)
+                const int es = min(e, total - 1);
+                int lo = 0, hi = 63;
+#pragma unroll
+                for (int it = 0; it < 6; ++it) {
+                    const int mid = (lo + hi) >> 1;
+                    const bool gt = __shfl(incl, mid, 64) > es;
+                    hi = gt ? mid : hi;
+                    lo = gt ? lo : min(mid + 1, 63);
+                }
+                const int src_run = __shfl(rs, lo, 64) + (es - __shfl(excl, lo, 64));
+                const int src = e < total ? src_run : -1;
+                float cd = INFINITY; int ci = 0;
+                if (src >= 0) {
+                    const float4 p = sorted[src];
+                    cd = sqdist3(Q.x, Q.y, Q.z, p.x, p.y, p.z);
+                    ci = __float_as_int(p.w);
+                }
+                consume_batch<NR>(L, cd, ci, tau, tau_pos, lane);
+            }
+        }
+        // everything unseen lies outside the searched box: lower-bound its distance
+        float dmin = INFINITY;
+        if (x0 > 0) dmin = fminf(dmin, Q.x - __fmaf_rn((float)x0, g.h, g.ox));
+        if (x1 < g.nx - 1) dmin = fminf(dmin, __fmaf_rn((float)(x1 + 1), g.h, g.ox) - Q.x);
+        if (y0 > 0) dmin = fminf(dmin, Q.y - __fmaf_rn((float)y0, g.h, g.oy));
+        if (y1 < g.ny - 1) dmin = fminf(dmin, __fmaf_rn((float)(y1 + 1), g.h, g.oy) - Q.y);
+        if (z0 > 0) dmin = fminf(dmin, Q.z - __fmaf_rn((float)z0, g.h, g.oz));
+        if (z1 < g.nz - 1) dmin = fminf(dmin, __fmaf_rn((float)(z1 + 1), g.h, g.oz) - Q.z);
+        if (dmin == INFINITY) break;  // whole grid covered
+        const float dm = dmin - margin;
+        if (dm > 0.f && tau < dm * dm) break;
+    }
+    finish_query<NR>(L, o, q, nsample, lane, xyz, Q);
+}
+
+// ---------------------------------------------------------------- exact replay of tied queries
+// knnquery_cuda_kernel.cu:65-108 restated for one wave: the heap lives in LDS, every lane runs the
+// same (uniform) heap code; 64 distances are evaluated per step and only those below the root are
+// offered to the heap, in index order -- the heap sees exactly the reference's insertion sequence.
+__global__ __launch_bounds__(64) void knn_replay_kernel(int nsample, const float* __restrict__ xyz, const float* __restrict__ new_xyz,
+                                                        const int* __restrict__ offset, const int* __restrict__ new_offset, KnnOut o)
+{
+    __shared__ float hd[128];
+    __shared__ int hi[128];
+    const int lane = threadIdx.x;
+    const int count = *o.tie_count;
+    for (int t = blockIdx.x; t < count; t += gridDim.x) {
+        const int q = o.tie_list[t];
+        int start, end, seg;
+        find_segment(q, offset, new_offset, start, end, seg);
+        Query Q = {new_xyz[(size_t)q * 3], new_xyz[(size_t)q * 3 + 1], new_xyz[(size_t)q * 3 + 2]};
+        for (int p = lane; p < nsample; p += 64) { hd[p] = KNN_FILL; hi[p] = start; }
+        __syncthreads();
+        for (int base = start; base < end; base += 64) {
+            const int k = base + lane;
+            float cd = INFINITY;
+            if (k < end) {
+                const float* p = xyz + (size_t)k * 3;
+                cd = sqdist3(Q.x, Q.y, Q.z, p[0], p[1], p[2]);
+            }
+            float root = hd[0];
+            unsigned long long mk = __ballot(cd < root);
+            while (mk) {
+                const int l = __ffsll((long long)mk) - 1;
+                mk &= mk - 1;
+                const float nd = rl_f(cd, l);
+                if (nd < root) {
+                    __syncthreads();
+                    if (lane == 0) {
+                        hd[0] = nd; hi[0] = base + l;
+                        int rt = 0, child = 1;  // reheap, l.21-36
+                        while (child < nsample) {
+                            if (child + 1 < nsample && hd[child + 1] > hd[child]) child++;
+                            if (hd[rt] > hd[child]) break;
+                            const float td = hd[rt]; hd[rt] = hd[child]; hd[child] = td;
+                            const int ti = hi[rt]; hi[rt] = hi[child]; hi[child] = ti;
+                            rt = child; child = rt * 2 + 1;
+                        }
+                    }
+                    __syncthreads();
+                    root = hd[0];
+                }
+            }
+        }
+        __syncthreads();
+        if (lane == 0) {  // heap_sort, l.39-48
+            for (int i = nsample - 1; i > 0; i--) {
+                float td = hd[0]; hd[0] = hd[i]; hd[i] = td;
+                int ti = hi[0]; hi[0] = hi[i]; hi[i] = ti;
+                int rt = 0, child = 1;
+                while (child < i) {
+                    if (child + 1 < i && hd[child + 1] > hd[child]) child++;
+                    if (hd[rt] > hd[child]) break;
+                    td = hd[rt]; hd[rt] = hd[child]; hd[child] = td;
+                    ti = hi[rt]; hi[rt] = hi[child]; hi[child] = ti;
+                    rt = child; child = rt * 2 + 1;
+                }
+            }
+        }
+        __syncthreads();
+        float d[2]; int i[2];
+        d[0] = lane < nsample ? hd[lane] : 0.f; i[0] = lane < nsample ? hi[lane] : 0;
+        d[1] = lane + 64 < nsample ? hd[lane + 64] : 0.f; i[1] = lane + 64 < nsample ? hi[lane + 64] : 0;
+        write_rows<2>(o, q, nsample, d, i, lane, xyz, Q);
+        __syncthreads();
+    }
+}
+
+// scratch for the legacy (workspace-less) entry point
+int* g_legacy_ws = nullptr;
+size_t g_legacy_ws_ints = 0;
+
+}  // namespace
+
+// Workspace layout (ints): [0] tie counter, [1 .. m] tie list, then (grid path)
+// grids (b * 8 words), cell_start (b * (GRID_MAX_CELLS+1)), sorted float4 (n * 4 words, 16-B aligned).
+extern "C" size_t roitr_knn_workspace_bytes(int b, int n, int m)
+{
+    size_t ints = 1 + (size_t)m;
+    ints = (ints + 3) & ~(size_t)3;
+    ints += (size_t)b * 8 + (size_t)b * (GRID_MAX_CELLS + 1);
+    ints = (ints + 3) & ~(size_t)3;
+    ints += (size_t)n * 4;
+    return ints * 4 + 64;
+}
+
+namespace {
+struct WsView {
+    int* tie_count; int* tie_list; RoitrGrid* grids; int* cell_start; float4* sorted;
+};
+WsView carve(void* ws, int b, int n, int m)
+{
+    uintptr_t base = ((uintptr_t)ws + 15) & ~(uintptr_t)15;
+    int* p = (int*)base;
+    WsView v;
+    v.tie_count = p; v.tie_list = p + 1;
+    size_t ints = 1 + (size_t)m; ints = (ints + 3) & ~(size_t)3;
+    v.grids = (RoitrGrid*)(p + ints); ints += (size_t)b * 8;
+    v.cell_start = p + ints; ints += (size_t)b * (GRID_MAX_CELLS + 1);
+    ints = (ints + 3) & ~(size_t)3;
+    v.sorted = (float4*)(p + ints);
+    (void)n;
+    return v;
+}
+}  // namespace
+
+// Builds the per-cloud uniform grids for `xyz` (b clouds, n points) into `ws`; reusable by any number
+// of roitr_knnquery_grid calls on the same reference cloud set (same b, n, m-capacity carve).
+extern "C" int roitr_knn_build_grid(int b, int n, int m_capacity, const float* xyz, const int* offset, void* ws, hipStream_t stream)
+{
+    if (b <= 0 || n <= 0) return ROITR_OK;
+    WsView v = carve(ws, b, n, m_capacity);
+    grid_build_kernel<<<b, 1024, 0, stream>>>(xyz, offset, v.grids, v.cell_start, v.sorted, 3.0f);
+    ROITR_LAUNCH_CHECK();
+    return ROITR_OK;
+}
+
+// The general entry point.  use_grid != 0 requires a prior roitr_knn_build_grid on the same ws.
+// Outputs idx / dist2 / group_idx / ppf are each optional (null = not wanted).
+extern "C" int roitr_knnquery_ex(int b, int n, int m, int nsample, const float* xyz, const float* new_xyz, const int* offset,
+                                 const int* new_offset, int* idx, float* dist2, int* group_idx, float* ppf,
+                                 const float* ref_normals, const float* query_normals, int use_grid, int m_capacity, void* ws,
+                                 hipStream_t stream)
+{
+    if (m <= 0) return ROITR_OK;
+    if (nsample < 1 || nsample > 100) return ROITR_ERR_ARG;  // best_dist[100], knnquery_cuda_kernel.cu:86
+    if (ppf && (!ref_normals || !query_normals)) return ROITR_ERR_ARG;
+    WsView v = carve(ws, b, n, m_capacity);
+    KnnOut o = {idx, dist2, group_idx, ppf, ref_normals, query_normals, v.tie_count, v.tie_list};
+    ROITR_HIP(hipMemsetAsync(v.tie_count, 0, sizeof(int), stream));
+    const int blocks = div_up(m, 4);
+    if (use_grid) {
+        if (nsample + 1 <= 64)
+            knn_grid_kernel<1><<<blocks, 256, 0, stream>>>(m, nsample, xyz, new_xyz, offset, new_offset, v.grids, v.cell_start, v.sorted, o);
+        else
+            knn_grid_kernel<2><<<blocks, 256, 0, stream>>>(m, nsample, xyz, new_xyz, offset, new_offset, v.grids, v.cell_start, v.sorted, o);
+    } else {
+        if (nsample + 1 <= 64)
+            knn_brute_kernel<1><<<blocks, 256, 0, stream>>>(m, nsample, xyz, new_xyz, offset, new_offset, o);
+        else
+            knn_brute_kernel<2><<<blocks, 256, 0, stream>>>(m, nsample, xyz, new_xyz, offset, new_offset, o);
+    }
+    ROITR_LAUNCH_CHECK();
+    knn_replay_kernel<<<min(m, 128), 64, 0, stream>>>(nsample, xyz, new_xyz, offset, new_offset, o);
+    ROITR_LAUNCH_CHECK();
+    return ROITR_OK;
+}
+
+// Exact drop-in for knnquery_cuda_kernel.h:9-17: no batch count, no point count, no workspace, void
+// return, legacy default stream.  Brute-force path (segments are discovered on the device exactly as
+// the reference does); the tie scratch is a process-global buffer grown on demand.
+extern "C" void knnquery_cuda_launcher(int m, int nsample, const float* xyz, const float* new_xyz, const int* offset,
+                                       const int* new_offset, int* idx, float* dist2)
+{
+    if (m <= 0) return;
+    const size_t need = (size_t)m + 8;
+    if (need > g_legacy_ws_ints) {
+        if (g_legacy_ws) (void)hipFree(g_legacy_ws);
+        g_legacy_ws_ints = need * 2;
+        if (hipMalloc(&g_legacy_ws, g_legacy_ws_ints * sizeof(int)) != hipSuccess) {
+            roitr_set_error("hipMalloc failed (legacy knn scratch)", __FILE__, __LINE__);
+            g_legacy_ws = nullptr; g_legacy_ws_ints = 0;
+            return;
+        }
+    }
+    (void)roitr_knnquery_ex(0, 0, m, nsample, xyz, new_xyz, offset, new_offset, idx, dist2, nullptr, nullptr, nullptr, nullptr, 0, m,
+                            g_legacy_ws, nullptr);
+}

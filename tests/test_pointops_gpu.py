@@ -1,0 +1,215 @@
+"""GPU parity: HIP pointops (through the C ABI) vs the CPU oracle and the golden fixtures.
+
+Bar: bit-exact int32 indices and bit-exact fp32 squared distances for FPS / kNN (both follow the
+same documented fmaf form); PPF within 2e-6 absolute (atan2f/sqrtf device libm vs torch CPU).
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import pointops_cpu as O  # noqa: E402  (checker only)
+
+
+def dev(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.cuda()
+
+
+def cloud(rng, n, kind="uniform"):
+    if kind == "uniform":
+        return (rng.random((n, 3)) * 2).astype(np.float32)
+    if kind == "lattice":  # heavy exact ties
+        g = rng.integers(0, 6, (n, 3)).astype(np.float32) * 0.25
+        return g
+    if kind == "dup":  # duplicated points
+        base = (rng.random((max(n // 3, 1), 3)) * 2).astype(np.float32)
+        return base[rng.integers(0, len(base), n)]
+    if kind == "plane":
+        p = (rng.random((n, 3)) * 2).astype(np.float32)
+        p[:, 2] = 0.5
+        return p
+    raise ValueError(kind)
+
+
+@pytest.mark.parametrize("kind", ["uniform", "lattice", "dup", "plane"])
+@pytest.mark.parametrize("sizes", [[5000], [1250], [312], [78], [16], [1024, 700, 2049], [8000], [3, 1, 130]])
+def test_fps_bit_exact(kind, sizes):
+    from roitr_amd import pointops as P
+    rng = np.random.default_rng(hash((kind, tuple(sizes))) % 2**32)
+    xyz = np.concatenate([cloud(rng, n, kind) for n in sizes])
+    off = np.cumsum(sizes).astype(np.int32)
+    noff = np.cumsum([max(n // 4, 1) for n in sizes]).astype(np.int32)
+    ref = O.furthestsampling(xyz, off, noff)
+    got = P.furthestsampling(dev(xyz), dev(off), dev(noff)).cpu().numpy()
+    assert got.dtype == np.int32 and np.array_equal(got, ref)
+
+
+def test_fps_golden(golden_pair):
+    from roitr_amd import pointops as P
+    g = golden_pair
+    for side, base in (("src", 0), ("tgt", 3)):
+        p = dev(g[f"in.{side}_points"] if side == "tgt" else g["in.raw_src_pcd"])
+        n = p.shape[0]
+        for lvl in range(3):
+            o = torch.tensor([n], dtype=torch.int32).cuda()
+            no = torch.tensor([n // 4], dtype=torch.int32).cuda()
+            idx = P.furthestsampling(p, o, no)
+            assert np.array_equal(idx.cpu().numpy(), g[f"fps.{base + lvl}"])
+            p = p[idx.long()].contiguous()
+            n = n // 4
+
+
+@pytest.mark.parametrize("use_grid", [False, True])
+@pytest.mark.parametrize("kind", ["uniform", "lattice", "dup", "plane"])
+@pytest.mark.parametrize("case", [
+    # (ref sizes, query = self?, nsample)
+    ([5000], True, 9), ([5000], True, 17), ([1250], True, 17), ([312], True, 17), ([78], True, 17),
+    ([16], True, 17), ([5000], False, 17), ([5000], False, 3), ([5000], False, 1), ([900, 1500, 40], True, 9),
+    ([900, 1500, 40], False, 17), ([3000], True, 65), ([2000], True, 100), ([5], True, 3),
+])
+def test_knn_bit_exact(case, kind, use_grid):
+    from roitr_amd import pointops as P
+    sizes, self_q, ns = case
+    rng = np.random.default_rng(hash((kind, tuple(sizes), self_q, ns)) % 2**32)
+    xyz = np.concatenate([cloud(rng, n, kind) for n in sizes])
+    off = np.cumsum(sizes).astype(np.int32)
+    if self_q:
+        q, qoff = xyz, off
+    else:
+        qs = [max(n // 4, 1) for n in sizes]
+        # queries partly outside the reference bounding box
+        q = np.concatenate([cloud(rng, m, "uniform") * 1.3 - 0.3 for m in qs]).astype(np.float32)
+        qoff = np.cumsum(qs).astype(np.int32)
+    ridx, rd2 = O.knnquery_raw(ns, xyz, q, off, qoff, threads=8)
+    idx, d2 = P.knnquery_raw(ns, dev(xyz), dev(q), dev(off), dev(qoff), use_grid=use_grid)
+    idx, d2 = idx.cpu().numpy(), d2.cpu().numpy()
+    assert np.array_equal(d2, rd2), f"dist2 mismatch rows={np.unique(np.nonzero(d2 != rd2)[0])[:10]}"
+    assert np.array_equal(idx, ridx), f"idx mismatch rows={np.unique(np.nonzero(idx != ridx)[0])[:10]}"
+
+
+def test_knn_golden(golden_pair):
+    from roitr_amd import pointops as P
+    g = golden_pair
+    # first calls of the forward: enc1 TransitionDown self-kNN(9) on the raw source cloud
+    p = dev(g["in.raw_src_pcd"])
+    o = torch.tensor([p.shape[0]], dtype=torch.int32).cuda()
+    idx, dist = P.knnquery(9, p, p, o, o)
+    assert np.array_equal(idx.cpu().numpy(), g["knn.0.idx"])
+    np.testing.assert_array_equal(dist.cpu().numpy(), g["knn.0.dist"])
+
+
+def test_knn_ppf_fused_matches_golden(golden_pair):
+    from roitr_amd import pointops as P
+    g = golden_pair
+    p, n = dev(g["in.raw_src_pcd"]), dev(g["in.src_normals"])
+    o = torch.tensor([p.shape[0]], dtype=torch.int32).cuda()
+    grp, ppf = P.knn_ppf(8, p, p, n, n, o, o)
+    assert np.array_equal(grp.cpu().numpy(), g["knn.0.idx"][:, 1:])
+    np.testing.assert_allclose(ppf.cpu().numpy(), g["ppf.0"], rtol=0, atol=2e-6)
+
+
+def test_ppf_stage_golden(golden_stages):
+    """calc_ppf_gpu known answers incl. the atan2(0,0) and parallel-normal corner cases."""
+    from roitr_amd import pointops as P
+    s = golden_stages
+    pts, nrm, patches, pn = s["ppf.pts"], s["ppf.nrm"], s["ppf.patches"], s["ppf.pnrm"]
+    m, k, _ = patches.shape
+    # lay the patches out as a reference cloud and query with explicit group indices via kNN-free path:
+    # reference cloud = [patches reshaped], each centre's neighbours are its own k rows
+    from roitr_amd import ops
+    grp = torch.arange(m * k, dtype=torch.int32).view(m, k).cuda()
+    out = ops.calc_ppf(dev(pts), dev(nrm), dev(patches.reshape(-1, 3)), dev(pn.reshape(-1, 3)), grp)
+    np.testing.assert_allclose(out.cpu().numpy(), s["ppf.out"], rtol=0, atol=2e-6)
+
+
+def test_interpolation_matches_oracle():
+    from roitr_amd import pointops as P
+    rng = np.random.default_rng(5)
+    xyz = cloud(rng, 312)
+    new = cloud(rng, 1250)
+    feat = rng.normal(0, 1, (312, 64)).astype(np.float32)
+    o, no = np.array([312], np.int32), np.array([1250], np.int32)
+    ref = O.interpolation(xyz, new, feat, o, no)
+    got = P.interpolation(dev(xyz), dev(new), dev(feat), dev(o), dev(no)).cpu().numpy()
+    np.testing.assert_allclose(got, ref, rtol=1e-5, atol=1e-6)
+
+
+def test_cold_ops_match_oracle():
+    from roitr_amd import pointops as P
+    rng = np.random.default_rng(11)
+    n, ns, c, wc = 200, 8, 32, 8
+    inp = rng.normal(0, 1, (n, c)).astype(np.float32)
+    inp2 = rng.normal(0, 1, (n, c)).astype(np.float32)
+    pos = rng.normal(0, 1, (n, ns, c)).astype(np.float32)
+    w = rng.normal(0, 1, (n, ns, wc)).astype(np.float32)
+    idx = rng.integers(0, n, (n, ns)).astype(np.int32)
+    g3 = rng.normal(0, 1, (n, ns, c)).astype(np.float32)
+    g2 = rng.normal(0, 1, (n, c)).astype(np.float32)
+    tin, tin2, tpos, tw, tidx = dev(inp), dev(inp2), dev(pos), dev(w), dev(idx)
+
+    x = tin.clone().requires_grad_(True)
+    out = P.grouping(x, tidx)
+    assert np.array_equal(out.detach().cpu().numpy(), O.grouping_forward(inp, idx))
+    out.backward(dev(g3))
+    np.testing.assert_allclose(x.grad.cpu().numpy(), O.grouping_backward(g3, idx, n), rtol=1e-5, atol=1e-5)
+
+    a, b = tin.clone().requires_grad_(True), tin2.clone().requires_grad_(True)
+    out = P.subtraction(a, b, tidx)
+    assert np.array_equal(out.detach().cpu().numpy(), O.subtraction_forward(inp, inp2, idx))
+    out.backward(dev(g3))
+    r1, r2 = O.subtraction_backward(idx, g3)
+    np.testing.assert_allclose(a.grad.cpu().numpy(), r1, rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(b.grad.cpu().numpy(), r2, rtol=1e-5, atol=1e-5)
+
+    a, p_, w_ = tin.clone().requires_grad_(True), tpos.clone().requires_grad_(True), tw.clone().requires_grad_(True)
+    out = P.aggregation(a, p_, w_, tidx)
+    np.testing.assert_allclose(out.detach().cpu().numpy(), O.aggregation_forward(inp, pos, w, idx), rtol=1e-5, atol=1e-5)
+    out.backward(dev(g2))
+    ri, rp, rw = O.aggregation_backward(inp, pos, w, idx, g2)
+    np.testing.assert_allclose(a.grad.cpu().numpy(), ri, rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(p_.grad.cpu().numpy(), rp, rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(w_.grad.cpu().numpy(), rw, rtol=1e-4, atol=1e-4)
+
+    # interpolation2 (native forward/backward)
+    xyz, new = cloud(rng, 100), cloud(rng, 300)
+    feat = rng.normal(0, 1, (100, 16)).astype(np.float32)
+    o, no = np.array([100], np.int32), np.array([300], np.int32)
+    f = dev(feat).requires_grad_(True)
+    out = P.interpolation2(dev(xyz), dev(new), f, dev(o), dev(no), 3)
+    np.testing.assert_allclose(out.detach().cpu().numpy(), O.interpolation(xyz, new, feat, o, no), rtol=1e-5, atol=1e-6)
+    go = rng.normal(0, 1, (300, 16)).astype(np.float32)
+    out.backward(dev(go))
+    kidx, kd = O.knnquery(3, xyz, new, o, no)
+    rec = 1.0 / (kd + 1e-8)
+    wgt = (rec / rec.sum(1, keepdims=True)).astype(np.float32)
+    np.testing.assert_allclose(f.grad.cpu().numpy(), O.interpolation_backward(go, kidx, wgt, 100), rtol=1e-4, atol=1e-5)
+
+
+def test_legacy_launchers_exact_names():
+    """The reference's own extern "C" symbols (void, default stream) work as drop-ins."""
+    import ctypes
+    from roitr_amd import _lib as L
+    rng = np.random.default_rng(3)
+    xyz = cloud(rng, 700)
+    off = np.array([300, 700], np.int32)
+    noff = np.array([75, 175], np.int32)
+    lib = L.lib()
+    txyz, toff, tnoff = dev(xyz), dev(off), dev(noff)
+    idx = torch.zeros(175, dtype=torch.int32).cuda()
+    tmp = torch.full((700,), 1e10).cuda()
+    torch.cuda.synchronize()
+    lib.furthestsampling_cuda_launcher(2, 400, L.ptr(txyz), L.ptr(toff), L.ptr(tnoff), L.ptr(tmp), L.ptr(idx))
+    torch.cuda.synchronize()
+    assert np.array_equal(idx.cpu().numpy(), O.furthestsampling(xyz, off, noff))
+    new = txyz[idx.long()].contiguous()
+    kidx = torch.zeros((175, 17), dtype=torch.int32).cuda()
+    kd2 = torch.zeros((175, 17), dtype=torch.float32).cuda()
+    torch.cuda.synchronize()
+    lib.knnquery_cuda_launcher(175, 17, L.ptr(txyz), L.ptr(new), L.ptr(toff), L.ptr(tnoff), L.ptr(kidx), L.ptr(kd2))
+    torch.cuda.synchronize()
+    ridx, rd2 = O.knnquery_raw(17, xyz, new.cpu().numpy(), off, noff)
+    assert np.array_equal(kidx.cpu().numpy(), ridx) and np.array_equal(kd2.cpu().numpy(), rd2)
