@@ -1,0 +1,218 @@
+/*
+ * roitr_engine.h -- C ABI of libroitr_hip.so, part 2: the fused stage operators of the RoITr
+ * inference path and the whole-pair engine (boundary B2 of SURVEY.md 8(b), restated as C entry
+ * points so a host in any language can drive the path; the roitr_amd Python package is one).
+ *
+ * Conventions: device pointers to contiguous fp32 / int32; caller owns all memory; every call is
+ * asynchronous on `stream` and returns 0 or an error code (text via roitr_last_error()).
+ * Citations are into /root/reference.
+ */
+#ifndef ROITR_ENGINE_H
+#define ROITR_ENGINE_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#ifndef ROITR_POINTOPS_H
+typedef struct ihipStream_t* roitr_stream_t;
+#endif
+
+/* ------------------------------------------------------------------ dense layers (nn.Linear) */
+/* C[b] = act(alpha * (A[b] (+A2[b])) @ W[b]^T + bias[b]);  A (M,K) lda, W (N,K) ldw, C (M,N) ldc.
+ * a_idx / w_idx: optional int32 row gathers; an index < 0 or >= *_limit (when *_limit > 0) reads
+ * a zero row (the reference's zero-padded patch rows, model/RIGA_v2.py:129-142). */
+typedef struct RoitrGemm {
+    int M, N, K;
+    const float* A; const float* A2; int lda; const int* a_idx; int a_limit;
+    const float* W; int ldw; const int* w_idx; int w_limit;
+    const float* bias; float alpha; int relu;
+    float* C; int ldc;
+    int batch; long sA, sW, sC, sBias, sAidx, sWidx;
+} RoitrGemm;
+int roitr_gemm(const RoitrGemm* g, roitr_stream_t stream);
+
+/* ------------------------------------------------------------------ row-wise layers */
+/* out = act( LayerNorm(x + res[res_idx]) * gamma + beta (+ post_add) ); res, res_idx, post_add optional.
+ * attention.py:319, model/model.py:138-140 (bn2, += identity, relu), geoattention.py:50,161,241. */
+int roitr_add_layernorm(int M, int C, const float* x, const float* res, const int* res_idx, const float* gamma,
+                        const float* beta, const float* post_add, int relu, float eps, float* out, roitr_stream_t stream);
+/* F.normalize(p=2, dim=1), model/RIGA_v2.py:64-65 */
+int roitr_l2_normalize(int M, int C, const float* x, float* out, roitr_stream_t stream);
+int roitr_transpose(int rows, int cols, const float* in, int ld_in, float* out, int ld_out, roitr_stream_t stream);
+/* out = base + 3-NN inverse-distance interpolation of feat (functions/pointops.py:168-182 + model/model.py:116);
+ * dist2 = SQUARED distances as produced by the kNN call. */
+int roitr_interp3_add(int n, int C, const float* feat, const int* idx, const float* dist2, const float* base, float* out,
+                      roitr_stream_t stream);
+/* per-cloud feature mean (model/model.py:101-109) */
+int roitr_segment_mean(int b, int C, const float* x, const int* offset, float* out, roitr_stream_t stream);
+/* SinusoidalPositionalEmbedding (positional_encoding.py:38-62): out (rows, C) */
+int roitr_sinusoid(long rows, int C, const float* vals, const float* div_term, float* out, roitr_stream_t stream);
+/* E = P_d + max_k P_a[:, k, :] (positional_encoding.py:146-152) */
+int roitr_geo_combine(long rows, int C, int k, const float* pd, const float* pa, float* out, roitr_stream_t stream);
+int roitr_gather_rows(long rows, int C, const float* in, const int* idx, int limit, float* out, roitr_stream_t stream);
+int roitr_compose_idx(int n, const int* outer, const int* inner, int* out, roitr_stream_t stream);
+/* lib/utils.py:358-389 with the gather fused: out (m,k,4) */
+int roitr_calc_ppf(int m, int k, const float* centre_xyz, const float* centre_normals, const float* ref_xyz,
+                   const float* ref_normals, const int* group_idx, float* out, roitr_stream_t stream);
+
+/* ------------------------------------------------------------------ local PPF attention */
+/* attention.py:152-200 with the positional branch folded (see csrc/local_attn.hip).
+ * q: (M, >= H + 5*heads) rows = [q | per head: Wpe_h^T q_h (4), q_h.bpe_h (1)]; k, v: rows of the input
+ * cloud (ld given); group_idx (M,K) int32; ppf (M,K,4); wvpe (H,4), bvpe (H); out (M,H).
+ * scale = 1/sqrt(H/heads). */
+typedef struct RoitrLocalAttn {
+    int M, K, H, heads;
+    const float* q; int ldq;
+    const float* k; int ldk;
+    const float* v; int ldv;
+    const int* group_idx; const float* ppf;
+    const float* wvpe; const float* bvpe;
+    float scale;
+    float* out; int ldo;
+} RoitrLocalAttn;
+int roitr_local_attention(const RoitrLocalAttn* a, roitr_stream_t stream);
+int roitr_build_pfold(int H, int heads, const float* wpe, const float* bpe, float* pfold, roitr_stream_t stream);
+
+/* ------------------------------------------------------------------ global geometric transformer */
+/* positional_encoding.py:110-137 get_embedding_indices for a batch of clouds.  pts (rows,3) = all nodes,
+ * offset (b) cumulative, cloud_of_row (rows), eoff (b) = element offset of cloud c's (n_c, n_c) block.
+ * d_idx: concatenated (n_c, n_c); a_idx: concatenated (n_c, n_c, angle_k). */
+int roitr_geo_indices(int rows, const float* pts, const int* offset, const int* cloud_of_row, const long* eoff,
+                      float sigma_d, float sigma_a, int angle_k, int n_max, float* d_idx, float* a_idx, roitr_stream_t stream);
+
+/* Multi-head attention, query rows [q_row0, q_row0 + q_rows) of the concatenated node array.
+ * Keys/values of query row r are the rows of cloud partner[cloud_of_row[r]] (partner == NULL: own cloud).
+ * Without E: geoattention.py:26-66 (cross attention; q/k already hold the +pos inputs).
+ * With E (n_c,n_c,C per cloud at eoff): geoattention.py:87-136 with the RPE branch folded --
+ *   qt (rows, heads, C) = Wp_h^T q_h,  bp (C) = proj_p.bias,  ebar (rows, heads, C) = sum_j a'_ij E_ij
+ *   where a' is the diagonal-masked softmax; the caller finishes pos_states = Wvp_h ebar_h + bvp_h. */
+typedef struct RoitrMha {
+    int q_row0, q_rows, C, heads;
+    const float* q; int ldq;
+    const float* k; int ldk;
+    const float* v; int ldv;
+    const int* offset; const int* cloud_of_row; const int* partner;
+    const float* E; const long* eoff; const float* qt; const float* bp;
+    float scale; int nk_max;
+    float* out; int ldo;
+    float* ebar;
+} RoitrMha;
+int roitr_mha(const RoitrMha* a, roitr_stream_t stream);
+
+/* ------------------------------------------------------------------ coarse-to-fine matching tail */
+/* Cloud layout for every batched call below: [src_0 .. src_{B-1}, tgt_0 .. tgt_{B-1}], B = pairs. */
+
+/* lib/utils.py:428-471.  p2n (n_points) node index local to the cloud; knn_idx (n_nodes, limit) point index
+ * local to the cloud, padded with the cloud's point count; masks are int32 0/1. */
+int roitr_point_to_node_partition(int b, int n_points, int n_nodes, const float* pts, const int* pt_offset,
+                                  const float* nodes, const int* node_offset, const int* cloud_of_node, int limit,
+                                  int* p2n, float* p2n_dist, int* node_masks, int* knn_idx, int* knn_mask, roitr_stream_t stream);
+
+/* model/modules.py:141-178 CoarseMatching (ref = tgt, src = src as called at RIGA_v2.py:121).
+ * feats (n_nodes, C) L2-normalised; outputs (pairs, num_corr): node indices local to their cloud (-1 beyond
+ * n_corr[pair]), scores.  scratch: pairs * scratch_stride floats, stride >= roitr_coarse_scratch_floats(). */
+typedef struct RoitrCoarse {
+    int pairs, C, num_corr, dual_norm, max_ref, max_src;
+    const float* feats; const int* node_offset; const int* node_masks;
+    float* scratch; long scratch_stride;
+    int* tgt_corr; int* src_corr; float* corr_scores; int* n_corr;
+} RoitrCoarse;
+size_t roitr_coarse_scratch_floats(int n_ref, int n_src);
+int roitr_coarse_matching(const RoitrCoarse* a, roitr_stream_t stream);
+
+/* model/RIGA_v2.py:125-147: per patch correspondence the `limit` point rows / points / masks of both sides.
+ * rows index the concatenated point arrays (-1 = the zero pad row). */
+typedef struct RoitrPatch {
+    int pairs, num_corr, limit;
+    const int* n_corr; const int* tgt_corr; const int* src_corr;
+    const int* node_offset; const int* pt_offset; const int* knn_idx; const int* knn_mask; const float* points;
+    int* tgt_rows; int* src_rows; int* tgt_masks; int* src_masks; float* tgt_pts; float* src_pts;
+} RoitrPatch;
+int roitr_patch_gather(const RoitrPatch* a, roitr_stream_t stream);
+
+/* model/modules.py:10-72 LearnableLogOptimalTransport: scores (patches, limit, limit) -> out (patches, limit+1, limit+1) */
+typedef struct RoitrOT {
+    int pairs, num_corr, limit, num_iter;
+    const int* n_corr; const float* scores; const int* row_masks; const int* col_masks; const float* alpha;
+    float* out;
+} RoitrOT;
+int roitr_optimal_transport(const RoitrOT* a, roitr_stream_t stream);
+
+/* model/modules.py:216-324 FineMatching (use_dustbin = False).  ot = the OT output; rows = tgt, cols = src.
+ * Emits correspondences in (patch, row, col) order; offsets[patch] = first output slot of the patch. */
+typedef struct RoitrFine {
+    int pairs, num_corr, limit, k, mutual;
+    float conf;
+    const int* n_corr; const float* ot; const int* row_masks; const int* col_masks;
+    const float* row_pts; const float* col_pts; const float* global_scores;
+    unsigned char* flags; int* counts; int* offsets; int* n_out;
+    float* out_row_pts; float* out_col_pts; float* out_scores; int* out_patch;
+} RoitrFine;
+int roitr_fine_matching(const RoitrFine* a, roitr_stream_t stream);
+
+/* ------------------------------------------------------------------ the whole-pair engine */
+/* One engine = one set of weights + its workspace on the current device.  Drives the complete test-mode
+ * forward of model/RIGA_v2.py:58-175 for a batch of B independent pairs with HIP kernels only.
+ *
+ * Parameters are registered by their reference state_dict key (e.g.
+ * "backbone.enc2.0.transformer.transformer.attention.proj_p.weight", lib/trainer.py:94-130 layout) as
+ * device pointers that must stay valid while the engine lives. */
+typedef struct RoitrEngineConfig {
+    int factor;            /* 1 = 3DMatch, 2 = 4DMatch (model/RIGA_v2.py:24,28) */
+    int num_corr;          /* num_est_coarse_corr */
+    int point_limit;       /* point_per_patch (64) */
+    int fine_topk, fine_mutual, fine_use_global_score;
+    float fine_conf;       /* fine_matching_confidence_threshold */
+    int n_geo_layers;      /* len(transformer_architecture) */
+    int geo_is_cross[16];  /* 0 = 'self', 1 = 'cross' */
+    float matching_radius; /* coarse_matching.matching_radius (GT helpers) */
+    int adaptive_coarse;   /* 1 = AdaptiveSuperPointMatching (4DMatch) -- not implemented yet */
+    float occlusion_radius;/* lib/utils.py:485 overlap_thres */
+} RoitrEngineConfig;
+
+typedef struct RoitrForwardIO {
+    int pairs;                 /* B */
+    const int* n_points;       /* host array, 2B entries: src_0..src_{B-1}, tgt_0..tgt_{B-1} */
+    /* inputs, device, clouds concatenated in that order */
+    const float* points_geom;  /* (T,3): src_raw_pcd / tgt_pcd (model/RIGA_v2.py:62) */
+    const float* normals;      /* (T,3) */
+    const float* feats;        /* (T,1) */
+    const float* points_out;   /* (T,3): src_pcd / tgt_pcd; NULL = points_geom */
+    const float* rot;          /* (B,3,3) or NULL: skips the ground-truth side outputs */
+    const float* trans;        /* (B,3) */
+    /* outputs, device, caller-allocated; any may be NULL.  T4 = total nodes, P = num_corr, L = point_limit */
+    float* node_xyz;           /* (T4,3) */
+    float* node_feats;         /* (T4, 256f) */
+    float* point_feats;        /* (T, 256f) */
+    int* node_masks;           /* (T4) */
+    int* node_knn_idx;         /* (T4, L) local point indices, pad = cloud size */
+    int* node_knn_mask;        /* (T4, L) */
+    int* tgt_corr; int* src_corr; float* corr_scores; int* n_corr;   /* (B,P) x3, (B) */
+    float* tgt_knn_pts; float* src_knn_pts;    /* (B,P,L,3) */
+    int* tgt_knn_masks; int* src_knn_masks;    /* (B,P,L) */
+    float* matching_scores;    /* (B,P,L+1,L+1) */
+    float* out_tgt_pts; float* out_src_pts; float* out_scores; int* out_patch;  /* capacity B*P*L*fine_topk rows */
+    int* fine_offsets;         /* (B*P) first output row of every patch */
+    int* n_out;                /* (1) total correspondences */
+    float* gt_tgt_occ; float* gt_src_occ;      /* (T4 halves) node occlusion scores, need rot/trans */
+} RoitrForwardIO;
+
+void* roitr_engine_create(const RoitrEngineConfig* cfg);
+void roitr_engine_destroy(void* engine);
+int roitr_engine_set_param(void* engine, const char* name, const float* device_ptr, long numel);
+int roitr_engine_finalize(void* engine, roitr_stream_t stream);
+int roitr_engine_forward(void* engine, const RoitrForwardIO* io, roitr_stream_t stream);
+/* Test taps: after stage `name` its output tensor is copied to `device_ptr` (NULL removes the tap);
+ * inject: the stage output is REPLACED by the tensor at device_ptr before the forward continues. */
+int roitr_engine_set_tap(void* engine, const char* name, void* device_ptr);
+int roitr_engine_set_inject(void* engine, const char* name, const void* device_ptr);
+/* level sizes the engine will use for a cloud of n points: out[0..3] (model/model.py:59-62 floor rule) */
+void roitr_level_sizes(int n, int* out4);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ROITR_ENGINE_H */

@@ -1,0 +1,846 @@
+// Whole-pair RoITr inference engine: host-side orchestration of the HIP kernels of this library.
+//
+// Reference path restated (file:line into /root/reference):
+//   RIGA_v2.forward                      model/RIGA_v2.py:58-175
+//   RIPointTransformer.forward           model/model.py:187-237
+//   TransitionDown / Block / TransitionUp model/model.py:47-142
+//   LocalPPFTransformer                  model/transformer/ppftransformer.py:202-253
+//   GeometricTransformer                 model/transformer/geotransformer.py:94-133
+//
+// Execution model: B independent pairs per call, every kernel batched over the 2B clouds laid out
+// [src_0..src_{B-1}, tgt_0..tgt_{B-1}] with cumulative offsets per hierarchy level (the reference's
+// own `offset` convention, one level deeper: it batches clouds through pointops but runs one pair per
+// forward).  No host synchronisation inside the forward: level sizes follow from the input sizes
+// (model/model.py:59-62), data-dependent counts stay on the device.  All scratch comes from one
+// arena sized from the input sizes; derived (folded / concatenated) weights are built once in finalize.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "common.h"
+#include "roitr_engine.h"
+#include "roitr_pointops.h"
+
+extern "C" int roitr_build_pfold(int H, int heads, const float* wpe, const float* bpe, float* pfold, hipStream_t stream);
+
+#define CHK(x)                    \
+    do {                          \
+        int s__ = (x);            \
+        if (s__ != 0) return s__; \
+    } while (0)
+
+namespace {
+
+constexpr int HEADS = 4;
+constexpr int GRID_MIN_POINTS = 768;  // clouds at or below this are scanned brute force
+
+struct Lin {
+    const float* w = nullptr; const float* b = nullptr; int out = 0, in = 0;
+};
+
+struct LocalT {  // LocalPPFTransformer (+ derived weights)
+    Lin emb, in_proj, q, k, v, p, vp, lin, out_proj;
+    const float* norm_w = nullptr; const float* norm_b = nullptr;
+    int in_dim = 0, H = 0, out_dim = 0;
+    float* wqkv = nullptr;  // rows: [Wq (H) ; Wqp (5*HEADS) ; Wk (H) ; Wv (H)] x H
+    float* bqkv = nullptr;
+    float* wvpe = nullptr;  // (H,4)
+    float* bvpe = nullptr;  // (H)
+    const float* bn2_w = nullptr; const float* bn2_b = nullptr;  // block only
+};
+
+struct Up {  // TransitionUp
+    Lin l1, l2; const float* l1n_w = nullptr; const float* l1n_b = nullptr; const float* l2n_w = nullptr; const float* l2n_b = nullptr;
+};
+
+struct Ffn {
+    Lin expand, squeeze; const float* n_w = nullptr; const float* n_b = nullptr;
+};
+
+struct GeoLayer {
+    bool cross = false;
+    Lin q, k, v, p, vp, lin, pos_lin;
+    const float *n_w = nullptr, *n_b = nullptr, *pn_w = nullptr, *pn_b = nullptr;
+    Ffn out, pos;
+    float* wqkv = nullptr; float* bqkv = nullptr;  // self: [Wq;Wk;Wv]
+    float* wpT = nullptr;                          // self: transpose(Wp)
+};
+
+struct Arena {
+    char* base = nullptr; size_t cap = 0, off = 0;
+    bool fail = false;
+    template <typename T> T* get(size_t count)
+    {
+        const size_t bytes = (count * sizeof(T) + 255) & ~(size_t)255;
+        if (off + bytes > cap) { fail = true; return (T*)base; }
+        T* p = (T*)(base + off);
+        off += bytes;
+        return p;
+    }
+};
+
+struct Engine {
+    RoitrEngineConfig cfg;
+    std::map<std::string, std::pair<const float*, long>> params;
+    std::map<std::string, void*> taps;
+    std::map<std::string, const void*> injects;
+    bool finalized = false;
+    int planes[4];
+    int nblocks[4] = {2, 3, 3, 3};
+    int nsample[4] = {8, 16, 16, 16};
+    LocalT enc[4][3];
+    LocalT dec[4];
+    Up up[4];
+    Lin geo_in, geo_out, proj_d, proj_a, coarse_proj, fine_proj;
+    const float* geo_div = nullptr;
+    float* geo_div_own = nullptr;
+    std::vector<GeoLayer> geo;
+    const float* ot_alpha = nullptr;
+    Arena warena;  // derived weights
+    Arena arena;   // per-forward scratch
+    static constexpr int RING = 4;   // descriptor staging slots: the host may run RING forwards ahead
+    char* pinned[RING] = {nullptr, nullptr, nullptr, nullptr}; size_t pinned_cap[RING] = {0, 0, 0, 0};
+    hipEvent_t pinned_ev[RING] = {nullptr, nullptr, nullptr, nullptr};
+    int ring_pos = 0;
+    std::string err;
+};
+
+const float* P(Engine& E, const std::string& name, long expect)
+{
+    auto it = E.params.find(name);
+    if (it == E.params.end()) { if (E.err.empty()) E.err = "missing parameter " + name; return nullptr; }
+    if (expect > 0 && it->second.second != expect) {
+        if (E.err.empty()) E.err = "parameter " + name + " has " + std::to_string(it->second.second) + " elements, expected " + std::to_string(expect);
+        return nullptr;
+    }
+    return it->second.first;
+}
+
+Lin lin(Engine& E, const std::string& prefix, int out, int in)
+{
+    Lin l;
+    l.w = P(E, prefix + ".weight", (long)out * in);
+    l.b = P(E, prefix + ".bias", out);
+    l.out = out; l.in = in;
+    return l;
+}
+
+int gemm(hipStream_t st, int M, int N, int K, const float* A, int lda, const float* W, int ldw, const float* bias, float* C, int ldc,
+         bool relu = false, const int* a_idx = nullptr, const float* A2 = nullptr, float alpha = 1.0f)
+{
+    RoitrGemm g;
+    memset(&g, 0, sizeof(g));
+    g.M = M; g.N = N; g.K = K; g.A = A; g.A2 = A2; g.lda = lda; g.a_idx = a_idx; g.W = W; g.ldw = ldw; g.bias = bias;
+    g.alpha = alpha; g.relu = relu ? 1 : 0; g.C = C; g.ldc = ldc; g.batch = 1;
+    return roitr_gemm(&g, st);
+}
+int gemm(hipStream_t st, int M, const float* A, const Lin& l, float* C, bool relu = false, const int* a_idx = nullptr, const float* A2 = nullptr)
+{
+    return gemm(st, M, l.out, l.in, A, l.in, l.w, l.in, l.b, C, l.out, relu, a_idx, A2);
+}
+
+int d2d(hipStream_t st, void* dst, const void* src, size_t bytes)
+{
+    ROITR_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, st));
+    return 0;
+}
+
+int tap(Engine& E, hipStream_t st, const std::string& name, void* data, size_t bytes)
+{
+    auto ij = E.injects.find(name);
+    if (ij != E.injects.end() && ij->second) CHK(d2d(st, data, ij->second, bytes));
+    auto it = E.taps.find(name);
+    if (it != E.taps.end() && it->second) CHK(d2d(st, it->second, data, bytes));
+    return 0;
+}
+
+// ---------------------------------------------------------------- weight resolution + folding
+int resolve_local(Engine& E, LocalT& L, const std::string& pre, int in_dim, int H, int out_dim)
+{
+    L.in_dim = in_dim; L.H = H; L.out_dim = out_dim;
+    L.emb = lin(E, pre + ".embedding.proj", H, 4);
+    L.in_proj = lin(E, pre + ".in_proj", H, in_dim);
+    const std::string at = pre + ".transformer.attention";
+    L.q = lin(E, at + ".proj_q", H, H); L.k = lin(E, at + ".proj_k", H, H); L.v = lin(E, at + ".proj_v", H, H);
+    L.p = lin(E, at + ".proj_p", H, H); L.vp = lin(E, at + ".proj_vp", H, H);
+    L.lin = lin(E, pre + ".transformer.linear", H, H);
+    L.norm_w = P(E, pre + ".transformer.norm.weight", H); L.norm_b = P(E, pre + ".transformer.norm.bias", H);
+    L.out_proj = lin(E, pre + ".out_proj", out_dim, H);
+    return E.err.empty() ? 0 : ROITR_ERR_ARG;
+}
+
+int fold_local(Engine& E, LocalT& L, hipStream_t st)
+{
+    const int H = L.H, NQ = 5 * HEADS;
+    Arena& A = E.warena;
+    float* weT = A.get<float>(4 * (size_t)H);
+    float* wpeT = A.get<float>(4 * (size_t)H);
+    float* wpe = A.get<float>(4 * (size_t)H);
+    float* bpe = A.get<float>(H);
+    float* wvpeT = A.get<float>(4 * (size_t)H);
+    L.wvpe = A.get<float>(4 * (size_t)H);
+    L.bvpe = A.get<float>(H);
+    float* pfold = A.get<float>((size_t)NQ * H);
+    float* wqT = A.get<float>((size_t)H * H);
+    const int R = 3 * H + NQ;
+    L.wqkv = A.get<float>((size_t)R * H);
+    L.bqkv = A.get<float>(R);
+    if (A.fail) return ROITR_ERR_ARG;
+    // Wpe^T (4,H) = We^T (4,H) @ Wp^T ; bpe = Wp be + bp        (see csrc/local_attn.hip)
+    CHK(roitr_transpose(H, 4, L.emb.w, 4, weT, H, st));
+    CHK(gemm(st, 4, H, H, weT, H, L.p.w, H, nullptr, wpeT, H));
+    CHK(roitr_transpose(4, H, wpeT, H, wpe, 4, st));
+    CHK(gemm(st, 1, H, H, L.emb.b, H, L.p.w, H, L.p.b, bpe, H));
+    CHK(gemm(st, 4, H, H, weT, H, L.vp.w, H, nullptr, wvpeT, H));
+    CHK(roitr_transpose(4, H, wvpeT, H, L.wvpe, 4, st));
+    CHK(gemm(st, 1, H, H, L.emb.b, H, L.vp.w, H, L.vp.b, L.bvpe, H));
+    // Wqp = Pfold @ Wq ; bqp = Pfold @ bq
+    CHK(roitr_build_pfold(H, HEADS, wpe, bpe, pfold, st));
+    CHK(roitr_transpose(H, H, L.q.w, H, wqT, H, st));
+    CHK(d2d(st, L.wqkv, L.q.w, sizeof(float) * (size_t)H * H));
+    CHK(gemm(st, NQ, H, H, pfold, H, wqT, H, nullptr, L.wqkv + (size_t)H * H, H));
+    CHK(d2d(st, L.wqkv + (size_t)(H + NQ) * H, L.k.w, sizeof(float) * (size_t)H * H));
+    CHK(d2d(st, L.wqkv + (size_t)(2 * H + NQ) * H, L.v.w, sizeof(float) * (size_t)H * H));
+    CHK(d2d(st, L.bqkv, L.q.b, sizeof(float) * H));
+    CHK(gemm(st, 1, NQ, H, L.q.b, H, pfold, H, nullptr, L.bqkv + H, NQ));
+    CHK(d2d(st, L.bqkv + H + NQ, L.k.b, sizeof(float) * H));
+    CHK(d2d(st, L.bqkv + 2 * H + NQ, L.v.b, sizeof(float) * H));
+    return 0;
+}
+
+Ffn ffn(Engine& E, const std::string& pre, int C)
+{
+    Ffn f;
+    f.expand = lin(E, pre + ".expand", 2 * C, C);
+    f.squeeze = lin(E, pre + ".squeeze", C, 2 * C);
+    f.n_w = P(E, pre + ".norm.weight", C); f.n_b = P(E, pre + ".norm.bias", C);
+    return f;
+}
+
+// ---------------------------------------------------------------- per-forward geometry
+struct Levels {
+    int B = 0, NC = 0;                 // pairs, clouds
+    std::vector<int> n[4];             // per cloud sizes per level (0-based level index = enc level - 1)
+    std::vector<int> off[4];           // cumulative
+    int T[4] = {0, 0, 0, 0};
+    int nmax[4] = {0, 0, 0, 0};
+};
+
+struct Dev {  // device-resident descriptors
+    int* off[4]; int* cloud_of_node; int* partner; long* eoff; int* cloud_ids;
+};
+
+// LocalPPFTransformer.forward (ppftransformer.py:227-253) on N_in input rows -> M node rows
+int local_transformer(Engine& E, hipStream_t st, const LocalT& L, int N_in, const float* x, int M, const int* node_idx, const int* group,
+                      const float* ppf, int K, float* out)
+{
+    Arena& A = E.arena;
+    const size_t mark = A.off;
+    const int H = L.H, NQ = 5 * HEADS;
+    float* f = A.get<float>((size_t)N_in * H);
+    CHK(gemm(st, N_in, x, L.in_proj, f));
+    const float *q, *k, *v; int ldq, ldkv;
+    if (!node_idx) {
+        const int R = 3 * H + NQ;
+        float* qkv = A.get<float>((size_t)N_in * R);
+        if (A.fail) return ROITR_ERR_ARG;
+        CHK(gemm(st, N_in, R, H, f, H, L.wqkv, H, L.bqkv, qkv, R));
+        q = qkv; k = qkv + H + NQ; v = qkv + 2 * H + NQ; ldq = R; ldkv = R;
+    } else {
+        float* qe = A.get<float>((size_t)M * (H + NQ));
+        float* kv = A.get<float>((size_t)N_in * 2 * H);
+        if (A.fail) return ROITR_ERR_ARG;
+        CHK(gemm(st, M, H + NQ, H, f, H, L.wqkv, H, L.bqkv, qe, H + NQ, false, node_idx));
+        CHK(gemm(st, N_in, 2 * H, H, f, H, L.wqkv + (size_t)(H + NQ) * H, H, L.bqkv + H + NQ, kv, 2 * H));
+        q = qe; k = kv; v = kv + H; ldq = H + NQ; ldkv = 2 * H;
+    }
+    float* att = A.get<float>((size_t)M * H);
+    float* hid = A.get<float>((size_t)M * H);
+    float* y = A.get<float>((size_t)M * H);
+    if (A.fail) return ROITR_ERR_ARG;
+    RoitrLocalAttn a;
+    memset(&a, 0, sizeof(a));
+    a.M = M; a.K = K; a.H = H; a.heads = HEADS; a.q = q; a.ldq = ldq; a.k = k; a.ldk = ldkv; a.v = v; a.ldv = ldkv;
+    a.group_idx = group; a.ppf = ppf; a.wvpe = L.wvpe; a.bvpe = L.bvpe; a.scale = 1.0f / sqrtf((float)(H / HEADS));
+    a.out = att; a.ldo = H;
+    CHK(roitr_local_attention(&a, st));
+    CHK(gemm(st, M, att, L.lin, hid));
+    CHK(roitr_add_layernorm(M, H, hid, f, node_idx, L.norm_w, L.norm_b, nullptr, 0, 1e-5f, y, st));
+    CHK(gemm(st, M, y, L.out_proj, out));
+    A.off = mark;
+    return 0;
+}
+
+// RIPointTransformerBlock.forward (model/model.py:131-142): relu(bn2(transformer(x)) + x)
+int block(Engine& E, hipStream_t st, const LocalT& L, int M, const float* x, const int* group, const float* ppf, int K, float* out)
+{
+    Arena& A = E.arena;
+    const size_t mark = A.off;
+    float* t = A.get<float>((size_t)M * L.out_dim);
+    if (A.fail) return ROITR_ERR_ARG;
+    CHK(local_transformer(E, st, L, M, x, M, nullptr, group, ppf, K, t));
+    CHK(roitr_add_layernorm(M, L.out_dim, t, nullptr, nullptr, L.bn2_w, L.bn2_b, x, 1, 1e-5f, out, st));
+    A.off = mark;
+    return 0;
+}
+
+int ffn_apply(Engine& E, hipStream_t st, const Ffn& F, int M, int C, const float* x, float* out)
+{
+    Arena& A = E.arena;
+    const size_t mark = A.off;
+    float* e = A.get<float>((size_t)M * 2 * C);
+    float* s = A.get<float>((size_t)M * C);
+    if (A.fail) return ROITR_ERR_ARG;
+    CHK(gemm(st, M, x, F.expand, e, true));
+    CHK(gemm(st, M, e, F.squeeze, s));
+    CHK(roitr_add_layernorm(M, C, s, x, nullptr, F.n_w, F.n_b, nullptr, 0, 1e-5f, out, st));
+    A.off = mark;
+    return 0;
+}
+
+}  // namespace
+
+extern "C" void roitr_level_sizes(int n, int* out4)
+{
+    out4[0] = n; out4[1] = n / 4; out4[2] = out4[1] / 4; out4[3] = out4[2] / 4;
+}
+
+extern "C" void* roitr_engine_create(const RoitrEngineConfig* cfg)
+{
+    Engine* E = new Engine();
+    E->cfg = *cfg;
+    const int f = cfg->factor;
+    E->planes[0] = 64 * f; E->planes[1] = 128 * f; E->planes[2] = 256 * f; E->planes[3] = 256 * f;
+    return E;
+}
+
+extern "C" void roitr_engine_destroy(void* h)
+{
+    Engine* E = (Engine*)h;
+    if (!E) return;
+    if (E->warena.base) (void)hipFree(E->warena.base);
+    if (E->arena.base) (void)hipFree(E->arena.base);
+    for (int i = 0; i < Engine::RING; ++i) {
+        if (E->pinned[i]) (void)hipHostFree(E->pinned[i]);
+        if (E->pinned_ev[i]) (void)hipEventDestroy(E->pinned_ev[i]);
+    }
+    delete E;
+}
+
+extern "C" int roitr_engine_set_param(void* h, const char* name, const float* ptr, long numel)
+{
+    Engine* E = (Engine*)h;
+    E->params[name] = std::make_pair(ptr, numel);
+    E->finalized = false;
+    return 0;
+}
+
+extern "C" int roitr_engine_set_tap(void* h, const char* name, void* ptr)
+{
+    ((Engine*)h)->taps[name] = ptr;
+    return 0;
+}
+
+extern "C" int roitr_engine_set_inject(void* h, const char* name, const void* ptr)
+{
+    ((Engine*)h)->injects[name] = ptr;
+    return 0;
+}
+
+extern "C" int roitr_engine_finalize(void* h, hipStream_t st)
+{
+    Engine& E = *(Engine*)h;
+    E.err.clear();
+    const int f = E.cfg.factor;
+    const int C4 = 256 * f;
+    // ---- resolve names (model/model.py:146-184 module tree)
+    int in_planes = 1;
+    for (int l = 0; l < 4; ++l) {
+        const std::string e = "backbone.enc" + std::to_string(l + 1);
+        const int pl = E.planes[l];
+        const int hid = pl < 256 * f ? pl : 256 * f;
+        resolve_local(E, E.enc[l][0], e + ".0.transformer", in_planes, hid, pl);
+        for (int b = 1; b < E.nblocks[l]; ++b) {
+            const std::string bp = e + "." + std::to_string(b);
+            resolve_local(E, E.enc[l][b], bp + ".transformer.transformer", pl, hid, pl);
+            E.enc[l][b].bn2_w = P(E, bp + ".bn2.weight", pl); E.enc[l][b].bn2_b = P(E, bp + ".bn2.bias", pl);
+        }
+        in_planes = pl;
+    }
+    for (int l = 3; l >= 0; --l) {
+        const std::string d = "backbone.dec" + std::to_string(l + 1);
+        const int pl = E.planes[l];
+        const int hid = pl < 256 * f ? pl : 256 * f;
+        Up& U = E.up[l];
+        if (l == 3) {
+            U.l1 = lin(E, d + ".0.linear1.0", pl, 2 * pl);
+            U.l2 = lin(E, d + ".0.linear2.0", pl, pl);
+            U.l1n_w = P(E, d + ".0.linear1.1.weight", pl); U.l1n_b = P(E, d + ".0.linear1.1.bias", pl);
+        } else {
+            U.l1 = lin(E, d + ".0.linear1.0", pl, pl);
+            U.l2 = lin(E, d + ".0.linear2.0", pl, E.planes[l + 1]);
+            U.l1n_w = P(E, d + ".0.linear1.1.weight", pl); U.l1n_b = P(E, d + ".0.linear1.1.bias", pl);
+            U.l2n_w = P(E, d + ".0.linear2.1.weight", pl); U.l2n_b = P(E, d + ".0.linear2.1.bias", pl);
+        }
+        resolve_local(E, E.dec[l], d + ".1.transformer.transformer", pl, hid, pl);
+        E.dec[l].bn2_w = P(E, d + ".1.bn2.weight", pl); E.dec[l].bn2_b = P(E, d + ".1.bn2.bias", pl);
+    }
+    const std::string g = "backbone.global_transformer";
+    E.proj_d = lin(E, g + ".embedding.proj_d", C4, C4);
+    E.proj_a = lin(E, g + ".embedding.proj_a", C4, C4);
+    E.geo_in = lin(E, g + ".in_proj", C4, C4);
+    E.geo_out = lin(E, g + ".out_proj", C4, C4);
+    E.geo.clear();
+    for (int i = 0; i < E.cfg.n_geo_layers; ++i) {
+        GeoLayer L;
+        L.cross = E.cfg.geo_is_cross[i] != 0;
+        const std::string lp = g + ".transformer.layers." + std::to_string(i);
+        const std::string at = lp + ".attention.attention";
+        L.q = lin(E, at + ".proj_q", C4, C4); L.k = lin(E, at + ".proj_k", C4, C4); L.v = lin(E, at + ".proj_v", C4, C4);
+        L.lin = lin(E, lp + ".attention.linear", C4, C4);
+        L.n_w = P(E, lp + ".attention.norm.weight", C4); L.n_b = P(E, lp + ".attention.norm.bias", C4);
+        L.out = ffn(E, lp + ".output", C4);
+        if (!L.cross) {
+            L.p = lin(E, at + ".proj_p", C4, C4); L.vp = lin(E, at + ".proj_vp", C4, C4);
+            L.pos_lin = lin(E, lp + ".attention.pos_linear", C4, C4);
+            L.pn_w = P(E, lp + ".attention.pos_norm.weight", C4); L.pn_b = P(E, lp + ".attention.pos_norm.bias", C4);
+            L.pos = ffn(E, lp + ".pos_proj", C4);
+        }
+        E.geo.push_back(L);
+    }
+    E.coarse_proj = lin(E, "coarse_proj", C4, C4);
+    E.fine_proj = lin(E, "fine_proj", C4, 64 * f);
+    E.ot_alpha = P(E, "optimal_transport.alpha", 1);
+    if (!E.err.empty()) { roitr_set_error(E.err.c_str(), __FILE__, __LINE__); return ROITR_ERR_ARG; }
+
+    // ---- derived weights
+    if (!E.warena.base) {
+        E.warena.cap = (size_t)96 << 20;
+        ROITR_HIP(hipMalloc((void**)&E.warena.base, E.warena.cap));
+    }
+    E.warena.off = 0; E.warena.fail = false;
+    for (int l = 0; l < 4; ++l) {
+        for (int b = 0; b < E.nblocks[l]; ++b) CHK(fold_local(E, E.enc[l][b], st));
+        CHK(fold_local(E, E.dec[l], st));
+    }
+    for (auto& L : E.geo) {
+        if (L.cross) continue;
+        L.wqkv = E.warena.get<float>((size_t)3 * C4 * C4);
+        L.bqkv = E.warena.get<float>((size_t)3 * C4);
+        L.wpT = E.warena.get<float>((size_t)C4 * C4);
+        if (E.warena.fail) break;
+        const Lin* qs[3] = {&L.q, &L.k, &L.v};
+        for (int j = 0; j < 3; ++j) {
+            CHK(d2d(st, L.wqkv + (size_t)j * C4 * C4, qs[j]->w, sizeof(float) * (size_t)C4 * C4));
+            CHK(d2d(st, L.bqkv + (size_t)j * C4, qs[j]->b, sizeof(float) * C4));
+        }
+        CHK(roitr_transpose(C4, C4, L.p.w, C4, L.wpT, C4, st));
+    }
+    // SinusoidalPositionalEmbedding.div_term (positional_encoding.py:43-45): a buffer in the state_dict;
+    // regenerate it in fp32 when the caller did not register it
+    {
+        auto it = E.params.find(g + ".embedding.embedding.div_term");
+        if (it != E.params.end()) E.geo_div = it->second.first;
+        else {
+            E.geo_div_own = E.warena.get<float>(C4 / 2);
+            std::vector<float> dv(C4 / 2);
+            const float c = (float)(-log(10000.0) / (double)C4);
+            for (int i = 0; i < C4 / 2; ++i) dv[i] = expf((float)(2 * i) * c);
+            ROITR_HIP(hipMemcpyAsync(E.geo_div_own, dv.data(), sizeof(float) * dv.size(), hipMemcpyHostToDevice, st));
+            ROITR_HIP(hipStreamSynchronize(st));
+            E.geo_div = E.geo_div_own;
+        }
+    }
+    if (E.warena.fail) { roitr_set_error("derived-weight arena exhausted", __FILE__, __LINE__); return ROITR_ERR_ARG; }
+    E.finalized = true;
+    return 0;
+}
+
+extern "C" int roitr_engine_forward(void* h, const RoitrForwardIO* io, hipStream_t st)
+{
+    Engine& E = *(Engine*)h;
+    if (!E.finalized) { roitr_set_error("engine not finalized", __FILE__, __LINE__); return ROITR_ERR_ARG; }
+    if (E.cfg.adaptive_coarse) { roitr_set_error("AdaptiveSuperPointMatching (4DMatch) not implemented", __FILE__, __LINE__); return ROITR_ERR_UNSUPPORTED; }
+    const int B = io->pairs, NC = 2 * B;
+    if (B <= 0) return 0;
+    const int f = E.cfg.factor, C4 = 256 * f, P_ = E.cfg.num_corr, LIM = E.cfg.point_limit;
+
+    // ---------------- level geometry (host), descriptors to the device
+    Levels V;
+    V.B = B; V.NC = NC;
+    for (int l = 0; l < 4; ++l) { V.n[l].resize(NC); V.off[l].resize(NC); }
+    for (int c = 0; c < NC; ++c) {
+        int s[4];
+        roitr_level_sizes(io->n_points[c], s);
+        for (int l = 0; l < 4; ++l) V.n[l][c] = s[l];
+        if (s[3] < 4) { roitr_set_error("cloud too small: needs >= 256 points (4 nodes)", __FILE__, __LINE__); return ROITR_ERR_ARG; }
+    }
+    for (int l = 0; l < 4; ++l) {
+        int acc = 0;
+        for (int c = 0; c < NC; ++c) { acc += V.n[l][c]; V.off[l][c] = acc; V.nmax[l] = V.n[l][c] > V.nmax[l] ? V.n[l][c] : V.nmax[l]; }
+        V.T[l] = acc;
+    }
+    const int T1 = V.T[0], T4 = V.T[3];
+    if (V.nmax[3] > 1024) { roitr_set_error("more than 1024 superpoints per cloud", __FILE__, __LINE__); return ROITR_ERR_UNSUPPORTED; }
+    std::vector<long> eoff(NC);
+    long etot = 0;
+    for (int c = 0; c < NC; ++c) { eoff[c] = etot; etot += (long)V.n[3][c] * V.n[3][c]; }
+
+    // ---------------- arena sizing (upper bound from the sizes)
+    {
+        size_t need = (size_t)T1 * 4 * (64 * f * 14 + 256 * f * 2 + 600) + (size_t)etot * C4 * 4 * 11 + (size_t)T4 * C4 * 4 * 40 +
+                      (size_t)B * P_ * (LIM * LIM * 3 + (LIM + 1) * (LIM + 1) + LIM * 16) * 4 + ((size_t)64 << 20);
+        for (int l = 0; l < 4; ++l) need += roitr_knn_workspace_bytes(NC, V.T[l], T1) + 1024;
+        need += (size_t)B * roitr_coarse_scratch_floats(V.nmax[3], V.nmax[3]) * 4;
+        if (need > E.arena.cap) {
+            ROITR_HIP(hipStreamSynchronize(st));
+            if (E.arena.base) ROITR_HIP(hipFree(E.arena.base));
+            E.arena.base = nullptr; E.arena.cap = 0;
+            ROITR_HIP(hipMalloc((void**)&E.arena.base, need));
+            E.arena.cap = need;
+        }
+        E.arena.off = 0; E.arena.fail = false;
+    }
+    Arena& A = E.arena;
+
+    // descriptors: off[4][NC], cloud_of_node[T4], partner[NC], eoff[NC] (long), cloud_ids for rows of level 4
+    const size_t desc_ints = (size_t)4 * NC + T4 + NC + 8;
+    const size_t desc_bytes = ((desc_ints * 4 + 15) & ~(size_t)15) + (size_t)NC * 8;
+    const int slot = E.ring_pos;
+    E.ring_pos = (E.ring_pos + 1) % Engine::RING;
+    if (!E.pinned_ev[slot]) ROITR_HIP(hipEventCreateWithFlags(&E.pinned_ev[slot], hipEventDisableTiming));
+    else ROITR_HIP(hipEventSynchronize(E.pinned_ev[slot]));  // the copy that last used this slot has finished
+    if (desc_bytes > E.pinned_cap[slot]) {
+        if (E.pinned[slot]) ROITR_HIP(hipHostFree(E.pinned[slot]));
+        E.pinned_cap[slot] = desc_bytes * 2;
+        ROITR_HIP(hipHostMalloc((void**)&E.pinned[slot], E.pinned_cap[slot], hipHostMallocDefault));
+    }
+    char* pin = E.pinned[slot];
+    int* hp = (int*)pin;
+    for (int l = 0; l < 4; ++l) memcpy(hp + (size_t)l * NC, V.off[l].data(), sizeof(int) * NC);
+    int* h_con = hp + (size_t)4 * NC;
+    for (int c = 0, r = 0; c < NC; ++c) for (int i = 0; i < V.n[3][c]; ++i) h_con[r++] = c;
+    int* h_partner = h_con + T4;
+    for (int c = 0; c < NC; ++c) h_partner[c] = c < B ? c + B : c - B;
+    long* h_eoff = (long*)(pin + ((desc_ints * 4 + 15) & ~(size_t)15));
+    memcpy(h_eoff, eoff.data(), sizeof(long) * NC);
+    char* ddesc = A.get<char>(desc_bytes);
+    ROITR_HIP(hipMemcpyAsync(ddesc, pin, desc_bytes, hipMemcpyHostToDevice, st));
+    ROITR_HIP(hipEventRecord(E.pinned_ev[slot], st));
+    Dev D;
+    for (int l = 0; l < 4; ++l) D.off[l] = (int*)ddesc + (size_t)l * NC;
+    D.cloud_of_node = (int*)ddesc + (size_t)4 * NC;
+    D.partner = D.cloud_of_node + T4;
+    D.eoff = (long*)(ddesc + ((desc_ints * 4 + 15) & ~(size_t)15));
+
+    // ---------------- hierarchy geometry: FPS, kNN groups, PPF  (model/model.py:56-80, 30-42)
+    const float* p[4]; const float* nrm[4];
+    p[0] = io->points_geom; nrm[0] = io->normals;
+    int* down[4] = {nullptr, nullptr, nullptr, nullptr};  // FPS indices into level l-1 (global rows)
+    int* g_self[4]; float* ppf_self[4];                    // self kNN groups (blocks + decoder)
+    int* g_td[4]; float* ppf_td[4];                        // TransitionDown groups (level l nodes over level l-1 points)
+    void* knn_ws[4];
+    bool grid[4];
+    float* fps_tmp = A.get<float>(T1);
+    for (int l = 0; l < 4; ++l) {
+        const int K = E.nsample[l];
+        if (l > 0) {
+            down[l] = A.get<int>(V.T[l]);
+            float* pl = A.get<float>((size_t)V.T[l] * 3);
+            float* nl = A.get<float>((size_t)V.T[l] * 3);
+            if (A.fail) break;
+            // tmp = 1e10 (functions/pointops.py:22)
+            ROITR_HIP(hipMemsetD32Async((hipDeviceptr_t)fps_tmp, 0x501502F9 /* bits of 1e10f */, V.T[l - 1], st));
+            CHK(roitr_furthestsampling(NC, V.nmax[l - 1], p[l - 1], D.off[l - 1], D.off[l], fps_tmp, down[l], st));
+            CHK(tap(E, st, "fps." + std::to_string(l + 1), down[l], sizeof(int) * V.T[l]));
+            CHK(roitr_gather_rows(V.T[l], 3, p[l - 1], down[l], 0, pl, st));
+            CHK(roitr_gather_rows(V.T[l], 3, nrm[l - 1], down[l], 0, nl, st));
+            p[l] = pl; nrm[l] = nl;
+        }
+        // grid over this level's points (refs for: own self-kNN, next level's TD query, finer level's 3-NN)
+        const int mcap = l == 0 ? T1 : V.T[l - 1];
+        knn_ws[l] = A.get<char>(roitr_knn_workspace_bytes(NC, V.T[l], mcap));
+        grid[l] = V.T[l] > GRID_MIN_POINTS * NC;
+        if (A.fail) break;
+        if (grid[l]) CHK(roitr_knn_build_grid(NC, V.T[l], mcap, p[l], D.off[l], knn_ws[l], st));
+        g_self[l] = A.get<int>((size_t)V.T[l] * K);
+        ppf_self[l] = A.get<float>((size_t)V.T[l] * K * 4);
+        if (A.fail) break;
+        CHK(roitr_knnquery_ex(NC, V.T[l], V.T[l], K + 1, p[l], p[l], D.off[l], D.off[l], nullptr, nullptr, g_self[l], ppf_self[l], nrm[l],
+                              nrm[l], grid[l] ? 1 : 0, mcap, knn_ws[l], st));
+        CHK(tap(E, st, "group.self." + std::to_string(l + 1), g_self[l], sizeof(int) * (size_t)V.T[l] * K));
+        CHK(tap(E, st, "ppf.self." + std::to_string(l + 1), ppf_self[l], sizeof(float) * (size_t)V.T[l] * K * 4));
+        if (l > 0) {
+            g_td[l] = A.get<int>((size_t)V.T[l] * K);
+            ppf_td[l] = A.get<float>((size_t)V.T[l] * K * 4);
+            if (A.fail) break;
+            const int mcap_prev = l - 1 == 0 ? T1 : V.T[l - 2];
+            CHK(roitr_knnquery_ex(NC, V.T[l - 1], V.T[l], K + 1, p[l - 1], p[l], D.off[l - 1], D.off[l], nullptr, nullptr, g_td[l],
+                                  ppf_td[l], nrm[l - 1], nrm[l], grid[l - 1] ? 1 : 0, mcap_prev, knn_ws[l - 1], st));
+            CHK(tap(E, st, "group.td." + std::to_string(l + 1), g_td[l], sizeof(int) * (size_t)V.T[l] * K));
+            CHK(tap(E, st, "ppf.td." + std::to_string(l + 1), ppf_td[l], sizeof(float) * (size_t)V.T[l] * K * 4));
+        } else {
+            g_td[0] = g_self[0]; ppf_td[0] = ppf_self[0];  // stride 1: the same kNN (model/model.py:75 vs :31)
+        }
+    }
+    if (A.fail) { roitr_set_error("arena exhausted (geometry)", __FILE__, __LINE__); return ROITR_ERR_ARG; }
+
+    // ---------------- encoder
+    float* xe[4];
+    {
+        const float* xin = io->feats;
+        for (int l = 0; l < 4; ++l) {
+            const int pl = E.planes[l], K = E.nsample[l];
+            float* a = A.get<float>((size_t)V.T[l] * pl);
+            float* b = A.get<float>((size_t)V.T[l] * pl);
+            if (A.fail) break;
+            const int n_in = l == 0 ? T1 : V.T[l - 1];
+            CHK(local_transformer(E, st, E.enc[l][0], n_in, xin, V.T[l], l == 0 ? nullptr : down[l], g_td[l], ppf_td[l], K, a));
+            CHK(tap(E, st, "enc" + std::to_string(l + 1) + ".0", a, sizeof(float) * (size_t)V.T[l] * pl));
+            float* cur = a; float* nxt = b;
+            for (int bi = 1; bi < E.nblocks[l]; ++bi) {
+                CHK(block(E, st, E.enc[l][bi], V.T[l], cur, g_self[l], ppf_self[l], K, nxt));
+                CHK(tap(E, st, "enc" + std::to_string(l + 1) + "." + std::to_string(bi), nxt, sizeof(float) * (size_t)V.T[l] * pl));
+                float* t = cur; cur = nxt; nxt = t;
+            }
+            xe[l] = cur; xin = cur;
+        }
+    }
+    if (A.fail) { roitr_set_error("arena exhausted (encoder)", __FILE__, __LINE__); return ROITR_ERR_ARG; }
+
+    // ---------------- global geometric transformer (geotransformer.py:94-133), all pairs batched
+    float* gfeat = A.get<float>((size_t)T4 * C4);
+    {
+        const size_t mark = A.off;
+        float* d_idx = A.get<float>(etot);
+        float* a_idx = A.get<float>((size_t)etot * 3);
+        float* S = A.get<float>((size_t)etot * 3 * C4);
+        float* Pd = A.get<float>((size_t)etot * C4);
+        float* Pa = A.get<float>((size_t)etot * 3 * C4);
+        float* Emb = A.get<float>((size_t)etot * C4);
+        if (A.fail) { roitr_set_error("arena exhausted (geo embedding)", __FILE__, __LINE__); return ROITR_ERR_ARG; }
+        CHK(roitr_geo_indices(T4, p[3], D.off[3], D.cloud_of_node, D.eoff, 0.2f, 15.0f, 3, V.nmax[3], d_idx, a_idx, st));
+        CHK(tap(E, st, "geo.d_idx", d_idx, sizeof(float) * etot));
+        CHK(tap(E, st, "geo.a_idx", a_idx, sizeof(float) * etot * 3));
+        CHK(roitr_sinusoid(etot, C4, d_idx, E.geo_div, S, st));
+        CHK(gemm(st, (int)etot, S, E.proj_d, Pd));
+        CHK(roitr_sinusoid(etot * 3, C4, a_idx, E.geo_div, S, st));
+        CHK(gemm(st, (int)(etot * 3), S, E.proj_a, Pa));
+        CHK(roitr_geo_combine(etot, C4, 3, Pd, Pa, Emb, st));
+        CHK(tap(E, st, "geo.emb", Emb, sizeof(float) * (size_t)etot * C4));
+
+        float* fcur = A.get<float>((size_t)T4 * C4);
+        float* pos = A.get<float>((size_t)T4 * C4);
+        float* qkv = A.get<float>((size_t)T4 * 3 * C4);
+        float* qt = A.get<float>((size_t)T4 * HEADS * C4);
+        float* ebar = A.get<float>((size_t)T4 * HEADS * C4);
+        float* hid = A.get<float>((size_t)T4 * C4);
+        float* t1 = A.get<float>((size_t)T4 * C4);
+        float* t2 = A.get<float>((size_t)T4 * C4);
+        if (A.fail) { roitr_set_error("arena exhausted (geo)", __FILE__, __LINE__); return ROITR_ERR_ARG; }
+        CHK(gemm(st, T4, xe[3], E.geo_in, fcur));
+        CHK(tap(E, st, "geo.in_proj", fcur, sizeof(float) * (size_t)T4 * C4));
+        const int cpe = C4 / HEADS;
+        const float scale = 1.0f / sqrtf((float)cpe);
+        const int Ts = V.off[3][B - 1];  // source-cloud rows come first
+        for (size_t li = 0; li < E.geo.size(); ++li) {
+            const GeoLayer& L = E.geo[li];
+            if (!L.cross) {
+                CHK(gemm(st, T4, 3 * C4, C4, fcur, C4, L.wqkv, C4, L.bqkv, qkv, 3 * C4));
+                {   // qt[(row,h), :] = Wp_h^T q_h   (batched over heads)
+                    RoitrGemm gq; memset(&gq, 0, sizeof(gq));
+                    gq.M = T4; gq.N = C4; gq.K = cpe; gq.A = qkv; gq.lda = 3 * C4; gq.W = L.wpT; gq.ldw = C4; gq.alpha = 1.f;
+                    gq.C = qt; gq.ldc = HEADS * C4; gq.batch = HEADS; gq.sA = cpe; gq.sW = cpe; gq.sC = C4;
+                    CHK(roitr_gemm(&gq, st));
+                }
+                RoitrMha m; memset(&m, 0, sizeof(m));
+                m.q_row0 = 0; m.q_rows = T4; m.C = C4; m.heads = HEADS; m.q = qkv; m.ldq = 3 * C4; m.k = qkv + C4; m.ldk = 3 * C4;
+                m.v = qkv + 2 * C4; m.ldv = 3 * C4; m.offset = D.off[3]; m.cloud_of_row = D.cloud_of_node; m.partner = nullptr;
+                m.E = Emb; m.eoff = D.eoff; m.qt = qt; m.bp = L.p.b; m.scale = scale; m.nk_max = V.nmax[3]; m.out = hid; m.ldo = C4; m.ebar = ebar;
+                CHK(roitr_mha(&m, st));
+                {   // pos_raw[:, h-slice] = Wvp_h ebar_h + bvp_h
+                    RoitrGemm gp; memset(&gp, 0, sizeof(gp));
+                    gp.M = T4; gp.N = cpe; gp.K = C4; gp.A = ebar; gp.lda = HEADS * C4; gp.W = L.vp.w; gp.ldw = C4; gp.bias = L.vp.b; gp.alpha = 1.f;
+                    gp.C = t2; gp.ldc = C4; gp.batch = HEADS; gp.sA = C4; gp.sW = (long)cpe * C4; gp.sC = cpe; gp.sBias = cpe;
+                    CHK(roitr_gemm(&gp, st));
+                }
+                // RPEAttentionLayer tail (geoattention.py:236-244) + AttentionOutput x2 (l.278-280)
+                CHK(gemm(st, T4, hid, L.lin, t1));
+                CHK(roitr_add_layernorm(T4, C4, t1, fcur, nullptr, L.n_w, L.n_b, nullptr, 0, 1e-5f, hid, st));
+                CHK(ffn_apply(E, st, L.out, T4, C4, hid, fcur));
+                CHK(gemm(st, T4, t2, L.pos_lin, t1));
+                CHK(roitr_add_layernorm(T4, C4, t1, nullptr, nullptr, L.pn_w, L.pn_b, nullptr, 0, 1e-5f, t2, st));
+                CHK(ffn_apply(E, st, L.pos, T4, C4, t2, pos));
+                CHK(tap(E, st, "geo.layer" + std::to_string(li) + ".pos", pos, sizeof(float) * (size_t)T4 * C4));
+            } else {
+                // geotransformer.py:45-46: feats0 (src) attends feats1 (tgt), then feats1 attends the UPDATED feats0
+                for (int half = 0; half < 2; ++half) {
+                    const int q0 = half == 0 ? 0 : Ts, qn = half == 0 ? Ts : T4 - Ts;
+                    const int k0 = half == 0 ? Ts : 0, kn = half == 0 ? T4 - Ts : Ts;
+                    float* qb_ = qkv;                          // (T4, C4) region reused: q rows at their own row index
+                    float* kb_ = qkv + (size_t)T4 * C4;
+                    float* vb_ = qkv + (size_t)2 * T4 * C4;
+                    CHK(gemm(st, qn, C4, C4, fcur + (size_t)q0 * C4, C4, L.q.w, C4, L.q.b, qb_ + (size_t)q0 * C4, C4, false, nullptr, pos + (size_t)q0 * C4));
+                    CHK(gemm(st, kn, C4, C4, fcur + (size_t)k0 * C4, C4, L.k.w, C4, L.k.b, kb_ + (size_t)k0 * C4, C4, false, nullptr, pos + (size_t)k0 * C4));
+                    CHK(gemm(st, kn, C4, C4, fcur + (size_t)k0 * C4, C4, L.v.w, C4, L.v.b, vb_ + (size_t)k0 * C4, C4));
+                    RoitrMha m; memset(&m, 0, sizeof(m));
+                    m.q_row0 = q0; m.q_rows = qn; m.C = C4; m.heads = HEADS; m.q = qb_; m.ldq = C4; m.k = kb_; m.ldk = C4; m.v = vb_; m.ldv = C4;
+                    m.offset = D.off[3]; m.cloud_of_row = D.cloud_of_node; m.partner = D.partner; m.scale = scale; m.nk_max = V.nmax[3];
+                    m.out = hid; m.ldo = C4;
+                    CHK(roitr_mha(&m, st));
+                    CHK(gemm(st, qn, hid + (size_t)q0 * C4, L.lin, t1 + (size_t)q0 * C4));
+                    CHK(roitr_add_layernorm(qn, C4, t1 + (size_t)q0 * C4, fcur + (size_t)q0 * C4, nullptr, L.n_w, L.n_b, nullptr, 0, 1e-5f,
+                                            t2 + (size_t)q0 * C4, st));
+                    CHK(ffn_apply(E, st, L.out, qn, C4, t2 + (size_t)q0 * C4, fcur + (size_t)q0 * C4));
+                }
+            }
+            CHK(tap(E, st, "geo.layer" + std::to_string(li), fcur, sizeof(float) * (size_t)T4 * C4));
+        }
+        CHK(gemm(st, T4, fcur, E.geo_out, gfeat));
+        CHK(tap(E, st, "geo.out", gfeat, sizeof(float) * (size_t)T4 * C4));
+        A.off = mark;
+    }
+
+    // ---------------- decoder (model/model.py:223-231)
+    float* xd[4];
+    {
+        // dec4 head: cat(x, linear2(mean).repeat) -> linear1 -> LN -> ReLU   (model/model.py:99-111)
+        const int pl = E.planes[3];
+        const Up& U = E.up[3];
+        float* mean = A.get<float>((size_t)NC * pl);
+        float* tm = A.get<float>((size_t)NC * pl);
+        float* um = A.get<float>((size_t)NC * pl);
+        float* y = A.get<float>((size_t)T4 * pl);
+        float* x0 = A.get<float>((size_t)T4 * pl);
+        xd[3] = A.get<float>((size_t)T4 * pl);
+        if (A.fail) { roitr_set_error("arena exhausted (decoder)", __FILE__, __LINE__); return ROITR_ERR_ARG; }
+        CHK(roitr_segment_mean(NC, pl, xe[3], D.off[3], mean, st));
+        CHK(gemm(st, NC, mean, U.l2, tm, true));
+        CHK(gemm(st, NC, pl, pl, tm, pl, U.l1.w + pl, 2 * pl, U.l1.b, um, pl));
+        CHK(gemm(st, T4, pl, pl, xe[3], pl, U.l1.w, 2 * pl, nullptr, y, pl));
+        CHK(roitr_add_layernorm(T4, pl, y, um, D.cloud_of_node, U.l1n_w, U.l1n_b, nullptr, 1, 1e-5f, x0, st));
+        CHK(tap(E, st, "dec4.0", x0, sizeof(float) * (size_t)T4 * pl));
+        CHK(block(E, st, E.dec[3], T4, x0, g_self[3], ppf_self[3], E.nsample[3], xd[3]));
+        CHK(tap(E, st, "dec4.1", xd[3], sizeof(float) * (size_t)T4 * pl));
+    }
+    for (int l = 2; l >= 0; --l) {
+        // TransitionUp (model/model.py:112-116): linear1(x1) + interpolation(p2, p1, linear2(x2))
+        const int pl = E.planes[l], pc = E.planes[l + 1];
+        const Up& U = E.up[l];
+        const int Tl = V.T[l], Tc = V.T[l + 1];
+        float* a0 = A.get<float>((size_t)Tl * pl);
+        float* a1 = A.get<float>((size_t)Tl * pl);
+        float* b0 = A.get<float>((size_t)Tc * pl);
+        float* b1 = A.get<float>((size_t)Tc * pl);
+        int* i3 = A.get<int>((size_t)Tl * 3);
+        float* d3 = A.get<float>((size_t)Tl * 3);
+        float* x0 = A.get<float>((size_t)Tl * pl);
+        xd[l] = A.get<float>((size_t)Tl * pl);
+        if (A.fail) { roitr_set_error("arena exhausted (decoder)", __FILE__, __LINE__); return ROITR_ERR_ARG; }
+        CHK(gemm(st, Tl, xe[l], U.l1, a0));
+        CHK(roitr_add_layernorm(Tl, pl, a0, nullptr, nullptr, U.l1n_w, U.l1n_b, nullptr, 1, 1e-5f, a1, st));
+        (void)pc;
+        CHK(gemm(st, Tc, xd[l + 1], U.l2, b0));
+        CHK(roitr_add_layernorm(Tc, pl, b0, nullptr, nullptr, U.l2n_w, U.l2n_b, nullptr, 1, 1e-5f, b1, st));
+        const int mcap_c = V.T[l];  // the coarser level's workspace was carved with m_capacity = T[l]
+        CHK(roitr_knnquery_ex(NC, Tc, Tl, 3, p[l + 1], p[l], D.off[l + 1], D.off[l], i3, d3, nullptr, nullptr, nullptr, nullptr,
+                              grid[l + 1] ? 1 : 0, mcap_c, knn_ws[l + 1], st));
+        CHK(roitr_interp3_add(Tl, pl, b1, i3, d3, a1, x0, st));
+        CHK(tap(E, st, "dec" + std::to_string(l + 1) + ".0", x0, sizeof(float) * (size_t)Tl * pl));
+        CHK(block(E, st, E.dec[l], Tl, x0, g_self[l], ppf_self[l], E.nsample[l], xd[l]));
+        CHK(tap(E, st, "dec" + std::to_string(l + 1) + ".1", xd[l], sizeof(float) * (size_t)Tl * pl));
+    }
+
+    // ---------------- heads (RIGA_v2.py:64-68) and node coordinates (model/model.py:233-235)
+    const float* pts_out = io->points_out ? io->points_out : io->points_geom;
+    float* node_xyz = io->node_xyz ? io->node_xyz : A.get<float>((size_t)T4 * 3);
+    float* node_feats = io->node_feats ? io->node_feats : A.get<float>((size_t)T4 * C4);
+    float* point_feats = io->point_feats ? io->point_feats : A.get<float>((size_t)T1 * C4);
+    {
+        int* c3 = A.get<int>(V.T[2]);
+        int* c4 = A.get<int>(T4);
+        float* cp = A.get<float>((size_t)T4 * C4);
+        if (A.fail) { roitr_set_error("arena exhausted (heads)", __FILE__, __LINE__); return ROITR_ERR_ARG; }
+        CHK(roitr_compose_idx(V.T[2], down[1], down[2], c3, st));  // level-3 nodes as level-1 rows
+        CHK(roitr_compose_idx(T4, c3, down[3], c4, st));
+        CHK(roitr_gather_rows(T4, 3, pts_out, c4, 0, node_xyz, st));
+        CHK(gemm(st, T4, gfeat, E.coarse_proj, cp));
+        CHK(roitr_l2_normalize(T4, C4, cp, node_feats, st));
+        CHK(gemm(st, T1, xd[0], E.fine_proj, point_feats));
+    }
+
+    // ---------------- point-to-node partition, coarse matching, patches, OT, fine matching
+    int* node_masks = io->node_masks ? io->node_masks : A.get<int>(T4);
+    int* kidx = io->node_knn_idx ? io->node_knn_idx : A.get<int>((size_t)T4 * LIM);
+    int* kmask = io->node_knn_mask ? io->node_knn_mask : A.get<int>((size_t)T4 * LIM);
+    int* p2n = A.get<int>(T1);
+    float* p2nd = A.get<float>(T1);
+    int* tgt_corr = io->tgt_corr ? io->tgt_corr : A.get<int>((size_t)B * P_);
+    int* src_corr = io->src_corr ? io->src_corr : A.get<int>((size_t)B * P_);
+    float* cscore = io->corr_scores ? io->corr_scores : A.get<float>((size_t)B * P_);
+    int* n_corr = io->n_corr ? io->n_corr : A.get<int>(B);
+    const size_t NP = (size_t)B * P_;
+    int* trows = A.get<int>(NP * LIM); int* srows = A.get<int>(NP * LIM);
+    int* tmask = io->tgt_knn_masks ? io->tgt_knn_masks : A.get<int>(NP * LIM);
+    int* smask = io->src_knn_masks ? io->src_knn_masks : A.get<int>(NP * LIM);
+    float* tpts = io->tgt_knn_pts ? io->tgt_knn_pts : A.get<float>(NP * LIM * 3);
+    float* spts = io->src_knn_pts ? io->src_knn_pts : A.get<float>(NP * LIM * 3);
+    float* mscore = A.get<float>(NP * LIM * LIM);
+    float* ot = io->matching_scores ? io->matching_scores : A.get<float>(NP * (LIM + 1) * (LIM + 1));
+    unsigned char* flags = A.get<unsigned char>(NP * LIM * LIM);
+    int* counts = A.get<int>(NP);
+    int* offsets = io->fine_offsets ? io->fine_offsets : A.get<int>(NP);
+    int* n_out = io->n_out ? io->n_out : A.get<int>(1);
+    const size_t cap = NP * LIM * (size_t)E.cfg.fine_topk;
+    float* o_t = io->out_tgt_pts ? io->out_tgt_pts : A.get<float>(cap * 3);
+    float* o_s = io->out_src_pts ? io->out_src_pts : A.get<float>(cap * 3);
+    float* o_sc = io->out_scores ? io->out_scores : A.get<float>(cap);
+    const long cstride = (long)roitr_coarse_scratch_floats(V.nmax[3], V.nmax[3]);
+    float* cscratch = A.get<float>((size_t)B * cstride);
+    if (A.fail) { roitr_set_error("arena exhausted (matching)", __FILE__, __LINE__); return ROITR_ERR_ARG; }
+
+    CHK(roitr_point_to_node_partition(NC, T1, T4, pts_out, D.off[0], node_xyz, D.off[3], D.cloud_of_node, LIM, p2n, p2nd, node_masks, kidx,
+                                      kmask, st));
+    {
+        RoitrCoarse c; memset(&c, 0, sizeof(c));
+        c.pairs = B; c.C = C4; c.num_corr = P_; c.dual_norm = 1; c.max_ref = V.nmax[3]; c.max_src = V.nmax[3];
+        c.feats = node_feats; c.node_offset = D.off[3]; c.node_masks = node_masks; c.scratch = cscratch; c.scratch_stride = cstride;
+        c.tgt_corr = tgt_corr; c.src_corr = src_corr; c.corr_scores = cscore; c.n_corr = n_corr;
+        CHK(roitr_coarse_matching(&c, st));
+    }
+    {
+        RoitrPatch pg; memset(&pg, 0, sizeof(pg));
+        pg.pairs = B; pg.num_corr = P_; pg.limit = LIM; pg.n_corr = n_corr; pg.tgt_corr = tgt_corr; pg.src_corr = src_corr;
+        pg.node_offset = D.off[3]; pg.pt_offset = D.off[0]; pg.knn_idx = kidx; pg.knn_mask = kmask; pg.points = pts_out;
+        pg.tgt_rows = trows; pg.src_rows = srows; pg.tgt_masks = tmask; pg.src_masks = smask; pg.tgt_pts = tpts; pg.src_pts = spts;
+        CHK(roitr_patch_gather(&pg, st));
+    }
+    {   // matching_scores = einsum('bnd,bmd->bnm', tgt, src) / sqrt(C)   (RIGA_v2.py:150-152)
+        RoitrGemm g; memset(&g, 0, sizeof(g));
+        g.M = LIM; g.N = LIM; g.K = C4; g.A = point_feats; g.lda = C4; g.a_idx = trows; g.a_limit = T1; g.W = point_feats; g.ldw = C4;
+        g.w_idx = srows; g.w_limit = T1; g.alpha = 1.0f / sqrtf((float)C4); g.C = mscore; g.ldc = LIM; g.batch = (int)NP;
+        g.sC = (long)LIM * LIM; g.sAidx = LIM; g.sWidx = LIM;
+        CHK(roitr_gemm(&g, st));
+    }
+    {
+        RoitrOT o; memset(&o, 0, sizeof(o));
+        o.pairs = B; o.num_corr = P_; o.limit = LIM; o.num_iter = 100; o.n_corr = n_corr; o.scores = mscore; o.row_masks = tmask;
+        o.col_masks = smask; o.alpha = E.ot_alpha; o.out = ot;
+        CHK(roitr_optimal_transport(&o, st));
+    }
+    {
+        RoitrFine fm; memset(&fm, 0, sizeof(fm));
+        fm.pairs = B; fm.num_corr = P_; fm.limit = LIM; fm.k = E.cfg.fine_topk; fm.mutual = E.cfg.fine_mutual; fm.conf = E.cfg.fine_conf;
+        fm.n_corr = n_corr; fm.ot = ot; fm.row_masks = tmask; fm.col_masks = smask; fm.row_pts = tpts; fm.col_pts = spts;
+        fm.global_scores = E.cfg.fine_use_global_score ? cscore : nullptr;
+        fm.flags = flags; fm.counts = counts; fm.offsets = offsets; fm.n_out = n_out;
+        fm.out_row_pts = o_t; fm.out_col_pts = o_s; fm.out_scores = o_sc; fm.out_patch = io->out_patch;
+        CHK(roitr_fine_matching(&fm, st));
+    }
+    return 0;
+}

@@ -1,0 +1,241 @@
+// Global (superpoint-level) geometric transformer kernels.
+//
+// Reference: model/transformer/positional_encoding.py:94-154 (GeometricStructureEmbedding),
+// model/transformer/geoattention.py:10-136 (MultiHeadAttention, RPEMultiHeadAttention).
+//
+// (1) geo_indices: per node i the distance indices d_ij/sigma_d and, for the 3 nearest neighbours
+//     of i, the triplet angles a_ijk * 180/(sigma_a*pi).  pairwise_distance (l.9-34) is the matmul
+//     form x2 - 2xy + y2 and its rounding noise is visible on the diagonal (sqrt of ~1e-7), so the
+//     arithmetic is pinned to what torch-CPU produces for K = 3: xy is an fma chain in k order, the
+//     squared norms are plain sums ((x0^2 + x1^2) + x2^2) -- verified against the golden vectors.
+// (2) mha: one workgroup per query row, one wave per head, lane = key index.  The RPE branch is
+//     folded:  q_h . (Wp_h e_ij + bp_h) = (Wp_h^T q_h) . e_ij + q_h . bp_h, and
+//     sum_j a_ij (Wvp_h e_ij + bvp_h) = Wvp_h (sum_j a_ij e_ij) + bvp_h, so the (n,n,C) tensors
+//     proj_p(E) / proj_vp(E) of geoattention.py:104-105 (n^2 C^2 MACs each, 3.3 GFLOP per self layer at
+//     n = 78) are never formed; what remains on E is two streaming passes (n^2 C MACs each).
+#include "common.h"
+#include "roitr_engine.h"
+
+namespace {
+
+// NB: hipcc's __fmul_rn/__fadd_rn are plain operators and would be re-fused by -ffp-contract=fast, so the
+// functions that pin torch-CPU arithmetic switch contraction off explicitly.
+__device__ __forceinline__ float sq_norm3(float x, float y, float z)
+{
+#pragma clang fp contract(off)
+    const float a = x * x, b = y * y, c = z * z;
+    return (a + b) + c;
+}
+__device__ __forceinline__ float dot3_fma(float ax, float ay, float az, float bx, float by, float bz)
+{
+#pragma clang fp contract(off)
+    const float m = ax * bx;
+    return __fmaf_rn(az, bz, __fmaf_rn(ay, by, m));
+}
+// pairwise_distance(x, y)[i][j] clamped at 0 (positional_encoding.py:30-33)
+__device__ __forceinline__ float pair_sqdist(float ax, float ay, float az, float bx, float by, float bz)
+{
+#pragma clang fp contract(off)
+    const float x2 = sq_norm3(ax, ay, az), y2 = sq_norm3(bx, by, bz);
+    const float xy = dot3_fma(ax, ay, az, bx, by, bz);
+    const float t = 2.0f * xy;
+    const float u = x2 - t;
+    return fmaxf(u + y2, 0.0f);
+}
+
+// grid: one block per node row (global row index over all clouds); 256 threads over j
+__global__ __launch_bounds__(256) void geo_indices_kernel(const float* __restrict__ pts, const int* __restrict__ offset,
+                                                          const int* __restrict__ cloud_of_row, const long* __restrict__ eoff,
+                                                          float inv_sigma_d_is_div, float sigma_d, float factor_a, int angle_k,
+                                                          float* __restrict__ d_idx, float* __restrict__ a_idx)
+{
+    __shared__ float sd[1024];
+    __shared__ unsigned long long red[4];
+    __shared__ int nb[8];
+    const int row = blockIdx.x;
+    const int c = cloud_of_row[row];
+    const int s = c == 0 ? 0 : offset[c - 1], e = offset[c];
+    const int n = e - s, i = row - s;
+    const float px = pts[(size_t)row * 3], py = pts[(size_t)row * 3 + 1], pz = pts[(size_t)row * 3 + 2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float* drow = d_idx + eoff[c] + (size_t)i * n;
+    for (int j = tid; j < n; j += 256) {
+        const float* q = pts + (size_t)(s + j) * 3;
+        const float d = sqrtf(pair_sqdist(px, py, pz, q[0], q[1], q[2]));
+        sd[j] = d;
+        drow[j] = d / sigma_d;
+    }
+    __syncthreads();
+    // k+1 smallest of the row, ascending, lowest index first on ties (topk(largest=False), l.124); drop the first
+    for (int t = 0; t <= angle_k; ++t) {
+        unsigned long long best = ~0ull;
+        for (int j = tid; j < n; j += 256) {
+            const unsigned long long key = ((unsigned long long)__float_as_uint(sd[j]) << 32) | (unsigned)j;
+            best = key < best ? key : best;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { const unsigned long long w = __shfl_xor(best, o, 64); best = w < best ? w : best; }
+        if (lane == 0) red[wave] = best;
+        __syncthreads();
+        if (tid == 0) {
+            unsigned long long b = red[0];
+            for (int w = 1; w < 4; ++w) b = red[w] < b ? red[w] : b;
+            const int j = (int)(unsigned)b;
+            nb[t] = (b == ~0ull) ? i : j;
+            if (b != ~0ull) sd[j] = INFINITY;  // distances are >= 0: +inf bits sort last
+        }
+        __syncthreads();
+    }
+    (void)inv_sigma_d_is_div;
+    float* arow = a_idx + (eoff[c] + (size_t)i * n) * angle_k;
+    for (int j = tid; j < n; j += 256) {
+        const float* q = pts + (size_t)(s + j) * 3;
+        const float ax = q[0] - px, ay = q[1] - py, az = q[2] - pz;  // anc = p_j - p_i (l.129)
+        for (int k = 0; k < angle_k; ++k) {
+            const float* r = pts + (size_t)(s + nb[k + 1]) * 3;
+            const float rx = r[0] - px, ry = r[1] - py, rz = r[2] - pz;  // ref = knn_k - p_i (l.128)
+            const float cx = ry * az - rz * ay, cy = rz * ax - rx * az, cz = rx * ay - ry * ax;
+            const float sn = sqrtf(cx * cx + cy * cy + cz * cz);
+            const float cs = 0.0f + rx * ax + ry * ay + rz * az;  // torch.sum starts from +0: (+0) + (-0) = +0
+            arow[(size_t)j * angle_k + k] = atan2f(sn, cs) * factor_a;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ multi-head attention, one block per query row
+__global__ __launch_bounds__(256) void mha_kernel(RoitrMha a)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int row = a.q_row0 + blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int C = a.C, NH = a.heads, c = C / NH;
+    const int cl = a.cloud_of_row[row];
+    const int kc = a.partner ? a.partner[cl] : cl;
+    const int ks = kc == 0 ? 0 : a.offset[kc - 1], ke = a.offset[kc];
+    const int nk = ke - ks;
+    const int qs_ = cl == 0 ? 0 : a.offset[cl - 1];
+    const int qi = row - qs_;  // index inside its own cloud (self attention: the diagonal position)
+
+    float* qsh = smem;                      // C        : q row
+    float* qt = qsh + C;                    // NH*C     : folded rpe queries (only with E)
+    float* sc = qt + (a.E ? NH * C : 0);    // NH*nkmax : scores -> probabilities
+    float* sc2 = sc + NH * a.nk_max;        // NH*nkmax : diagonal-masked probabilities (only with E)
+    float* qb = sc2 + (a.E ? NH * a.nk_max : 0);  // 8 : q_h . bp_h
+
+    const float* qrow = a.q + (size_t)row * a.ldq;
+    for (int i = tid; i < C; i += 256) qsh[i] = qrow[i];
+    if (a.E) {
+        const float* qtr = a.qt + (size_t)row * NH * C;
+        for (int i = tid; i < NH * C; i += 256) qt[i] = qtr[i];
+    }
+    __syncthreads();
+    if (a.E && tid < NH) {
+        float s = 0.f;
+        for (int i = 0; i < c; ++i) s += qsh[tid * c + i] * a.bp[tid * c + i];
+        qb[tid] = s;
+    }
+    __syncthreads();
+
+    const float* Erow = a.E ? a.E + a.eoff[cl] * C + (size_t)qi * nk * C : nullptr;
+    // ---- scores: wave = head (loop if NH > 4), lane = key
+    for (int h = wave; h < NH; h += 4) {
+        const float* qh = qsh + h * c;
+        for (int j0 = 0; j0 < nk; j0 += 64) {
+            const int j = j0 + lane;
+            if (j < nk) {
+                const float* krow = a.k + (size_t)(ks + j) * a.ldk + h * c;
+                float dot = 0.f;
+                for (int i = 0; i < c; i += 4) {
+                    const float4 kv = *reinterpret_cast<const float4*>(krow + i);
+                    const float4 qv = *reinterpret_cast<const float4*>(qh + i);
+                    dot += kv.x * qv.x; dot += kv.y * qv.y; dot += kv.z * qv.z; dot += kv.w * qv.w;
+                }
+                if (Erow) {
+                    const float* er = Erow + (size_t)j * C;
+                    const float* qth = qt + h * C;
+                    float dp = 0.f;
+                    for (int i = 0; i < C; i += 4) {
+                        const float4 ev = *reinterpret_cast<const float4*>(er + i);
+                        const float4 qv = *reinterpret_cast<const float4*>(qth + i);
+                        dp += ev.x * qv.x; dp += ev.y * qv.y; dp += ev.z * qv.z; dp += ev.w * qv.w;
+                    }
+                    dot += dp + qb[h];
+                }
+                sc[h * a.nk_max + j] = dot * a.scale;
+            }
+        }
+        // softmax (and the diagonal-masked softmax of geoattention.py:117-134) over j, inside this wave
+        float mx = -INFINITY, mx2 = -INFINITY;
+        for (int j = lane; j < nk; j += 64) {
+            const float v = sc[h * a.nk_max + j];
+            mx = fmaxf(mx, v);
+            if (j != qi) mx2 = fmaxf(mx2, v);
+        }
+        mx = wave_max(mx); mx2 = wave_max(mx2);
+        float sm = 0.f, sm2 = 0.f;
+        for (int j = lane; j < nk; j += 64) {
+            const float v = sc[h * a.nk_max + j];
+            const float e1 = expf(v - mx);
+            sc[h * a.nk_max + j] = e1; sm += e1;
+            if (a.E) {
+                const float e2 = j != qi ? expf(v - mx2) : 0.f;
+                sc2[h * a.nk_max + j] = e2; sm2 += e2;
+            }
+        }
+        sm = wave_sum(sm); sm2 = wave_sum(sm2);
+        for (int j = lane; j < nk; j += 64) {
+            sc[h * a.nk_max + j] /= sm;
+            if (a.E) sc2[h * a.nk_max + j] /= sm2;
+        }
+    }
+    __syncthreads();
+    // ---- hidden[h*c + ch] = sum_j p[h][j] v[j][h*c + ch]
+    for (int ch = tid; ch < C; ch += 256) {
+        const int h = ch / c;
+        float acc = 0.f;
+        for (int j = 0; j < nk; ++j) acc += sc[h * a.nk_max + j] * a.v[(size_t)(ks + j) * a.ldv + ch];
+        a.out[(size_t)row * a.ldo + ch] = acc;
+    }
+    // ---- ebar[h][:] = sum_j p2[h][j] E[i][j][:]
+    if (Erow) {
+        for (int ch = tid; ch < C; ch += 256) {
+            float acc[8];
+#pragma unroll
+            for (int h = 0; h < 8; ++h) acc[h] = 0.f;
+            for (int j = 0; j < nk; ++j) {
+                const float ev = Erow[(size_t)j * C + ch];
+#pragma unroll
+                for (int h = 0; h < 8; ++h)
+                    if (h < NH) acc[h] += sc2[h * a.nk_max + j] * ev;
+            }
+#pragma unroll
+            for (int h = 0; h < 8; ++h)
+                if (h < NH) a.ebar[((size_t)row * NH + h) * C + ch] = acc[h];
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int roitr_geo_indices(int rows, const float* pts, const int* offset, const int* cloud_of_row, const long* eoff,
+                                 float sigma_d, float sigma_a, int angle_k, int n_max, float* d_idx, float* a_idx, hipStream_t stream)
+{
+    if (rows <= 0) return ROITR_OK;
+    if (n_max > 1024 || angle_k > 6) return ROITR_ERR_UNSUPPORTED;
+    const float factor_a = (float)(180.0 / ((double)sigma_a * 3.14159265358979323846));
+    geo_indices_kernel<<<rows, 256, 0, stream>>>(pts, offset, cloud_of_row, eoff, 0.f, sigma_d, factor_a, angle_k, d_idx, a_idx);
+    ROITR_LAUNCH_CHECK();
+    return ROITR_OK;
+}
+
+extern "C" int roitr_mha(const RoitrMha* a, hipStream_t stream)
+{
+    if (a->q_rows <= 0) return ROITR_OK;
+    const int c = a->C / a->heads;
+    if (a->heads > 8 || a->C % a->heads || c % 4 || a->ldk % 4 || a->C % 4) return ROITR_ERR_UNSUPPORTED;
+    size_t floats = (size_t)a->C + (a->E ? (size_t)a->heads * a->C : 0) + (size_t)a->heads * a->nk_max * (a->E ? 2 : 1) + 8;
+    if (floats * 4 > 150 * 1024) return ROITR_ERR_UNSUPPORTED;
+    mha_kernel<<<a->q_rows, 256, floats * sizeof(float), stream>>>(*a);
+    ROITR_LAUNCH_CHECK();
+    return ROITR_OK;
+}

@@ -1,0 +1,489 @@
+// Coarse-to-fine matching tail of the RoITr forward pass (reference model/RIGA_v2.py:82-173):
+// point-to-node partition, coarse (superpoint) matching, patch assembly, optimal transport,
+// fine (point) matching with deterministic row-major compaction.
+//
+// All kernels are batched over `pairs`: clouds are laid out [src_0..src_{B-1}, tgt_0..tgt_{B-1}].
+#include "common.h"
+#include "roitr_engine.h"
+
+namespace {
+
+// hipcc's __fmul_rn/__fadd_rn are plain operators (re-fusable), so contraction is switched off explicitly
+__device__ __forceinline__ float sq_norm3(float x, float y, float z)
+{
+#pragma clang fp contract(off)
+    const float a = x * x, b = y * y, c = z * z;
+    return (a + b) + c;
+}
+// lib/utils.py:139-156 square_distance for 3-vectors in torch-CPU arithmetic:
+// dist = -2*matmul (fma chain over k) ; dist += |src|^2 ; dist += |tgt|^2 ; clamp(min=1e-12)
+__device__ __forceinline__ float square_distance3(float sx, float sy, float sz, float s2, float tx, float ty, float tz, float t2)
+{
+#pragma clang fp contract(off)
+    const float m = sx * tx;
+    const float xy = __fmaf_rn(sz, tz, __fmaf_rn(sy, ty, m));
+    const float a = -2.0f * xy;
+    const float b = a + s2;
+    return fmaxf(b + t2, 1e-12f);
+}
+
+// ------------------------------------------------------------------ point_to_node_partition (lib/utils.py:428-471)
+// A: every point -> nearest node of its cloud (first minimum), distance kept for step B
+__global__ __launch_bounds__(256) void p2n_assign_kernel(int n_points, const float* __restrict__ pts, const int* __restrict__ pt_offset,
+                                                         const int* __restrict__ cloud_of_pt_hint, const float* __restrict__ nodes,
+                                                         const int* __restrict__ node_offset, int b, int* __restrict__ p2n,
+                                                         float* __restrict__ p2n_dist, int* __restrict__ node_masks)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_points) return;
+    int c = 0;
+    while (c < b - 1 && i >= pt_offset[c]) ++c;
+    (void)cloud_of_pt_hint;
+    const int ns = c == 0 ? 0 : node_offset[c - 1], ne = node_offset[c];
+    const float px = pts[(size_t)i * 3], py = pts[(size_t)i * 3 + 1], pz = pts[(size_t)i * 3 + 2];
+    const float p2 = sq_norm3(px, py, pz);
+    float best = INFINITY; int bi = ns;
+    for (int j = ns; j < ne; ++j) {
+        const float nx = nodes[(size_t)j * 3], ny = nodes[(size_t)j * 3 + 1], nz = nodes[(size_t)j * 3 + 2];
+        const float d = square_distance3(nx, ny, nz, sq_norm3(nx, ny, nz), px, py, pz, p2);
+        if (d < best) { best = d; bi = j; }
+    }
+    p2n[i] = bi - ns;  // node index local to the cloud, as the reference returns it
+    p2n_dist[i] = best;
+    node_masks[bi] = 1;
+}
+
+// B: one block per node: the `limit` nearest OWNED points, ascending (distance, index); pad = n_c (cloud size)
+__global__ __launch_bounds__(256) void p2n_topk_kernel(const int* __restrict__ pt_offset, const int* __restrict__ node_offset,
+                                                       const int* __restrict__ cloud_of_node, const int* __restrict__ p2n,
+                                                       const float* __restrict__ p2n_dist, int limit, int* __restrict__ knn_idx,
+                                                       int* __restrict__ knn_mask)
+{
+    __shared__ unsigned long long red[4];
+    __shared__ unsigned long long last_s;
+    const int node = blockIdx.x;
+    const int c = cloud_of_node[node];
+    const int ps = c == 0 ? 0 : pt_offset[c - 1], pe = pt_offset[c];
+    const int local = node - (c == 0 ? 0 : node_offset[c - 1]);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    unsigned long long last = 0ull;  // keys are > 0 (distance >= 1e-12)
+    bool first = true;
+    for (int t = 0; t < limit; ++t) {
+        unsigned long long best = ~0ull;
+        for (int j = ps + tid; j < pe; j += 256) {
+            if (p2n[j] == local) {
+                const unsigned long long key = ((unsigned long long)__float_as_uint(p2n_dist[j]) << 32) | (unsigned)(j - ps);
+                if ((first || key > last) && key < best) best = key;
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { const unsigned long long w = __shfl_xor(best, o, 64); best = w < best ? w : best; }
+        if (lane == 0) red[wave] = best;
+        __syncthreads();
+        if (tid == 0) {
+            unsigned long long bb = red[0];
+            for (int w = 1; w < 4; ++w) bb = red[w] < bb ? red[w] : bb;
+            last_s = bb;
+            const bool ok = bb != ~0ull;
+            knn_idx[(size_t)node * limit + t] = ok ? (int)(unsigned)bb : (pe - ps);
+            knn_mask[(size_t)node * limit + t] = ok ? 1 : 0;
+        }
+        __syncthreads();
+        last = last_s; first = false;
+        if (last == ~0ull) {  // exhausted: pad the rest
+            for (int u = t + 1 + tid; u < limit; u += 256) { knn_idx[(size_t)node * limit + u] = pe - ps; knn_mask[(size_t)node * limit + u] = 0; }
+            break;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ CoarseMatching (model/modules.py:141-178)
+// one block (1024 threads) per pair.  ref = tgt nodes, src = src nodes (RIGA_v2.py:121).
+// scores[i][j] = exp(-square_distance(ref_i, src_j)) over mask-valid rows/cols, dual normalisation,
+// top-`num` by (score desc, flat index asc).  Scratch: n_r*n_s floats per pair.
+__global__ __launch_bounds__(1024) void coarse_match_kernel(RoitrCoarse a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned long long keys[];
+    const int pair = blockIdx.x, B = a.pairs;
+    const int sc = pair, tc = B + pair;  // cloud ids
+    const int s0 = sc == 0 ? 0 : a.node_offset[sc - 1], s1 = a.node_offset[sc];
+    const int t0 = a.node_offset[tc - 1], t1 = a.node_offset[tc];
+    const int nr = t1 - t0, nsr = s1 - s0;  // ref rows (tgt), src cols
+    const int tid = threadIdx.x;
+    float* M = a.scratch + (size_t)pair * a.scratch_stride;
+    float* rowsum = M + (size_t)nr * nsr;
+    float* colsum = rowsum + nr;
+    const int C = a.C;
+    // squared norms with a plain sequential sum (tolerance-level parity: torch.sum is a pairwise tree)
+    for (int i = tid; i < nr + nsr; i += 1024) {
+        const float* f = a.feats + (size_t)(i < nr ? t0 + i : s0 + (i - nr)) * C;
+        float s = 0.f;
+        for (int k = 0; k < C; ++k) s += f[k] * f[k];
+        (i < nr ? rowsum : colsum)[i < nr ? i : i - nr] = s;  // temporarily: norms
+    }
+    __syncthreads();
+    for (int e = tid; e < nr * nsr; e += 1024) {
+        const int i = e / nsr, j = e % nsr;
+        const bool ok = a.node_masks[t0 + i] && a.node_masks[s0 + j];
+        float v = -1.f;
+        if (ok) {
+            const float* fr = a.feats + (size_t)(t0 + i) * C;
+            const float* fs = a.feats + (size_t)(s0 + j) * C;
+            float xy = 0.f;
+            for (int k = 0; k < C; ++k) xy = __fmaf_rn(fr[k], fs[k], xy);
+            const float d = fmaxf((-2.0f * xy + rowsum[i]) + colsum[j], 1e-12f);
+            v = expf(-d);
+        }
+        M[e] = v;
+    }
+    __syncthreads();
+    // row / column sums over valid entries (sequential order within a row/col); nr + nsr <= 1024
+    {
+        float s = 0.f;
+        const int i = tid;
+        if (i < nr) { for (int j = 0; j < nsr; ++j) { const float v = M[(size_t)i * nsr + j]; if (v >= 0.f) s += v; } }
+        else if (i < nr + nsr) { const int j = i - nr; for (int r = 0; r < nr; ++r) { const float v = M[(size_t)r * nsr + j]; if (v >= 0.f) s += v; } }
+        __syncthreads();
+        if (i < nr) rowsum[i] = s; else if (i < nr + nsr) colsum[i - nr] = s;
+        __syncthreads();
+    }
+    int nvr = 0, nvs = 0;
+    for (int i = 0; i < nr; ++i) nvr += a.node_masks[t0 + i] ? 1 : 0;
+    for (int j = 0; j < nsr; ++j) nvs += a.node_masks[s0 + j] ? 1 : 0;
+    const int num = min(a.num_corr, nvr * nvs);
+    // keys: (~score bits, compacted flat index) ascending == score descending, reference flat order
+    const int total = nr * nsr;
+    int cap = 1;
+    while (cap < total) cap <<= 1;
+    for (int e = tid; e < cap; e += 1024) {
+        unsigned long long key = ~0ull;
+        if (e < total) {
+            const float v = M[e];
+            if (v >= 0.f) {
+                const int i = e / nsr, j = e % nsr;
+                float sv = v;
+                if (a.dual_norm) sv = (v / (rowsum[i] + 1e-8f)) * (v / (colsum[j] + 1e-8f));
+                key = ((unsigned long long)(~__float_as_uint(sv)) << 32) | (unsigned)e;
+            }
+        }
+        keys[e] = key;
+    }
+    __syncthreads();
+    for (int k = 2; k <= cap; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int e = tid; e < cap; e += 1024) {
+                const int p = e ^ j;
+                if (p > e) {
+                    const unsigned long long x = keys[e], y = keys[p];
+                    const bool up = (e & k) == 0;
+                    if ((x > y) == up) { keys[e] = y; keys[p] = x; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (int t = tid; t < a.num_corr; t += 1024) {
+        int ri = -1, si = -1; float sv = 0.f;
+        if (t < num) {
+            const unsigned long long key = keys[t];
+            const int e = (int)(unsigned)key;
+            ri = e / nsr; si = e % nsr;
+            sv = __uint_as_float(~(unsigned)(key >> 32));
+        }
+        a.tgt_corr[(size_t)pair * a.num_corr + t] = ri;
+        a.src_corr[(size_t)pair * a.num_corr + t] = si;
+        a.corr_scores[(size_t)pair * a.num_corr + t] = sv;
+    }
+    if (tid == 0) a.n_corr[pair] = num;
+}
+
+// ------------------------------------------------------------------ patch assembly (RIGA_v2.py:125-147)
+// per (pair, corr p, slot i): global feature-row index (or -1 = zero pad), knn point, mask, for both sides
+__global__ void patch_gather_kernel(RoitrPatch a)
+{
+    const long t = blockIdx.x * 256L + threadIdx.x;
+    const long per_pair = (long)a.num_corr * a.limit;
+    if (t >= per_pair * a.pairs) return;
+    const int pair = (int)(t / per_pair);
+    const int p = (int)((t % per_pair) / a.limit), i = (int)(t % a.limit);
+    const bool live = p < a.n_corr[pair];
+#pragma unroll
+    for (int side = 0; side < 2; ++side) {  // 0 = tgt (rows of the score matrix), 1 = src (columns)
+        const int cloud = side == 0 ? a.pairs + pair : pair;
+        const int n0 = cloud == 0 ? 0 : a.node_offset[cloud - 1];
+        const int p0 = cloud == 0 ? 0 : a.pt_offset[cloud - 1], p1 = a.pt_offset[cloud];
+        const int* corr = side == 0 ? a.tgt_corr : a.src_corr;
+        int row = -1, mask = 0; float x = 0.f, y = 0.f, z = 0.f;
+        if (live) {
+            const int node = n0 + corr[(size_t)pair * a.num_corr + p];
+            const int li = a.knn_idx[(size_t)node * a.limit + i];
+            mask = a.knn_mask[(size_t)node * a.limit + i];
+            if (li < p1 - p0) {  // index n_c selects the zero pad row (RIGA_v2.py:86-89)
+                row = p0 + li;
+                const float* q = a.points + (size_t)row * 3;
+                x = q[0]; y = q[1]; z = q[2];
+            }
+        }
+        const size_t o = (size_t)t;
+        (side == 0 ? a.tgt_rows : a.src_rows)[o] = row;
+        (side == 0 ? a.tgt_masks : a.src_masks)[o] = mask;
+        float* pp = (side == 0 ? a.tgt_pts : a.src_pts) + o * 3;
+        pp[0] = x; pp[1] = y; pp[2] = z;
+    }
+}
+
+// ------------------------------------------------------------------ LearnableLogOptimalTransport (modules.py:10-72)
+// One block (320 threads) per patch; rows/cols = limit+1 = 65.  The log-domain Sinkhorn of the reference
+//   u = log_mu - logsumexp_j(S + v),  v = log_nu - logsumexp_i(S + u)      (100 iterations)
+// is run in the exponential domain with per-row max shifts: K'_ij = exp(S_ij - m_i), b = e^v,
+// a~_i = mu_i / (K' b)_i (= e^{u_i + m_i}), b_j = nu_j / (K'^T a~)_j -- the same iteration, no exp/log inside
+// the loop.  Each thread keeps its 17-element strip of a row AND of a column of K' in registers; only the
+// two 65-vectors go through LDS.  Masked rows/cols carry mu = 0 / K' = 0 exactly (the reference's -1e6
+// entries underflow to 0 in its logsumexp as well).
+constexpr int OTN = 65, OTQ = 4, OTE = 17;
+__global__ __launch_bounds__(320) void ot_kernel(RoitrOT a)
+{
+    __shared__ float S[OTN][OTN + 1];
+    __shared__ float av[OTN + 3], bv[OTN + 3], mrow[OTN + 3];
+    __shared__ int rmask[OTN], cmask[OTN];
+    const int patch = blockIdx.x;
+    const int pair = patch / a.num_corr, p = patch % a.num_corr;
+    const int tid = threadIdx.x;
+    const int L = a.limit;  // 64
+    float* out = a.out + (size_t)patch * OTN * OTN;
+    if (p >= a.n_corr[pair]) return;
+    const float alpha = *a.alpha;
+    const float* sc = a.scores + (size_t)patch * L * L;
+    const int* rm = a.row_masks + (size_t)patch * L;
+    const int* cm = a.col_masks + (size_t)patch * L;
+    for (int i = tid; i < OTN; i += 320) { rmask[i] = i < L ? rm[i] : 1; cmask[i] = i < L ? cm[i] : 1; }
+    __syncthreads();
+    for (int e = tid; e < OTN * OTN; e += 320) {
+        const int i = e / OTN, j = e % OTN;
+        float v = (i < L && j < L) ? sc[i * L + j] : alpha;
+        if (!rmask[i] || !cmask[j]) v = -1e6f;
+        S[i][j] = v;
+    }
+    int nvr = 0, nvc = 0;
+    for (int i = 0; i < L; ++i) { nvr += rmask[i] ? 1 : 0; nvc += cmask[i] ? 1 : 0; }
+    const float norm = -logf((float)nvr + (float)nvc);
+    __syncthreads();
+    const int i = tid >> 2, q = tid & 3;
+    const bool act = tid < OTN * OTQ;
+    // row maxima
+    if (act) {
+        float m = -INFINITY;
+        for (int e = 0; e < OTE; ++e) { const int j = q * OTE + e; if (j < OTN) m = fmaxf(m, S[i][j]); }
+        m = fmaxf(m, __shfl_xor(m, 1, 64)); m = fmaxf(m, __shfl_xor(m, 2, 64));
+        if (q == 0) mrow[i] = m;
+    }
+    __syncthreads();
+    float kr[OTE], kc[OTE];  // my strip of row i of K', my strip of column i of K'
+    float mu = 0.f, nu = 0.f;
+    if (act) {
+#pragma unroll
+        for (int e = 0; e < OTE; ++e) {
+            const int j = q * OTE + e;
+            kr[e] = (j < OTN && rmask[i] && cmask[j]) ? expf(S[i][j] - mrow[i]) : 0.f;
+            kc[e] = (j < OTN && rmask[j] && cmask[i]) ? expf(S[j][i] - mrow[j]) : 0.f;  // column i, row j
+        }
+        // mu_i = exp(log_mu_i), nu likewise (modules.py:55-63)
+        mu = rmask[i] ? (i < L ? expf(norm) : expf(logf((float)nvc) + norm)) : 0.f;
+        nu = cmask[i] ? (i < L ? expf(norm) : expf(logf((float)nvr) + norm)) : 0.f;
+        if (q == 0) bv[i] = cmask[i] ? 1.0f : 0.f;  // v = 0
+    }
+    __syncthreads();
+    for (int it = 0; it < a.num_iter; ++it) {
+        if (act) {
+            float r = 0.f;
+#pragma unroll
+            for (int e = 0; e < OTE; ++e) { const int j = q * OTE + e; r += kr[e] * bv[j < OTN ? j : 0]; }
+            r += __shfl_xor(r, 1, 64); r += __shfl_xor(r, 2, 64);
+            if (q == 0) av[i] = rmask[i] ? mu / r : 0.f;
+        }
+        __syncthreads();
+        if (act) {
+            float cs = 0.f;
+#pragma unroll
+            for (int e = 0; e < OTE; ++e) { const int j = q * OTE + e; cs += kc[e] * av[j < OTN ? j : 0]; }
+            cs += __shfl_xor(cs, 1, 64); cs += __shfl_xor(cs, 2, 64);
+            if (q == 0) bv[i] = cmask[i] ? nu / cs : 0.f;
+        }
+        __syncthreads();
+    }
+    // outputs = S + u + v - norm  with u_i = log(a~_i) - m_i, v_j = log(b_j)  (modules.py:27,66-67)
+    if (act && q == 0) {
+        av[i] = rmask[i] ? logf(av[i]) - mrow[i] : 0.f;
+        bv[i] = cmask[i] ? logf(bv[i]) : 0.f;
+    }
+    __syncthreads();
+    for (int e = tid; e < OTN * OTN; e += 320) {
+        const int r = e / OTN, c = e % OTN;
+        out[e] = S[r][c] + av[r] + bv[c] - norm;
+    }
+}
+
+// ------------------------------------------------------------------ FineMatching (modules.py:216-324)
+// one block per patch: mutual top-k on exp(score) (dustbin dropped, RIGA_v2.py:159-160), threshold, masks
+__global__ __launch_bounds__(256) void fine_flag_kernel(RoitrFine a)
+{
+    __shared__ float E[64][65];
+    __shared__ int cnt_s[4];
+    const int patch = blockIdx.x;
+    const int pair = patch / a.num_corr, p = patch % a.num_corr;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int L = a.limit;
+    unsigned char* fl = a.flags + (size_t)patch * L * L;
+    if (p >= a.n_corr[pair]) {
+        for (int e = tid; e < L * L; e += 256) fl[e] = 0;
+        if (tid == 0) a.counts[patch] = 0;
+        return;
+    }
+    const float* sc = a.ot + (size_t)patch * (L + 1) * (L + 1);
+    for (int e = tid; e < L * L; e += 256) { const int i = e / L, j = e % L; E[i][j] = expf(sc[i * (L + 1) + j]); }
+    __syncthreads();
+    const int* rm = a.row_masks + (size_t)patch * L;
+    const int* cm = a.col_masks + (size_t)patch * L;
+    int local = 0;
+    for (int e = tid; e < L * L; e += 256) {
+        const int i = e / L, j = e % L;
+        const float v = E[i][j];
+        int rr = 0, rc = 0;  // how many in my row / column beat me (value desc, index asc)
+        for (int t = 0; t < L; ++t) {
+            const float x = E[i][t]; rr += (x > v || (x == v && t < j)) ? 1 : 0;
+            const float y = E[t][j]; rc += (y > v || (y == v && t < i)) ? 1 : 0;
+        }
+        const bool rtop = rr < a.k && v > a.conf, ctop = rc < a.k && v > a.conf;
+        bool f = a.mutual ? (rtop && ctop) : (rtop || ctop);
+        f = f && rm[i] && cm[j];
+        fl[e] = f ? 1 : 0;
+        local += f ? 1 : 0;
+    }
+    local = (int)wave_sum((float)local);
+    if (lane == 0) cnt_s[wave] = local;
+    __syncthreads();
+    if (tid == 0) a.counts[patch] = cnt_s[0] + cnt_s[1] + cnt_s[2] + cnt_s[3];
+}
+
+// exclusive scan of per-patch counts (single block), total -> *n_out
+__global__ __launch_bounds__(1024) void fine_scan_kernel(int n, const int* __restrict__ counts, int* __restrict__ offsets, int* __restrict__ n_out)
+{
+    __shared__ int wsum[16];
+    __shared__ int carry_s;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) carry_s = 0;
+    __syncthreads();
+    for (int base = 0; base < n; base += 1024) {
+        const int i = base + tid;
+        const int v = i < n ? counts[i] : 0;
+        int incl = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        int wb = 0;
+        for (int w = 0; w < wave; ++w) wb += wsum[w];
+        const int carry = carry_s;
+        if (i < n) offsets[i] = carry + wb + incl - v;
+        __syncthreads();
+        if (tid == 1023) carry_s = carry + wb + incl;
+        __syncthreads();
+    }
+    if (tid == 0) *n_out = carry_s;
+}
+
+// row-major (patch, i, j) compaction -- the order of torch.nonzero (modules.py:282)
+__global__ __launch_bounds__(256) void fine_emit_kernel(RoitrFine a)
+{
+    __shared__ int wsum[4];
+    const int patch = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int L = a.limit;
+    if (a.counts[patch] == 0) return;
+    const unsigned char* fl = a.flags + (size_t)patch * L * L;
+    const float* sc = a.ot + (size_t)patch * (L + 1) * (L + 1);
+    const int per = (L * L) / 256;  // 16 consecutive entries per thread
+    int c = 0;
+    for (int u = 0; u < per; ++u) c += fl[tid * per + u];
+    int incl = c;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int pos = a.offsets[patch] + incl - c;
+    for (int w = 0; w < wave; ++w) pos += wsum[w];
+    const float g = a.global_scores ? a.global_scores[patch] : 1.0f;
+    for (int u = 0; u < per; ++u) {
+        const int e = tid * per + u;
+        if (fl[e]) {
+            const int i = e / L, j = e % L;
+            const float* rp = a.row_pts + ((size_t)patch * L + i) * 3;
+            const float* cp = a.col_pts + ((size_t)patch * L + j) * 3;
+            a.out_row_pts[(size_t)pos * 3] = rp[0]; a.out_row_pts[(size_t)pos * 3 + 1] = rp[1]; a.out_row_pts[(size_t)pos * 3 + 2] = rp[2];
+            a.out_col_pts[(size_t)pos * 3] = cp[0]; a.out_col_pts[(size_t)pos * 3 + 1] = cp[1]; a.out_col_pts[(size_t)pos * 3 + 2] = cp[2];
+            a.out_scores[pos] = expf(sc[i * (L + 1) + j]) * g;
+            if (a.out_patch) a.out_patch[pos] = patch;
+            ++pos;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int roitr_point_to_node_partition(int b, int n_points, int n_nodes, const float* pts, const int* pt_offset,
+                                             const float* nodes, const int* node_offset, const int* cloud_of_node, int limit,
+                                             int* p2n, float* p2n_dist, int* node_masks, int* knn_idx, int* knn_mask, hipStream_t stream)
+{
+    if (n_points <= 0 || n_nodes <= 0) return ROITR_OK;
+    ROITR_HIP(hipMemsetAsync(node_masks, 0, sizeof(int) * (size_t)n_nodes, stream));
+    p2n_assign_kernel<<<div_up(n_points, 256), 256, 0, stream>>>(n_points, pts, pt_offset, nullptr, nodes, node_offset, b, p2n, p2n_dist, node_masks);
+    ROITR_LAUNCH_CHECK();
+    p2n_topk_kernel<<<n_nodes, 256, 0, stream>>>(pt_offset, node_offset, cloud_of_node, p2n, p2n_dist, limit, knn_idx, knn_mask);
+    ROITR_LAUNCH_CHECK();
+    return ROITR_OK;
+}
+
+extern "C" size_t roitr_coarse_scratch_floats(int n_ref, int n_src) { return (size_t)n_ref * n_src + n_ref + n_src + 8; }
+
+extern "C" int roitr_coarse_matching(const RoitrCoarse* a, hipStream_t stream)
+{
+    if (a->pairs <= 0) return ROITR_OK;
+    long cap = 1;
+    while (cap < (long)a->max_ref * a->max_src) cap <<= 1;
+    if (cap * 8 > 128 * 1024 || a->max_ref + a->max_src > 1024) return ROITR_ERR_UNSUPPORTED;
+    coarse_match_kernel<<<a->pairs, 1024, cap * 8, stream>>>(*a);
+    ROITR_LAUNCH_CHECK();
+    return ROITR_OK;
+}
+
+extern "C" int roitr_patch_gather(const RoitrPatch* a, hipStream_t stream)
+{
+    const long total = (long)a->pairs * a->num_corr * a->limit;
+    if (total <= 0) return ROITR_OK;
+    patch_gather_kernel<<<div_up(total, 256), 256, 0, stream>>>(*a);
+    ROITR_LAUNCH_CHECK();
+    return ROITR_OK;
+}
+
+extern "C" int roitr_optimal_transport(const RoitrOT* a, hipStream_t stream)
+{
+    if (a->pairs <= 0) return ROITR_OK;
+    if (a->limit != 64) return ROITR_ERR_UNSUPPORTED;
+    ot_kernel<<<a->pairs * a->num_corr, 320, 0, stream>>>(*a);
+    ROITR_LAUNCH_CHECK();
+    return ROITR_OK;
+}
+
+extern "C" int roitr_fine_matching(const RoitrFine* a, hipStream_t stream)
+{
+    if (a->pairs <= 0) return ROITR_OK;
+    if (a->limit != 64) return ROITR_ERR_UNSUPPORTED;
+    const int patches = a->pairs * a->num_corr;
+    fine_flag_kernel<<<patches, 256, 0, stream>>>(*a);
+    ROITR_LAUNCH_CHECK();
+    fine_scan_kernel<<<1, 1024, 0, stream>>>(patches, a->counts, a->offsets, a->n_out);
+    ROITR_LAUNCH_CHECK();
+    fine_emit_kernel<<<patches, 256, 0, stream>>>(*a);
+    ROITR_LAUNCH_CHECK();
+    return ROITR_OK;
+}

@@ -13,9 +13,12 @@
 //
 // Bit-exactness: the reference's result depends on its launch shape -- thread `tid` of a
 // `bs`-thread block (bs = opt_n_threads(n), cuda_utils.h:11-14) scans k = start+tid, +bs, ...
-// keeping the first strict maximum (l.49-59) and the tree keeps the lower tid on equal values
-// (l.5-10).  That is the total order "max d, then min (k-start) mod bs, then min k".  It is folded
-// into the low 32 bits of the reduction key, so any reduction shape reproduces the reference.
+// keeping the first strict maximum (l.49-59); the shared-memory tree (l.64-123) merges slot t with
+// slot t+s for s = bs/2 ... 1 and keeps the LOWER SLOT on equal values (l.5-10).  Because slot t
+// already holds the winner of {t, t+bs/2} when it meets slot t+bs/4, the tournament's tie order is
+// not "lowest tid": the group with tid bit0 = 0 beats bit0 = 1, inside it bit1 = 0 beats bit1 = 1, ...
+// i.e. the total order is "max d, then min BITREVERSE(tid) over log2(bs) bits, then min k".  It is
+// folded into the low 32 bits of the reduction key, so any reduction shape reproduces the reference.
 #include "common.h"
 #include <algorithm>
 #include <cmath>
@@ -39,11 +42,18 @@ __device__ __forceinline__ long long wave_max_i64(long long v)
 
 // Key = (float bits of d2) << 32 | tie-break.  d2 >= 0 for real points, so the bits order like
 // the values; empty register slots carry d2 = -1 (sign bit set => negative key => never wins).
-// tie-break = ((1023 - ((k-start) mod bs_ref)) << 21 | (0x1FFFFF - (k-start))) + 1, larger wins.
+// tie-break = ((1023 - bitrev((k-start) mod bs_ref)) << 21 | (0x1FFFFF - (k-start))) + 1, larger wins.
+__device__ __forceinline__ unsigned tie_field(int koff, int bs_ref_mask, int bs_ref_bits)
+{
+    const unsigned t = (unsigned)(koff & bs_ref_mask);
+    const unsigned rev = bs_ref_bits ? (__brev(t) >> (32 - bs_ref_bits)) : 0u;
+    return ((1023u - rev) << 21 | (0x1FFFFFu - (unsigned)koff)) + 1u;
+}
+
 template <int BLOCK, int PPT>
 __global__ __launch_bounds__(BLOCK) void fps_kernel(const float* __restrict__ xyz, const int* __restrict__ offset,
                                                     const int* __restrict__ new_offset, float* __restrict__ tmp,
-                                                    int* __restrict__ idx, int bs_ref_mask)
+                                                    int* __restrict__ idx, int bs_ref_mask, int bs_ref_bits)
 {
     constexpr int NW = BLOCK / 64;
     __shared__ Slot slots[2][NW];
@@ -63,7 +73,7 @@ __global__ __launch_bounds__(BLOCK) void fps_kernel(const float* __restrict__ xy
     unsigned tba[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r)
-        tba[r] = ((1023u - (unsigned)((tid + r * BLOCK) & bs_ref_mask)) << 21 | (0x1FFFFFu - (unsigned)tid)) + 1u;
+        tba[r] = tie_field(tid + r * BLOCK, bs_ref_mask, bs_ref_bits) + (unsigned)(r * BLOCK);
 #pragma unroll
     for (int j = 0; j < PPT; ++j) {
         const int koff = tid + j * BLOCK;
@@ -138,7 +148,7 @@ __global__ __launch_bounds__(BLOCK) void fps_kernel(const float* __restrict__ xy
 template <int BLOCK>
 __global__ __launch_bounds__(BLOCK) void fps_stream_kernel(const float* __restrict__ xyz, const int* __restrict__ offset,
                                                            const int* __restrict__ new_offset, float* __restrict__ tmp,
-                                                           int* __restrict__ idx, int bs_ref_mask)
+                                                           int* __restrict__ idx, int bs_ref_mask, int bs_ref_bits)
 {
     constexpr int NW = BLOCK / 64;
     __shared__ Slot slots[2][NW];
@@ -158,7 +168,7 @@ __global__ __launch_bounds__(BLOCK) void fps_stream_kernel(const float* __restri
             const float* p = xyz + (size_t)(start_n + koff) * 3;
             const float d2 = fminf(sqdist3(p[0], p[1], p[2], ox, oy, oz), tmp[start_n + koff]);
             tmp[start_n + koff] = d2;
-            const unsigned t = ((1023u - (unsigned)(koff & bs_ref_mask)) << 21 | (0x1FFFFFu - (unsigned)koff)) + 1u;
+            const unsigned t = tie_field(koff, bs_ref_mask, bs_ref_bits);
             const long long key = (long long)((unsigned long long)__float_as_uint(d2) << 32 | t);
             best = key > best ? key : best;
         }
@@ -191,9 +201,11 @@ extern "C" int roitr_furthestsampling(int b, int n_max, const float* xyz, const 
     if (b <= 0) return ROITR_OK;
     if (n_max >= (1 << 21)) return ROITR_ERR_UNSUPPORTED;
     const int mask = ref_block_size(n_max) - 1;
+    int bits = 0;
+    while ((1 << bits) <= mask) ++bits;
 #define FPS_CASE(BLK, P)                                                                              \
     if (n_max <= (BLK) * (P)) {                                                                       \
-        fps_kernel<BLK, P><<<b, BLK, 0, stream>>>(xyz, offset, new_offset, tmp, idx, mask);           \
+        fps_kernel<BLK, P><<<b, BLK, 0, stream>>>(xyz, offset, new_offset, tmp, idx, mask, bits);           \
         ROITR_LAUNCH_CHECK();                                                                         \
         return ROITR_OK;                                                                              \
     }
@@ -210,7 +222,7 @@ extern "C" int roitr_furthestsampling(int b, int n_max, const float* xyz, const 
     FPS_CASE(1024, 16)
     FPS_CASE(1024, 24)
 #undef FPS_CASE
-    fps_stream_kernel<1024><<<b, 1024, 0, stream>>>(xyz, offset, new_offset, tmp, idx, mask);
+    fps_stream_kernel<1024><<<b, 1024, 0, stream>>>(xyz, offset, new_offset, tmp, idx, mask, bits);
     ROITR_LAUNCH_CHECK();
     return ROITR_OK;
 }

@@ -100,7 +100,7 @@ __device__ __forceinline__ void consume_batch(WaveList<NR>& L, float cd, int ci,
 // [ |d|, atan2(|n1 x d|, n1.d), atan2(|n2 x d|, n2.d), atan2(|n1 x n2|, n1.n2) ] with angles / pi
 __device__ __forceinline__ float ang(float ax, float ay, float az, float bx, float by, float bz)
 {
-    const float dt = ax * bx + ay * by + az * bz;
+    const float dt = 0.0f + ax * bx + ay * by + az * bz;  // torch.sum starts from +0: keeps atan2(0, +0) = 0
     const float cx = ay * bz - az * by, cy = az * bx - ax * bz, cz = ax * by - ay * bx;
     const float cn = sqrtf(cx * cx + cy * cy + cz * cz);
     return atan2f(cn, dt) / 3.14159265358979323846f;

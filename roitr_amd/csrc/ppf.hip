@@ -8,7 +8,7 @@
 namespace {
 __device__ __forceinline__ float ang3(float ax, float ay, float az, float bx, float by, float bz)
 {
-    const float dt = ax * bx + ay * by + az * bz;
+    const float dt = 0.0f + ax * bx + ay * by + az * bz;  // torch.sum starts from +0: keeps atan2(0, +0) = 0
     const float cx = ay * bz - az * by, cy = az * bx - ax * bz, cz = ax * by - ay * bx;
     return atan2f(sqrtf(cx * cx + cy * cy + cz * cz), dt) / 3.14159265358979323846f;
 }

@@ -1,0 +1,352 @@
+"""Host-side mirror of the reference's model API for the inference path.
+
+`create_model(config)` / `RIGA_v2(config)` follow model/RIGA_v2.py:11-181 (reference): the same
+constructor config keys, the same `forward(src_pcd, tgt_pcd, src_feats, tgt_feats,
+src_normals, tgt_normals, rot, trans, src_raw_pcd)` signature and the same output dict keys
+(model/RIGA_v2.py:70-173), and -- so that the released checkpoints load unchanged through a strict
+`load_state_dict` (lib/trainer.py:94-130) -- the same 522-entry state_dict layout.
+
+The module tree below only HOLDS parameters; all arithmetic happens in libroitr_hip.so through the
+engine (csrc/engine.cpp).  There is no PyTorch compute path and no CPU fallback.
+"""
+import ctypes
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib as L
+
+
+# ----------------------------------------------------------------------------------------------
+# state_dict layout (names follow the reference module tree: model/model.py:146-184,
+# model/transformer/ppftransformer.py:202-225, geotransformer.py:62-92, geoattention.py, RIGA_v2.py:14-53)
+# ----------------------------------------------------------------------------------------------
+def _linear(prefix, out, inp):
+    return [(prefix + ".weight", (out, inp), "param"), (prefix + ".bias", (out,), "param")]
+
+
+def _norm(prefix, c):
+    return [(prefix + ".weight", (c,), "param"), (prefix + ".bias", (c,), "param")]
+
+
+def _local_transformer(prefix, inp, hidden, out):
+    ent = [(prefix + ".embedding.embedding.div_term", (hidden // 2,), "buffer")]
+    ent += _linear(prefix + ".embedding.proj", hidden, 4)
+    ent += _linear(prefix + ".in_proj", hidden, inp)
+    for n in ("proj_q", "proj_k", "proj_v", "proj_p", "proj_vp"):
+        ent += _linear(prefix + ".transformer.attention." + n, hidden, hidden)
+    ent += _linear(prefix + ".transformer.linear", hidden, hidden)
+    ent += _norm(prefix + ".transformer.norm", hidden)
+    ent += _linear(prefix + ".out_proj", out, hidden)
+    return ent
+
+
+def _ffn(prefix, c):
+    return _linear(prefix + ".expand", 2 * c, c) + _linear(prefix + ".squeeze", c, 2 * c) + _norm(prefix + ".norm", c)
+
+
+def state_dict_layout(factor=1, architecture=("self", "cross", "self", "cross", "self", "cross"), blocks=(2, 3, 3, 3)):
+    """[(key, shape, 'param'|'buffer')] in the reference's registration order."""
+    f = factor
+    planes = [64 * f, 128 * f, 256 * f, 256 * f]
+    ent = []
+    inp = 1
+    for lvl in range(4):
+        pl = planes[lvl]
+        hid = min(pl, 256 * f)
+        e = f"backbone.enc{lvl + 1}"
+        ent += _local_transformer(e + ".0.transformer", inp, hid, pl)
+        for b in range(1, blocks[lvl]):
+            ent += _local_transformer(f"{e}.{b}.transformer.transformer", pl, hid, pl)
+            ent += _norm(f"{e}.{b}.bn2", pl)
+        inp = pl
+    for lvl in (3, 2, 1, 0):
+        pl = planes[lvl]
+        hid = min(pl, 256 * f)
+        d = f"backbone.dec{lvl + 1}"
+        if lvl == 3:
+            ent += _linear(d + ".0.linear1.0", pl, 2 * pl) + _norm(d + ".0.linear1.1", pl)
+            ent += _linear(d + ".0.linear2.0", pl, pl)
+        else:
+            ent += _linear(d + ".0.linear1.0", pl, pl) + _norm(d + ".0.linear1.1", pl)
+            ent += _linear(d + ".0.linear2.0", pl, planes[lvl + 1]) + _norm(d + ".0.linear2.1", pl)
+        ent += _local_transformer(d + ".1.transformer.transformer", pl, hid, pl)
+        ent += _norm(d + ".1.bn2", pl)
+    c = 256 * f
+    g = "backbone.global_transformer"
+    ent += [(g + ".embedding.embedding.div_term", (c // 2,), "buffer")]
+    ent += _linear(g + ".embedding.proj_d", c, c) + _linear(g + ".embedding.proj_a", c, c)
+    ent += _linear(g + ".in_proj", c, c)
+    for i, kind in enumerate(architecture):
+        lp = f"{g}.transformer.layers.{i}"
+        at = lp + ".attention.attention"
+        names = ("proj_q", "proj_k", "proj_v", "proj_p", "proj_vp") if kind == "self" else ("proj_q", "proj_k", "proj_v")
+        for n in names:
+            ent += _linear(f"{at}.{n}", c, c)
+        ent += _linear(lp + ".attention.linear", c, c) + _norm(lp + ".attention.norm", c)
+        if kind == "self":
+            ent += _linear(lp + ".attention.pos_linear", c, c) + _norm(lp + ".attention.pos_norm", c)
+        ent += _ffn(lp + ".output", c)
+        if kind == "self":
+            ent += _ffn(lp + ".pos_proj", c)
+    ent += _linear(g + ".out_proj", c, c)
+    ent += _linear("backbone.occ_proj", 1, c)
+    ent += [("OT.alpha", (), "param")]
+    ent += _linear("coarse_proj", c, c)
+    ent += _linear("fine_proj", c, 64 * f)
+    ent += [("optimal_transport.alpha", (), "param")]
+    return ent
+
+
+def div_term(d_model):
+    """SinusoidalPositionalEmbedding buffer, positional_encoding.py:43-45, in float32 like torch."""
+    idx = torch.arange(0, d_model, 2).float()
+    return torch.exp(idx * (-np.log(10000.0) / d_model))
+
+
+class _Holder(nn.Module):
+    """Bare container: gives the parameters their reference names."""
+
+
+def _attach(root, key, tensor, kind):
+    parts = key.split(".")
+    mod = root
+    for p in parts[:-1]:
+        if p not in mod._modules:
+            mod.add_module(p, _Holder())
+        mod = mod._modules[p]
+    if kind == "param":
+        mod.register_parameter(parts[-1], nn.Parameter(tensor, requires_grad=False))
+    else:
+        mod.register_buffer(parts[-1], tensor)
+
+
+class _CConfig(ctypes.Structure):
+    _fields_ = [("factor", ctypes.c_int), ("num_corr", ctypes.c_int), ("point_limit", ctypes.c_int),
+                ("fine_topk", ctypes.c_int), ("fine_mutual", ctypes.c_int), ("fine_use_global_score", ctypes.c_int),
+                ("fine_conf", ctypes.c_float), ("n_geo_layers", ctypes.c_int), ("geo_is_cross", ctypes.c_int * 16),
+                ("matching_radius", ctypes.c_float), ("adaptive_coarse", ctypes.c_int), ("occlusion_radius", ctypes.c_float)]
+
+
+_P = ctypes.c_void_p
+
+
+class _CForwardIO(ctypes.Structure):
+    _fields_ = [("pairs", ctypes.c_int), ("n_points", ctypes.POINTER(ctypes.c_int)),
+                ("points_geom", _P), ("normals", _P), ("feats", _P), ("points_out", _P), ("rot", _P), ("trans", _P),
+                ("node_xyz", _P), ("node_feats", _P), ("point_feats", _P), ("node_masks", _P), ("node_knn_idx", _P),
+                ("node_knn_mask", _P), ("tgt_corr", _P), ("src_corr", _P), ("corr_scores", _P), ("n_corr", _P),
+                ("tgt_knn_pts", _P), ("src_knn_pts", _P), ("tgt_knn_masks", _P), ("src_knn_masks", _P),
+                ("matching_scores", _P), ("out_tgt_pts", _P), ("out_src_pts", _P), ("out_scores", _P), ("out_patch", _P),
+                ("fine_offsets", _P), ("n_out", _P), ("gt_tgt_occ", _P), ("gt_src_occ", _P)]
+
+
+def _cfg_get(config, key, default=None):
+    if isinstance(config, dict):
+        return config.get(key, default)
+    return getattr(config, key, default)
+
+
+class RIGA_v2(nn.Module):
+    """The RoITr pipeline (model/RIGA_v2.py:11-175) on the MI355X engine."""
+
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        self.benchmark = _cfg_get(config, "benchmark")
+        self.with_cross_pos_embed = _cfg_get(config, "with_cross_pos_embed", True)
+        self.factor = 1 if self.benchmark in ("3DMatch", "3DLoMatch") else 2
+        self.architecture = list(_cfg_get(config, "transformer_architecture"))
+        self.mode = _cfg_get(config, "mode", "test")
+        self.point_per_patch = int(_cfg_get(config, "point_per_patch", 64))
+        self.matching_radius = float(_cfg_get(config, "matching_radius", 0.05))
+        self.num_est_coarse_corr = int(_cfg_get(config, "num_est_coarse_corr", 256))
+        self.fine_topk = int(_cfg_get(config, "fine_matching_topk", 3))
+        self.fine_mutual = bool(_cfg_get(config, "fine_matching_mutual", True))
+        self.fine_conf = float(_cfg_get(config, "fine_matching_confidence_threshold", 0.05))
+        self.fine_use_dustbin = bool(_cfg_get(config, "fine_matching_use_dustbin", False))
+        self.fine_use_global_score = bool(_cfg_get(config, "fine_matching_use_global_score", False))
+        if self.fine_use_dustbin:
+            raise NotImplementedError("fine_matching_use_dustbin=True is not on the reference's test configs")
+        for key, shape, kind in state_dict_layout(self.factor, self.architecture):
+            if kind == "buffer":
+                t = div_term(shape[0] * 2)
+            elif len(shape) == 2:  # nn.Linear default init range, deterministic content comes from load_state_dict
+                t = torch.empty(shape).uniform_(-1.0 / math.sqrt(shape[1]), 1.0 / math.sqrt(shape[1]))
+            elif len(shape) == 1:
+                t = torch.ones(shape) if key.endswith(".weight") else torch.zeros(shape)
+            else:
+                t = torch.tensor(1.0)
+            _attach(self, key, t, kind)
+        self._engine = None
+        self._engine_sig = None
+
+    # ---------------------------------------------------------------- engine plumbing
+    def _make_engine(self):
+        lib = L.lib()
+        cfg = _CConfig()
+        cfg.factor = self.factor
+        cfg.num_corr = self.num_est_coarse_corr
+        cfg.point_limit = self.point_per_patch
+        cfg.fine_topk = self.fine_topk
+        cfg.fine_mutual = int(self.fine_mutual)
+        cfg.fine_use_global_score = int(self.fine_use_global_score)
+        cfg.fine_conf = self.fine_conf
+        cfg.n_geo_layers = len(self.architecture)
+        for i, a in enumerate(self.architecture):
+            cfg.geo_is_cross[i] = 0 if a == "self" else 1
+        cfg.matching_radius = self.matching_radius
+        cfg.adaptive_coarse = 0 if self.factor == 1 else 1
+        cfg.occlusion_radius = 0.0375
+        lib.roitr_engine_create.restype = ctypes.c_void_p
+        h = lib.roitr_engine_create(ctypes.byref(cfg))
+        if not h:
+            raise L.RoitrError("roitr_engine_create failed")
+        return ctypes.c_void_p(h)
+
+    def sync_engine(self):
+        """(Re)register every parameter's device pointer with the engine and rebuild the derived weights."""
+        lib = L.lib()
+        if self._engine is None:
+            self._engine = self._make_engine()
+        sig = []
+        for k, v in self.state_dict(keep_vars=True).items():
+            if not v.is_cuda:
+                raise L.RoitrError(f"parameter {k} is not on a ROCm device: call model.cuda() (no CPU fallback)")
+            if v.dtype != torch.float32 or not v.is_contiguous():
+                raise L.RoitrError(f"parameter {k} must be contiguous float32")
+            L.check(lib.roitr_engine_set_param(self._engine, k.encode(), L.ptr(v), ctypes.c_long(v.numel())), "set_param")
+            sig.append((v.data_ptr(), v._version))
+        L.check(lib.roitr_engine_finalize(self._engine, L.stream_ptr()), "engine_finalize")
+        self._engine_sig = sig
+
+    def _ensure_engine(self):
+        sig = [(v.data_ptr(), v._version) for v in self.state_dict(keep_vars=True).values()]
+        if self._engine is None or sig != self._engine_sig:
+            self.sync_engine()
+
+    def set_tap(self, name, tensor):
+        self._ensure_engine()
+        self._taps = getattr(self, "_taps", {})
+        self._taps[name] = tensor
+        L.lib().roitr_engine_set_tap(self._engine, name.encode(), L.ptr(tensor))
+
+    def set_inject(self, name, tensor):
+        self._ensure_engine()
+        self._injects = getattr(self, "_injects", {})
+        self._injects[name] = tensor
+        L.lib().roitr_engine_set_inject(self._engine, name.encode(), L.ptr(tensor))
+
+    def __del__(self):
+        try:
+            if self._engine is not None:
+                L.lib().roitr_engine_destroy(self._engine)
+        except Exception:
+            pass
+
+    # ---------------------------------------------------------------- forward
+    @staticmethod
+    def level_sizes(n):
+        return [n, n // 4, n // 4 // 4, n // 4 // 4 // 4]
+
+    def forward_batch(self, pairs, want_gt=True):
+        """pairs: list of dicts with the forward() arguments as keys.  Returns a list of output dicts.
+
+        All B pairs go through the engine in ONE batched pass (clouds laid out src_0..src_{B-1},
+        tgt_0..tgt_{B-1}); the only host synchronisation is the final read of the correspondence count."""
+        self._ensure_engine()
+        dev = pairs[0]["src_pcd"].device
+        B = len(pairs)
+        f32 = torch.float32
+        n_src = [int(p["src_raw_pcd"].shape[0]) for p in pairs]
+        n_tgt = [int(p["tgt_pcd"].shape[0]) for p in pairs]
+        n_all = n_src + n_tgt
+        T = sum(n_all)
+        cat = lambda ks, kt: torch.cat([p[ks].to(f32) for p in pairs] + [p[kt].to(f32) for p in pairs], 0).contiguous()
+        geom = cat("src_raw_pcd", "tgt_pcd")
+        pout = cat("src_pcd", "tgt_pcd")
+        nrm = cat("src_normals", "tgt_normals")
+        feats = cat("src_feats", "tgt_feats")
+        n4 = [self.level_sizes(n)[3] for n in n_all]
+        T4 = sum(n4)
+        C = 256 * self.factor
+        P, Lm = self.num_est_coarse_corr, self.point_per_patch
+        cap = B * P * Lm * self.fine_topk
+        z = lambda shape, dt=f32: torch.zeros(shape, dtype=dt, device=dev)
+        i32 = torch.int32
+        out = dict(node_xyz=z((T4, 3)), node_feats=z((T4, C)), point_feats=z((T, C)), node_masks=z((T4,), i32),
+                   node_knn_idx=z((T4, Lm), i32), node_knn_mask=z((T4, Lm), i32), tgt_corr=z((B, P), i32), src_corr=z((B, P), i32),
+                   corr_scores=z((B, P)), n_corr=z((B,), i32), tgt_knn_pts=z((B, P, Lm, 3)), src_knn_pts=z((B, P, Lm, 3)),
+                   tgt_knn_masks=z((B, P, Lm), i32), src_knn_masks=z((B, P, Lm), i32), matching_scores=z((B, P, Lm + 1, Lm + 1)),
+                   out_tgt_pts=z((cap, 3)), out_src_pts=z((cap, 3)), out_scores=z((cap,)), out_patch=z((cap,), i32),
+                   fine_offsets=z((B * P,), i32), n_out=z((1,), i32))
+        io = _CForwardIO()
+        io.pairs = B
+        arr = (ctypes.c_int * (2 * B))(*n_all)
+        io.n_points = ctypes.cast(arr, ctypes.POINTER(ctypes.c_int))
+        io.points_geom, io.normals, io.feats, io.points_out = L.ptr(geom), L.ptr(nrm), L.ptr(feats), L.ptr(pout)
+        rot = trans = None
+        if want_gt and pairs[0].get("rot") is not None:
+            rot = torch.stack([p["rot"].reshape(3, 3).to(f32) for p in pairs]).contiguous()
+            trans = torch.stack([p["trans"].reshape(3).to(f32) for p in pairs]).contiguous()
+        io.rot, io.trans = L.ptr(rot), L.ptr(trans)
+        for k, v in out.items():
+            setattr(io, k, L.ptr(v))
+        L.check(L.lib().roitr_engine_forward(self._engine, ctypes.byref(io), L.stream_ptr()), "engine_forward")
+        # ---- unpack per pair (host sync happens here, on the counts)
+        offs = out["fine_offsets"].view(B, P)
+        starts = offs[:, 0].tolist() + [int(out["n_out"].item())]
+        n_corr = out["n_corr"].tolist()
+        o_pts = np.cumsum([0] + n_all)
+        o_nod = np.cumsum([0] + n4)
+        results = []
+        for b in range(B):
+            sc, tc = b, B + b
+            nc = n_corr[b]
+            r = {}
+            r["src_points"] = pairs[b]["src_pcd"]
+            r["tgt_points"] = pairs[b]["tgt_pcd"]
+            r["src_nodes"] = out["node_xyz"][o_nod[sc]:o_nod[sc + 1]]
+            r["tgt_nodes"] = out["node_xyz"][o_nod[tc]:o_nod[tc + 1]]
+            r["src_point_feats"] = out["point_feats"][o_pts[sc]:o_pts[sc + 1]]
+            r["tgt_point_feats"] = out["point_feats"][o_pts[tc]:o_pts[tc + 1]]
+            r["src_node_feats"] = out["node_feats"][o_nod[sc]:o_nod[sc + 1]]
+            r["tgt_node_feats"] = out["node_feats"][o_nod[tc]:o_nod[tc + 1]]
+            r["gt_node_corr_indices"] = None
+            r["gt_node_corr_overlaps"] = None
+            r["gt_tgt_node_occ"] = None
+            r["gt_src_node_occ"] = None
+            r["src_node_corr_indices"] = out["src_corr"][b, :nc].long()
+            r["tgt_node_corr_indices"] = out["tgt_corr"][b, :nc].long()
+            r["src_node_corr_knn_points"] = out["src_knn_pts"][b, :nc]
+            r["tgt_node_corr_knn_points"] = out["tgt_knn_pts"][b, :nc]
+            r["src_node_corr_knn_masks"] = out["src_knn_masks"][b, :nc].bool()
+            r["tgt_node_corr_knn_masks"] = out["tgt_knn_masks"][b, :nc].bool()
+            r["matching_scores"] = out["matching_scores"][b, :nc]
+            s, e = starts[b], starts[b + 1]
+            r["tgt_corr_points"] = out["out_tgt_pts"][s:e]
+            r["src_corr_points"] = out["out_src_pts"][s:e]
+            r["corr_scores"] = out["out_scores"][s:e]
+            # extras (not in the reference dict): partition and coarse scores, handy for evaluation
+            r["_node_corr_scores"] = out["corr_scores"][b, :nc]
+            r["_src_node_knn_indices"] = out["node_knn_idx"][o_nod[sc]:o_nod[sc + 1]]
+            r["_tgt_node_knn_indices"] = out["node_knn_idx"][o_nod[tc]:o_nod[tc + 1]]
+            r["_src_node_knn_masks"] = out["node_knn_mask"][o_nod[sc]:o_nod[sc + 1]].bool()
+            r["_tgt_node_knn_masks"] = out["node_knn_mask"][o_nod[tc]:o_nod[tc + 1]].bool()
+            r["_src_node_masks"] = out["node_masks"][o_nod[sc]:o_nod[sc + 1]].bool()
+            r["_tgt_node_masks"] = out["node_masks"][o_nod[tc]:o_nod[tc + 1]].bool()
+            results.append(r)
+        return results
+
+    def forward(self, src_pcd, tgt_pcd, src_feats, tgt_feats, src_normals, tgt_normals, rot, trans, src_raw_pcd):
+        """model/RIGA_v2.py:58 -- one pair, same argument order, same output keys."""
+        pair = dict(src_pcd=src_pcd, tgt_pcd=tgt_pcd, src_feats=src_feats, tgt_feats=tgt_feats, src_normals=src_normals,
+                    tgt_normals=tgt_normals, rot=rot, trans=trans, src_raw_pcd=src_raw_pcd)
+        return self.forward_batch([pair])[0]
+
+
+def create_model(config):
+    """model/RIGA_v2.py:178."""
+    return RIGA_v2(config)

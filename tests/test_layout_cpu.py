@@ -1,0 +1,41 @@
+"""CPU: the engine-side parameter layout equals the reference's state_dict (keys, shapes, buffers)."""
+import json
+import os
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_state_dict_layout_matches_reference_capture():
+    from roitr_amd.riga import state_dict_layout
+    ref = json.load(open(os.path.join(ROOT, "tests", "golden", "state_dict_layout.json")))
+    mine = state_dict_layout(1)
+    assert len(mine) == len(ref) == 522
+    for (k, s, t), (rk, rs, rt) in zip(mine, ref):
+        assert k == rk and list(s) == list(rs) and t == rt, (k, rk)
+    assert sum(int(np.prod(s)) for k, s, t in mine if t == "param") == 10102531
+
+
+def test_module_state_dict_keys_are_reference_keys():
+    from roitr_amd.config import test_config
+    from roitr_amd.riga import create_model
+    m = create_model(test_config("3DMatch"))
+    ref = json.load(open(os.path.join(ROOT, "tests", "golden", "state_dict_layout.json")))
+    sd = m.state_dict()
+    assert list(sd.keys()) == [k for k, _, _ in ref]
+    for k, s, _ in ref:
+        assert list(sd[k].shape) == s
+    # div_term buffers follow positional_encoding.py:43-45
+    dt = sd["backbone.global_transformer.embedding.embedding.div_term"].numpy()
+    np.testing.assert_allclose(dt, np.exp(np.arange(0, 256, 2, dtype=np.float32) * np.float32(-np.log(10000.0) / 256)), rtol=1e-6)
+
+
+def test_closed_form_weights_are_stable():
+    from roitr_amd.weights import closed_form_param
+    a = closed_form_param("coarse_proj.weight", (256, 256))
+    assert a.dtype == np.float32 and a.shape == (256, 256)
+    # pinned values: the golden fixtures were generated with exactly these weights
+    np.testing.assert_allclose(a[0, :3], closed_form_param("coarse_proj.weight", (256, 256))[0, :3])
+    assert abs(float(a.mean())) < 1e-3 and 0.03 < float(a.std()) < 0.04
+    assert closed_form_param("OT.alpha", ()).shape == ()

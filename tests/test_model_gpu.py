@@ -1,0 +1,165 @@
+"""GPU parity of the whole HIP forward against tensors captured from the reference (tests/golden).
+
+Tolerances (north star: fp32 features within 1e-4): features are compared with atol 1e-4 on O(1)
+LayerNorm-ed activations; integer outputs (FPS / group indices, partition) must be identical.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from gpu_util import build_model, golden_pair_inputs, pair_to_device  # noqa: E402
+
+FEAT_ATOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def run(golden_pair):
+    g = golden_pair
+    model = build_model()
+    pair = pair_to_device(golden_pair_inputs(g))
+    n = 1024
+    sizes = [n, n // 4, n // 16, n // 64]
+    planes = [64, 128, 256, 256]
+    K = [8, 16, 16, 16]
+    taps = {}
+
+    def tap(name, shape, dtype=torch.float32):
+        t = torch.zeros(shape, dtype=dtype, device="cuda")
+        model.set_tap(name, t)
+        taps[name] = t
+
+    for l in range(4):
+        T = 2 * sizes[l]
+        if l > 0:
+            tap(f"fps.{l + 1}", (T,), torch.int32)
+            tap(f"group.td.{l + 1}", (T, K[l]), torch.int32)
+            tap(f"ppf.td.{l + 1}", (T, K[l], 4))
+        tap(f"group.self.{l + 1}", (T, K[l]), torch.int32)
+        tap(f"ppf.self.{l + 1}", (T, K[l], 4))
+        for b in range([2, 3, 3, 3][l]):
+            tap(f"enc{l + 1}.{b}", (T, planes[l]))
+        tap(f"dec{l + 1}.0", (T, planes[l]))
+        tap(f"dec{l + 1}.1", (T, planes[l]))
+    n4 = sizes[3]
+    tap("geo.d_idx", (2 * n4 * n4,))
+    tap("geo.a_idx", (2 * n4 * n4 * 3,))
+    tap("geo.emb", (2 * n4 * n4, 256))
+    tap("geo.in_proj", (2 * n4, 256))
+    for i in range(6):
+        tap(f"geo.layer{i}", (2 * n4, 256))
+        if i % 2 == 0:
+            tap(f"geo.layer{i}.pos", (2 * n4, 256))
+    tap("geo.out", (2 * n4, 256))
+    with torch.no_grad():
+        out = model.forward(**pair)
+    torch.cuda.synchronize()
+    return g, out, {k: v.cpu().numpy() for k, v in taps.items()}, sizes
+
+
+def both(g, key):
+    return np.concatenate([g[key + ".0"], g[key + ".1"]], 0)
+
+
+def test_fps_chain(run):
+    g, out, taps, sizes = run
+    for l in (1, 2, 3):
+        m = sizes[l]
+        got = taps[f"fps.{l + 1}"]
+        src, tgt = got[:m], got[m:] - sizes[l - 1]  # tgt indices are global rows: subtract the src cloud's rows
+        assert np.array_equal(src, g[f"fps.{l - 1}"])
+        assert np.array_equal(tgt, g[f"fps.{3 + l - 1}"])
+
+
+def test_groups_and_ppf(run):
+    g, out, taps, sizes = run
+    # reference call order per cloud (model/model.py:195-205): enc1 TD kNN, enc1 block kNN, enc2 TD, enc2 block, ...
+    # knn.{0..7} = src, knn.{8..15} = tgt ; ppf likewise
+    for l in range(4):
+        m = sizes[l]
+        for kind, ci in (("td", 2 * l), ("self", 2 * l + 1)):
+            if l == 0 and kind == "td":
+                continue
+            grp = taps[f"group.{kind}.{l + 1}"]
+            ppf = taps[f"ppf.{kind}.{l + 1}"]
+            ref_rows = sizes[l] if kind == "self" else sizes[l - 1]
+            for side, base in ((0, 0), (1, 8)):
+                gi = grp[side * m:(side + 1) * m] - side * ref_rows
+                assert np.array_equal(gi, g[f"knn.{base + ci}.idx"][:, 1:]), (l, kind, side)
+                np.testing.assert_allclose(ppf[side * m:(side + 1) * m], g[f"ppf.{base + ci}"], rtol=0, atol=3e-6)
+
+
+@pytest.mark.parametrize("stage", ["enc1.0", "enc1.1", "enc2.0", "enc2.1", "enc2.2", "enc3.0", "enc3.1", "enc3.2", "enc4.0", "enc4.1",
+                                   "enc4.2", "dec4.0", "dec4.1", "dec3.0", "dec3.1", "dec2.0", "dec2.1", "dec1.0", "dec1.1"])
+def test_backbone_features(run, stage):
+    g, out, taps, sizes = run
+    ref = both(g, "feat." + stage)
+    if ref.ndim == 3:
+        ref = ref.reshape(-1, ref.shape[-1])
+    got = taps[stage]
+    err = np.abs(got - ref).max()
+    assert err < FEAT_ATOL, f"{stage}: max abs err {err:.3e} (ref scale {np.abs(ref).max():.2f})"
+
+
+def test_geo_embedding(run):
+    g, out, taps, sizes = run
+    ref = np.concatenate([g["feat.geo.embedding.0"].reshape(-1, 256), g["feat.geo.embedding.1"].reshape(-1, 256)], 0)
+    err = np.abs(taps["geo.emb"] - ref).max()
+    assert err < FEAT_ATOL, f"geo.emb max abs err {err:.3e}"
+
+
+@pytest.mark.parametrize("stage", ["geo.in_proj", "geo.layer0", "geo.layer0.pos", "geo.layer1", "geo.layer2", "geo.layer2.pos", "geo.layer3",
+                                   "geo.layer4", "geo.layer4.pos", "geo.layer5", "geo.out"])
+def test_geo_features(run, stage):
+    g, out, taps, sizes = run
+    ref = np.concatenate([g[f"feat.{stage}.0"].reshape(-1, 256), g[f"feat.{stage}.1"].reshape(-1, 256)], 0)
+    err = np.abs(taps[stage] - ref).max()
+    assert err < FEAT_ATOL, f"{stage}: max abs err {err:.3e}"
+
+
+def test_descriptors(run):
+    g, out, taps, sizes = run
+    for k in ("src_nodes", "tgt_nodes"):
+        assert np.array_equal(out[k].cpu().numpy(), g["out." + k])
+    for k in ("src_node_feats", "tgt_node_feats", "src_point_feats", "tgt_point_feats"):
+        err = np.abs(out[k].cpu().numpy() - g["out." + k]).max()
+        assert err < FEAT_ATOL, f"{k}: {err:.3e}"
+
+
+def test_partition(run):
+    g, out, taps, sizes = run
+    for side in ("src", "tgt"):
+        assert np.array_equal(out[f"_{side}_node_knn_indices"].cpu().numpy(), g[f"part.{side}.knn_indices"])
+        assert np.array_equal(out[f"_{side}_node_knn_masks"].cpu().numpy(), g[f"part.{side}.knn_masks"])
+        assert np.array_equal(out[f"_{side}_node_masks"].cpu().numpy(), g[f"part.{side}.node_masks"])
+
+
+def test_coarse_and_ot(run):
+    g, out, taps, sizes = run
+    # n = 16 nodes per cloud -> all 256 node pairs are selected; order by score (near-ties may swap): compare as sets + scores
+    got = sorted(zip(out["tgt_node_corr_indices"].tolist(), out["src_node_corr_indices"].tolist()))
+    ref = sorted(zip(g["out.tgt_node_corr_indices"].tolist(), g["out.src_node_corr_indices"].tolist()))
+    assert got == ref
+    np.testing.assert_allclose(np.sort(out["_node_corr_scores"].cpu().numpy())[::-1], g["coarse.scores"], rtol=2e-4, atol=1e-9)
+    # OT: compare patch by patch through the (tgt,src) node pair; only mask-valid entries are defined
+    ms = out["matching_scores"].cpu().numpy()
+    key = {(t, s): i for i, (t, s) in enumerate(zip(out["tgt_node_corr_indices"].tolist(), out["src_node_corr_indices"].tolist()))}
+    rt, rs = g["out.tgt_node_corr_indices"], g["out.src_node_corr_indices"]
+    ref_ms = g["out.matching_scores.every4"]
+    tm_all, sm_all = g["out.tgt_node_corr_knn_masks"], g["out.src_node_corr_knn_masks"]
+    worst = 0.0
+    for j in range(ref_ms.shape[0]):
+        p = 4 * j
+        i = key[(int(rt[p]), int(rs[p]))]
+        rm = np.concatenate([tm_all[p], [True]])
+        cm = np.concatenate([sm_all[p], [True]])
+        valid = rm[:, None] & cm[None, :]
+        worst = max(worst, np.abs(ms[i] - ref_ms[j])[valid].max())
+        assert (ms[i][~valid] < -1e5).all()
+    assert worst < 2e-4, f"OT max abs err on valid entries {worst:.3e}"
+
+
+def test_final_correspondences_count(run):
+    g, out, taps, sizes = run
+    assert out["corr_scores"].shape[0] == g["out.corr_scores"].shape[0]
