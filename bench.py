@@ -1,0 +1,165 @@
+#!/usr/bin/env python3
+"""Headline benchmark: RoITr test-mode forward throughput in point-cloud pairs/s on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--pairs-per-step B] [--n-points 5000]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = one engine forward over B independent synthetic 3DMatch-sized pairs (BASELINE.json
+configs[1]: ~5000 points per cloud, fp32, 3DMatch test settings) -- the complete path of
+model/RIGA_v2.py:58-175: FPS, kNN/PPF, local PPF-attention encoder/decoder, global geometric transformer,
+partition, coarse matching, optimal transport, fine matching.  Inputs are resident in HBM before the timed
+region.  Pairs shard over ranks with no data-path collective (weak scaling: every rank runs the same
+per-step work on its own pairs); the only collective is the final gather of the per-rank correspondence
+counts (the KB-scale result record of SURVEY.md 8e), outside the per-pair path.
+
+Prints ONE JSON line (rank 0) with `roofline` (dominant kernel, measured live with HIP events on the
+launch stream) and `cpu_baseline` (the CPU oracle timed on this host, rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--pairs-per-step", type=int, default=8)
+    ap.add_argument("--n-points", type=int, default=5000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-seconds", type=float, default=20.0)
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    distributed = world > 1
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback in roitr_amd)")
+    torch.cuda.set_device(local_rank)
+    if distributed:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl")  # RCCL on ROCm
+
+    from roitr_amd.shard import gather_counts, pairs_for_rank
+    from roitr_amd.synthetic import make_pair
+    from tests.gpu_util import build_model, pair_to_device
+
+    model = build_model("3DMatch")
+    B, N = args.pairs_per_step, args.n_points
+    # distinct resident pairs, cycled; pair ids are sharded over ranks exactly like the test loop would
+    n_resident = max(2 * B, 16)
+    ids = pairs_for_rank(n_resident * world, rank, world)
+    pool = [pair_to_device(make_pair(N, config=2, pair_index=i)) for i in ids]
+
+    def batch(step):
+        return [pool[(step * B + j) % len(pool)] for j in range(B)]
+
+    def barrier():
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with torch.no_grad():
+        for s in range(args.warmup):
+            model.forward_batch(batch(s), want_gt=True)
+        barrier()
+        model.profile_reset()
+        t0 = time.perf_counter()
+        n_corr_total = 0
+        for s in range(args.steps):
+            res = model.forward_batch(batch(args.warmup + s), want_gt=True)
+            n_corr_total += sum(int(r["corr_scores"].shape[0]) for r in res)
+        barrier()
+        dt = time.perf_counter() - t0
+    prof = model.profile_read()
+
+    # max over ranks of the timed region; total work = pairs of all ranks
+    if distributed:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        counts = gather_counts(n_corr_total)
+    else:
+        counts = [n_corr_total]
+    total_pairs = B * args.steps * world
+    value = total_pairs / dt
+
+    out = {
+        "metric": "point-cloud pairs/s",
+        "value": round(value, 3),
+        "unit": "pairs/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(1e3 * dt / args.steps, 4),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": f"3DMatch-sized synthetic pairs: {N} pts/cloud src+tgt, fp32, 3DMatch test settings "
+                        f"(P=256 patches x 64 pts, 100 Sinkhorn iterations), full RIGA_v2 forward",
+            "pairs_per_step": B,
+            "n_points": N,
+            "sharding": f"pairs over {world} rank(s), no data-path collective",
+            "correspondences_found": int(sum(counts)),
+        },
+    }
+    if rank == 0:
+        out["roofline"] = roofline(prof, B, N)
+        out["kernel_ms_per_step"] = {k: round(v["ms"] / max(args.steps, 1), 4) for k, v in prof.items()}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(N, args.cpu_baseline_seconds)
+        print(json.dumps(out), flush=True)
+    if distributed:
+        dist.destroy_process_group()
+
+
+def roofline(prof, B, N):
+    """Dominant kernel family of the timed region (by summed HIP-event time) against the HBM roofline.
+
+    Algorithmic bytes (SURVEY.md 8d / DESIGN.md): FPS n->m: 12n + 4m (+ 8n for the in/out `tmp` the
+    reference API carries); kNN+PPF: 24R + 24M[queries != refs] + 4MK + 16MK."""
+    if not prof:
+        return None
+    name = max(prof, key=lambda k: prof[k]["ms"])
+    p = prof[name]
+    launches = max(p["launches"], 1)
+    avg_ms = p["ms"] / launches
+    bytes_per_launch = p["bytes"] / launches
+    achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    return {"bound": "hbm", "kernel": name, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None, "avg_launch_ms": round(avg_ms, 5),
+            "algorithmic_bytes_per_launch": int(bytes_per_launch), "launches_timed": int(p["launches"])}
+
+
+def cpu_baseline(N, budget_s):
+    """The CPU oracle (oracle/, 'port' kind) on this host: full forward of ONE pair of the same workload."""
+    try:
+        from oracle import roitr_ref
+    except Exception as e:  # oracle model restatement not available
+        return {"value": None, "unit": "pairs/s", "cores": 0, "kind": "port", "sample": f"unavailable: {e}"}
+    return roitr_ref.timed_baseline(N, budget_s)
+
+
+if __name__ == "__main__":
+    main()

@@ -23,6 +23,7 @@
 #include <vector>
 
 #include "common.h"
+#include "prof.h"
 #include "roitr_engine.h"
 #include "roitr_pointops.h"
 
@@ -538,6 +539,8 @@ extern "C" int roitr_engine_forward(void* h, const RoitrForwardIO* io, hipStream
     D.partner = D.cloud_of_node + T4;
     D.eoff = (long*)(ddesc + ((desc_ints * 4 + 15) & ~(size_t)15));
 
+    roitr_prof_begin(ROITR_PROF_PH_FORWARD, 0.0, st);
+    roitr_prof_begin(ROITR_PROF_PH_GEOM, 0.0, st);
     // ---------------- hierarchy geometry: FPS, kNN groups, PPF  (model/model.py:56-80, 30-42)
     const float* p[4]; const float* nrm[4];
     p[0] = io->points_geom; nrm[0] = io->normals;
@@ -556,6 +559,7 @@ extern "C" int roitr_engine_forward(void* h, const RoitrForwardIO* io, hipStream
             if (A.fail) break;
             // tmp = 1e10 (functions/pointops.py:22)
             ROITR_HIP(hipMemsetD32Async((hipDeviceptr_t)fps_tmp, 0x501502F9 /* bits of 1e10f */, V.T[l - 1], st));
+            roitr_prof_next_bytes(ROITR_PROF_FPS, 12.0 * V.T[l - 1] + 4.0 * V.T[l] + 8.0 * V.T[l - 1]);
             CHK(roitr_furthestsampling(NC, V.nmax[l - 1], p[l - 1], D.off[l - 1], D.off[l], fps_tmp, down[l], st));
             CHK(tap(E, st, "fps." + std::to_string(l + 1), down[l], sizeof(int) * V.T[l]));
             CHK(roitr_gather_rows(V.T[l], 3, p[l - 1], down[l], 0, pl, st));
@@ -590,6 +594,8 @@ extern "C" int roitr_engine_forward(void* h, const RoitrForwardIO* io, hipStream
     }
     if (A.fail) { roitr_set_error("arena exhausted (geometry)", __FILE__, __LINE__); return ROITR_ERR_ARG; }
 
+    roitr_prof_end(ROITR_PROF_PH_GEOM, st);
+    roitr_prof_begin(ROITR_PROF_PH_ENC, 0.0, st);
     // ---------------- encoder
     float* xe[4];
     {
@@ -613,6 +619,8 @@ extern "C" int roitr_engine_forward(void* h, const RoitrForwardIO* io, hipStream
     }
     if (A.fail) { roitr_set_error("arena exhausted (encoder)", __FILE__, __LINE__); return ROITR_ERR_ARG; }
 
+    roitr_prof_end(ROITR_PROF_PH_ENC, st);
+    roitr_prof_begin(ROITR_PROF_PH_GEO, 0.0, st);
     // ---------------- global geometric transformer (geotransformer.py:94-133), all pairs batched
     float* gfeat = A.get<float>((size_t)T4 * C4);
     {
@@ -706,6 +714,8 @@ extern "C" int roitr_engine_forward(void* h, const RoitrForwardIO* io, hipStream
         A.off = mark;
     }
 
+    roitr_prof_end(ROITR_PROF_PH_GEO, st);
+    roitr_prof_begin(ROITR_PROF_PH_DEC, 0.0, st);
     // ---------------- decoder (model/model.py:223-231)
     float* xd[4];
     {
@@ -756,6 +766,8 @@ extern "C" int roitr_engine_forward(void* h, const RoitrForwardIO* io, hipStream
         CHK(tap(E, st, "dec" + std::to_string(l + 1) + ".1", xd[l], sizeof(float) * (size_t)Tl * pl));
     }
 
+    roitr_prof_end(ROITR_PROF_PH_DEC, st);
+    roitr_prof_begin(ROITR_PROF_PH_MATCH, 0.0, st);
     // ---------------- heads (RIGA_v2.py:64-68) and node coordinates (model/model.py:233-235)
     const float* pts_out = io->points_out ? io->points_out : io->points_geom;
     float* node_xyz = io->node_xyz ? io->node_xyz : A.get<float>((size_t)T4 * 3);
@@ -842,5 +854,7 @@ extern "C" int roitr_engine_forward(void* h, const RoitrForwardIO* io, hipStream
         fm.out_row_pts = o_t; fm.out_col_pts = o_s; fm.out_scores = o_sc; fm.out_patch = io->out_patch;
         CHK(roitr_fine_matching(&fm, st));
     }
+    roitr_prof_end(ROITR_PROF_PH_MATCH, st);
+    roitr_prof_end(ROITR_PROF_PH_FORWARD, st);
     return 0;
 }

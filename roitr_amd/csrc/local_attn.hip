@@ -16,6 +16,7 @@
 // group.  Phase 2: lane = channel; the value rows are read fully coalesced.  Gathered k/v rows are
 // never materialised (the reference builds (M,K,H) copies with fancy indexing, attention.py:174-175).
 #include "common.h"
+#include "prof.h"
 #include "roitr_engine.h"
 
 namespace {
@@ -118,7 +119,10 @@ extern "C" int roitr_local_attention(const RoitrLocalAttn* a, hipStream_t stream
     const size_t per_wave = (size_t)a->H + 5 * a->heads + 64 + 4 * a->heads + 64;
     const size_t lds = per_wave * 4 * sizeof(float);
     if (per_wave % 4) return ROITR_ERR_UNSUPPORTED;  // keeps every wave's q row 16-byte aligned
+    // algorithmic bytes: q row + K gathered k and v rows + ppf + idx in, one row out
+    roitr_prof_begin(ROITR_PROF_LOCAL_ATTN, (double)a->M * ((a->H + 20.0) * 4 + a->K * (2.0 * a->H * 4 + 20.0) + a->H * 4.0), stream);
     local_attn_kernel<<<div_up(a->M, 4), 256, lds, stream>>>(*a);
+    roitr_prof_end(ROITR_PROF_LOCAL_ATTN, stream);
     ROITR_LAUNCH_CHECK();
     return ROITR_OK;
 }

@@ -4,6 +4,7 @@
 //
 // All kernels are batched over `pairs`: clouds are laid out [src_0..src_{B-1}, tgt_0..tgt_{B-1}].
 #include "common.h"
+#include "prof.h"
 #include "roitr_engine.h"
 
 namespace {
@@ -469,7 +470,9 @@ extern "C" int roitr_optimal_transport(const RoitrOT* a, hipStream_t stream)
 {
     if (a->pairs <= 0) return ROITR_OK;
     if (a->limit != 64) return ROITR_ERR_UNSUPPORTED;
+    roitr_prof_begin(ROITR_PROF_OT, (double)a->pairs * a->num_corr * (64.0 * 64 + 65.0 * 65) * 4.0, stream);
     ot_kernel<<<a->pairs * a->num_corr, 320, 0, stream>>>(*a);
+    roitr_prof_end(ROITR_PROF_OT, stream);
     ROITR_LAUNCH_CHECK();
     return ROITR_OK;
 }

@@ -20,6 +20,7 @@
 // i.e. the total order is "max d, then min BITREVERSE(tid) over log2(bs) bits, then min k".  It is
 // folded into the low 32 bits of the reduction key, so any reduction shape reproduces the reference.
 #include "common.h"
+#include "prof.h"
 #include <algorithm>
 #include <cmath>
 
@@ -205,7 +206,9 @@ extern "C" int roitr_furthestsampling(int b, int n_max, const float* xyz, const 
     while ((1 << bits) <= mask) ++bits;
 #define FPS_CASE(BLK, P)                                                                              \
     if (n_max <= (BLK) * (P)) {                                                                       \
-        fps_kernel<BLK, P><<<b, BLK, 0, stream>>>(xyz, offset, new_offset, tmp, idx, mask, bits);           \
+        roitr_prof_begin(ROITR_PROF_FPS, -1.0, stream);                                               \
+        fps_kernel<BLK, P><<<b, BLK, 0, stream>>>(xyz, offset, new_offset, tmp, idx, mask, bits);     \
+        roitr_prof_end(ROITR_PROF_FPS, stream);                                                       \
         ROITR_LAUNCH_CHECK();                                                                         \
         return ROITR_OK;                                                                              \
     }

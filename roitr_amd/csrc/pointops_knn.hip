@@ -23,6 +23,7 @@
 //     second kernel REPLAYS the reference algorithm for them exactly -- index-order scan, max-heap,
 //     heap_sort -- wave-cooperatively (64 distances per step, ballot-pruned against the heap root).
 #include "common.h"
+#include "prof.h"
 #include <math.h>
 
 #define KNN_FILL 1e10f  // knnquery_cuda_kernel.cu:89
@@ -541,7 +542,9 @@ extern "C" int roitr_knn_build_grid(int b, int n, int m_capacity, const float* x
 {
     if (b <= 0 || n <= 0) return ROITR_OK;
     WsView v = carve(ws, b, n, m_capacity);
+    roitr_prof_begin(ROITR_PROF_GRID, 12.0 * n + 16.0 * n, stream);
     grid_build_kernel<<<b, 1024, 0, stream>>>(xyz, offset, v.grids, v.cell_start, v.sorted, 3.0f);
+    roitr_prof_end(ROITR_PROF_GRID, stream);
     ROITR_LAUNCH_CHECK();
     return ROITR_OK;
 }
@@ -560,6 +563,13 @@ extern "C" int roitr_knnquery_ex(int b, int n, int m, int nsample, const float* 
     KnnOut o = {idx, dist2, group_idx, ppf, ref_normals, query_normals, v.tie_count, v.tie_list};
     ROITR_HIP(hipMemsetAsync(v.tie_count, 0, sizeof(int), stream));
     const int blocks = div_up(m, 4);
+    // algorithmic bytes: refs xyz(+normals) once, queries when distinct, idx + dist2/ppf rows out
+    {
+        const int kk = group_idx || ppf ? nsample - 1 : nsample;
+        double bytes = (ppf ? 24.0 : 12.0) * n + (new_xyz != xyz ? (ppf ? 24.0 : 12.0) * m : 0.0);
+        bytes += ((idx ? 4.0 * nsample : 0.0) + (dist2 ? 4.0 * nsample : 0.0) + (group_idx ? 4.0 * kk : 0.0) + (ppf ? 16.0 * kk : 0.0)) * m;
+        roitr_prof_begin(ROITR_PROF_KNN, bytes, stream);
+    }
     if (use_grid) {
         if (nsample + 1 <= 64)
             knn_grid_kernel<1><<<blocks, 256, 0, stream>>>(m, nsample, xyz, new_xyz, offset, new_offset, v.grids, v.cell_start, v.sorted, o);
@@ -571,8 +581,11 @@ extern "C" int roitr_knnquery_ex(int b, int n, int m, int nsample, const float* 
         else
             knn_brute_kernel<2><<<blocks, 256, 0, stream>>>(m, nsample, xyz, new_xyz, offset, new_offset, o);
     }
+    roitr_prof_end(ROITR_PROF_KNN, stream);
     ROITR_LAUNCH_CHECK();
+    roitr_prof_begin(ROITR_PROF_REPLAY, 0.0, stream);
     knn_replay_kernel<<<min(m, 128), 64, 0, stream>>>(nsample, xyz, new_xyz, offset, new_offset, o);
+    roitr_prof_end(ROITR_PROF_REPLAY, stream);
     ROITR_LAUNCH_CHECK();
     return ROITR_OK;
 }

@@ -1,0 +1,92 @@
+// Optional HIP-event instrumentation (used by bench.py for the `roofline` object): when enabled, the launch
+// wrappers bracket their dominant kernel with an event pair on the launch stream and account its
+// algorithmic bytes.  Disabled by default: zero events, zero overhead on the product path.
+#include <hip/hip_runtime.h>
+
+#include <mutex>
+#include <vector>
+
+#include "prof.h"
+
+namespace {
+struct Rec { int cls; hipEvent_t a, b; double bytes; };
+std::mutex g_mu;
+bool g_on = false;
+std::vector<Rec> g_open;   // begun, not ended (one per class at a time)
+std::vector<Rec> g_done;
+std::vector<hipEvent_t> g_pool;
+double g_ms[ROITR_PROF_CLASSES], g_bytes[ROITR_PROF_CLASSES];
+long g_launches[ROITR_PROF_CLASSES];
+double g_next_bytes[ROITR_PROF_CLASSES];
+
+hipEvent_t get_event()
+{
+    if (!g_pool.empty()) { hipEvent_t e = g_pool.back(); g_pool.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+void drain()
+{
+    for (auto& r : g_done) {
+        (void)hipEventSynchronize(r.b);
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) { g_ms[r.cls] += ms; g_bytes[r.cls] += r.bytes; g_launches[r.cls] += 1; }
+        g_pool.push_back(r.a); g_pool.push_back(r.b);
+    }
+    g_done.clear();
+}
+}  // namespace
+
+extern "C" void roitr_prof_enable(int on)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_on = on != 0;
+}
+
+extern "C" void roitr_prof_reset(void)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    drain();
+    for (int i = 0; i < ROITR_PROF_CLASSES; ++i) { g_ms[i] = 0; g_bytes[i] = 0; g_launches[i] = 0; }
+}
+
+extern "C" int roitr_prof_read(int cls, double* ms, long* launches, double* bytes)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (cls < 0 || cls >= ROITR_PROF_CLASSES) return 1;
+    drain();
+    *ms = g_ms[cls]; *launches = g_launches[cls]; *bytes = g_bytes[cls];
+    return 0;
+}
+
+// bytes for the next begin() of `cls` that passes a negative byte count (the wrapper does not know the sizes)
+extern "C" void roitr_prof_next_bytes(int cls, double bytes)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (cls >= 0 && cls < ROITR_PROF_CLASSES) g_next_bytes[cls] = bytes;
+}
+
+void roitr_prof_begin(int cls, double bytes, hipStream_t st)
+{
+    if (!g_on) return;
+    std::lock_guard<std::mutex> lk(g_mu);
+    Rec r; r.cls = cls; r.bytes = bytes >= 0.0 ? bytes : g_next_bytes[cls]; r.a = get_event(); r.b = get_event();
+    (void)hipEventRecord(r.a, st);
+    g_open.push_back(r);
+}
+
+void roitr_prof_end(int cls, hipStream_t st)
+{
+    if (!g_on) return;
+    std::lock_guard<std::mutex> lk(g_mu);
+    for (size_t i = g_open.size(); i-- > 0;) {
+        if (g_open[i].cls == cls) {
+            (void)hipEventRecord(g_open[i].b, st);
+            g_done.push_back(g_open[i]);
+            g_open.erase(g_open.begin() + i);
+            return;
+        }
+    }
+}

@@ -1,0 +1,27 @@
+// Event-profiling classes (see prof.cpp).  Kernel classes bracket exactly one kernel launch; phase classes
+// bracket a run of launches inside the engine forward.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#define ROITR_PROF_CLASSES 12
+enum {
+    ROITR_PROF_FPS = 0,        // fps_kernel, one launch
+    ROITR_PROF_KNN = 1,        // knn_grid_kernel / knn_brute_kernel (the query kernel incl. fused PPF), one launch
+    ROITR_PROF_GRID = 2,       // grid_build_kernel
+    ROITR_PROF_REPLAY = 3,     // knn_replay_kernel
+    ROITR_PROF_PH_GEOM = 4,    // engine phases
+    ROITR_PROF_PH_ENC = 5,
+    ROITR_PROF_PH_GEO = 6,
+    ROITR_PROF_PH_DEC = 7,
+    ROITR_PROF_PH_MATCH = 8,
+    ROITR_PROF_PH_FORWARD = 9,
+    ROITR_PROF_OT = 10,        // ot_kernel
+    ROITR_PROF_LOCAL_ATTN = 11 // local_attn_kernel
+};
+
+void roitr_prof_begin(int cls, double bytes, hipStream_t st);
+void roitr_prof_end(int cls, hipStream_t st);
+extern "C" void roitr_prof_enable(int on);
+extern "C" void roitr_prof_reset(void);
+extern "C" void roitr_prof_next_bytes(int cls, double bytes);
+extern "C" int roitr_prof_read(int cls, double* ms, long* launches, double* bytes);

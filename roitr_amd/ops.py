@@ -30,3 +30,115 @@ def calc_ppf_gpu(points, point_normals, patches, patch_normals):
     m, k, _ = patches.shape
     grp = torch.arange(m * k, dtype=torch.int32, device=points.device).view(m, k)
     return calc_ppf(points, point_normals, patches.reshape(-1, 3), patch_normals.reshape(-1, 3), grp)
+
+
+# ------------------------------------------------------------------------------------------------
+# Matching-tail operators (single pair / single batch of patches), thin ctypes fronts of the batched kernels.
+# ------------------------------------------------------------------------------------------------
+import ctypes  # noqa: E402
+
+_P = ctypes.c_void_p
+
+
+class _Coarse(ctypes.Structure):
+    _fields_ = [("pairs", ctypes.c_int), ("C", ctypes.c_int), ("num_corr", ctypes.c_int), ("dual_norm", ctypes.c_int),
+                ("max_ref", ctypes.c_int), ("max_src", ctypes.c_int), ("feats", _P), ("node_offset", _P), ("node_masks", _P),
+                ("scratch", _P), ("scratch_stride", ctypes.c_long), ("tgt_corr", _P), ("src_corr", _P), ("corr_scores", _P),
+                ("n_corr", _P)]
+
+
+class _OT(ctypes.Structure):
+    _fields_ = [("pairs", ctypes.c_int), ("num_corr", ctypes.c_int), ("limit", ctypes.c_int), ("num_iter", ctypes.c_int),
+                ("n_corr", _P), ("scores", _P), ("row_masks", _P), ("col_masks", _P), ("alpha", _P), ("out", _P)]
+
+
+class _Fine(ctypes.Structure):
+    _fields_ = [("pairs", ctypes.c_int), ("num_corr", ctypes.c_int), ("limit", ctypes.c_int), ("k", ctypes.c_int),
+                ("mutual", ctypes.c_int), ("conf", ctypes.c_float), ("n_corr", _P), ("ot", _P), ("row_masks", _P),
+                ("col_masks", _P), ("row_pts", _P), ("col_pts", _P), ("global_scores", _P), ("flags", _P), ("counts", _P),
+                ("offsets", _P), ("n_out", _P), ("out_row_pts", _P), ("out_col_pts", _P), ("out_scores", _P), ("out_patch", _P)]
+
+
+def point_to_node_partition(points, nodes, point_limit):
+    """lib/utils.py:428-471 -> (point_to_node (N,) i64, node_masks (M,) bool, node_knn_indices (M,K) i64, node_knn_masks bool)"""
+    dev = points.device
+    N, M = points.shape[0], nodes.shape[0]
+    i32 = torch.int32
+    po = torch.tensor([N], dtype=i32, device=dev)
+    no = torch.tensor([M], dtype=i32, device=dev)
+    con = torch.zeros(M, dtype=i32, device=dev)
+    p2n = torch.zeros(N, dtype=i32, device=dev)
+    p2nd = torch.zeros(N, dtype=torch.float32, device=dev)
+    nm = torch.zeros(M, dtype=i32, device=dev)
+    kidx = torch.zeros((M, point_limit), dtype=i32, device=dev)
+    kmask = torch.zeros((M, point_limit), dtype=i32, device=dev)
+    L.check(L.lib().roitr_point_to_node_partition(1, N, M, L.ptr(points.contiguous()), L.ptr(po), L.ptr(nodes.contiguous()), L.ptr(no),
+                                                  L.ptr(con), int(point_limit), L.ptr(p2n), L.ptr(p2nd), L.ptr(nm), L.ptr(kidx),
+                                                  L.ptr(kmask), L.stream_ptr()), "point_to_node_partition")
+    return p2n.long(), nm.bool(), kidx.long(), kmask.bool()
+
+
+def coarse_matching(ref_feats, src_feats, ref_masks, src_masks, num_correspondences=256, dual_normalization=True):
+    """model/modules.py:141-178 CoarseMatching.forward -> (ref_corr_indices, src_corr_indices, corr_scores)"""
+    dev = ref_feats.device
+    nr, ns = ref_feats.shape[0], src_feats.shape[0]
+    lib = L.lib()
+    lib.roitr_coarse_scratch_floats.restype = ctypes.c_size_t
+    feats = torch.cat([src_feats, ref_feats], 0).contiguous().float()   # cloud order: [src, tgt(=ref)]
+    masks = torch.cat([src_masks, ref_masks], 0).to(torch.int32).contiguous()
+    off = torch.tensor([ns, ns + nr], dtype=torch.int32, device=dev)
+    stride = lib.roitr_coarse_scratch_floats(nr, ns)
+    scratch = torch.empty(stride, dtype=torch.float32, device=dev)
+    P = int(num_correspondences)
+    tc = torch.zeros(P, dtype=torch.int32, device=dev)
+    sc = torch.zeros(P, dtype=torch.int32, device=dev)
+    cs = torch.zeros(P, dtype=torch.float32, device=dev)
+    nc = torch.zeros(1, dtype=torch.int32, device=dev)
+    a = _Coarse(1, feats.shape[1], P, int(dual_normalization), nr, ns, L.ptr(feats), L.ptr(off), L.ptr(masks), L.ptr(scratch),
+                stride, L.ptr(tc), L.ptr(sc), L.ptr(cs), L.ptr(nc))
+    L.check(lib.roitr_coarse_matching(ctypes.byref(a), L.stream_ptr()), "coarse_matching")
+    n = int(nc.item())
+    return tc[:n].long(), sc[:n].long(), cs[:n]
+
+
+def optimal_transport(scores, row_masks, col_masks, alpha, num_iter=100):
+    """model/modules.py:28-68 LearnableLogOptimalTransport.forward: (B,64,64) -> (B,65,65)"""
+    dev = scores.device
+    B, M, N = scores.shape
+    out = torch.zeros((B, M + 1, N + 1), dtype=torch.float32, device=dev)
+    nc = torch.tensor([B], dtype=torch.int32, device=dev)
+    al = torch.as_tensor(alpha, dtype=torch.float32, device=dev).reshape(1).contiguous()
+    sc = scores.contiguous().float()
+    rm = row_masks.to(torch.int32).contiguous()   # named: temporaries must outlive the launch
+    cm = col_masks.to(torch.int32).contiguous()
+    a = _OT(1, B, M, int(num_iter), L.ptr(nc), L.ptr(sc), L.ptr(rm), L.ptr(cm), L.ptr(al), L.ptr(out))
+    L.check(L.lib().roitr_optimal_transport(ctypes.byref(a), L.stream_ptr()), "optimal_transport")
+    return out
+
+
+def fine_matching(ref_knn_points, src_knn_points, ref_knn_masks, src_knn_masks, matching_scores, k, mutual=True,
+                  confidence_threshold=0.05, global_scores=None):
+    """model/modules.py:288-324 FineMatching.forward (use_dustbin=False).  matching_scores: the (B,65,65) OT output
+    (its dustbin row/column are dropped inside, RIGA_v2.py:159-160) -> (ref_corr_points, src_corr_points, corr_scores)"""
+    dev = matching_scores.device
+    B, Lp1, _ = matching_scores.shape
+    Lm = Lp1 - 1
+    i32 = torch.int32
+    cap = B * Lm * Lm
+    nc = torch.tensor([B], dtype=i32, device=dev)
+    flags = torch.zeros(B * Lm * Lm, dtype=torch.uint8, device=dev)
+    counts = torch.zeros(B, dtype=i32, device=dev)
+    offs = torch.zeros(B, dtype=i32, device=dev)
+    n_out = torch.zeros(1, dtype=i32, device=dev)
+    o_r = torch.zeros((cap, 3), dtype=torch.float32, device=dev)
+    o_c = torch.zeros((cap, 3), dtype=torch.float32, device=dev)
+    o_s = torch.zeros(cap, dtype=torch.float32, device=dev)
+    rm, cm = ref_knn_masks.to(i32).contiguous(), src_knn_masks.to(i32).contiguous()
+    rp, cp = ref_knn_points.contiguous().float(), src_knn_points.contiguous().float()
+    ms = matching_scores.contiguous().float()
+    gs = global_scores.contiguous().float() if global_scores is not None else None
+    a = _Fine(1, B, Lm, int(k), int(mutual), float(confidence_threshold), L.ptr(nc), L.ptr(ms), L.ptr(rm), L.ptr(cm), L.ptr(rp),
+              L.ptr(cp), L.ptr(gs), L.ptr(flags), L.ptr(counts), L.ptr(offs), L.ptr(n_out), L.ptr(o_r), L.ptr(o_c), L.ptr(o_s), L.ptr(None))
+    L.check(L.lib().roitr_fine_matching(ctypes.byref(a), L.stream_ptr()), "fine_matching")
+    n = int(n_out.item())
+    return o_r[:n], o_c[:n], o_s[:n]

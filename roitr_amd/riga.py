@@ -239,6 +239,29 @@ class RIGA_v2(nn.Module):
         self._injects[name] = tensor
         L.lib().roitr_engine_set_inject(self._engine, name.encode(), L.ptr(tensor))
 
+    PROF_CLASSES = {"fps_kernel": 0, "knn_query_kernel": 1, "grid_build_kernel": 2, "knn_replay_kernel": 3, "phase.geometry": 4,
+                    "phase.encoder": 5, "phase.global_transformer": 6, "phase.decoder": 7, "phase.matching": 8,
+                    "phase.forward": 9, "ot_kernel": 10, "local_attn_kernel": 11}
+
+    @staticmethod
+    def profile_reset(enable=True):
+        """HIP-event instrumentation of the dominant kernels (csrc/prof.cpp); off by default."""
+        lib = L.lib()
+        lib.roitr_prof_enable(1 if enable else 0)
+        lib.roitr_prof_reset()
+
+    @classmethod
+    def profile_read(cls, kernels_only=True):
+        lib = L.lib()
+        out = {}
+        for name, cid in cls.PROF_CLASSES.items():
+            ms, n, by = ctypes.c_double(0), ctypes.c_long(0), ctypes.c_double(0)
+            lib.roitr_prof_read(cid, ctypes.byref(ms), ctypes.byref(n), ctypes.byref(by))
+            if n.value and (not kernels_only or not name.startswith("phase.")):
+                out[name] = {"ms": ms.value, "launches": n.value, "bytes": by.value}
+        lib.roitr_prof_enable(0)
+        return out
+
     def __del__(self):
         try:
             if self._engine is not None:

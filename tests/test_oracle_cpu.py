@@ -1,0 +1,124 @@
+"""CPU: the oracle (oracle/pointops_ref.c + oracle/roitr_ref.py) against tensors captured from the reference.
+
+These tests pin the oracle.  The native FPS/kNN goldens were produced by the reference's own Python glue
+driving oracle/pointops_ref.c (the CUDA originals cannot run here), so for those the test checks glue +
+determinism; everything downstream (PPF, attention, global transformer, matching) is pinned by the real
+reference Python.
+"""
+import numpy as np
+import pytest
+
+from oracle import pointops_cpu as O
+from oracle import roitr_ref as R
+
+ATOL = 2e-5
+
+
+def inputs(g):
+    return {k[3:]: g[k] for k in g.files if k.startswith("in.")}
+
+
+@pytest.fixture(scope="module")
+def oracle_run(golden_pair):
+    taps = {}
+    out = R.forward(R.closed_form_state(), inputs(golden_pair), taps=taps, threads=4)
+    return golden_pair, out, taps
+
+
+def test_fps_and_knn_calls_reproduce(golden_pair):
+    g = golden_pair
+    p = g["in.raw_src_pcd"]
+    n = p.shape[0]
+    idx = O.furthestsampling(p, np.array([n], np.int32), np.array([n // 4], np.int32))
+    assert np.array_equal(idx, g["fps.0"])
+    o = np.array([n], np.int32)
+    kidx, kd = O.knnquery(9, p, p, o, o)
+    assert np.array_equal(kidx, g["knn.0.idx"])
+    # torch-CPU sqrt (Sleef) is not always correctly rounded: 1-ulp slack on the euclidean distances only
+    np.testing.assert_allclose(kd, g["knn.0.dist"], rtol=2e-7, atol=0)
+    assert O.opt_n_threads(5000) == 1024 and O.opt_n_threads(312) == 256 and O.opt_n_threads(78) == 64
+
+
+def test_fps_tie_rule_is_the_block_tournament():
+    """Equal maxima: the reference's shared-memory tree keeps the lower SLOT, so the winner is decided by the
+    bit-reversed thread id, not by the lowest index (sampling_cuda_kernel.cu:5-10,64-123)."""
+    pts = np.zeros((8, 3), np.float32)
+    pts[1:, 0] = 1.0  # seven points tie at distance 1 from point 0
+    idx = O.furthestsampling(pts, np.array([8], np.int32), np.array([2], np.int32))
+    assert idx.tolist() == [0, 4]  # bitrev3(4) = 1 is the smallest among tids 1..7
+
+
+def test_knn_fill_when_cloud_smaller_than_k():
+    pts = np.random.default_rng(0).random((5, 3)).astype(np.float32)
+    o = np.array([5], np.int32)
+    idx, d2 = O.knnquery_raw(8, pts, pts, o, o)
+    assert (idx[:, 5:] == 0).all() and (d2[:, 5:] == np.float32(1e10)).all()
+
+
+def test_ppf_stage(golden_stages):
+    s = golden_stages
+    out = R.calc_ppf(s["ppf.pts"], s["ppf.nrm"], s["ppf.patches"], s["ppf.pnrm"])
+    np.testing.assert_allclose(out, s["ppf.out"], rtol=0, atol=2e-6)
+
+
+@pytest.mark.parametrize("stage", ["enc1.0", "enc1.1", "enc2.0", "enc2.2", "enc3.2", "enc4.2", "dec4.1", "dec3.1", "dec2.1", "dec1.1"])
+def test_backbone_stages(oracle_run, stage):
+    g, out, taps = oracle_run
+    for j, tag in enumerate(("src", "tgt")):
+        ref = g[f"feat.{stage}.{j}"]
+        err = np.abs(taps[f"{tag}.{stage}"] - ref).max()
+        assert err < ATOL, f"{tag}.{stage}: {err:.2e}"
+
+
+def test_global_transformer_and_descriptors(oracle_run):
+    g, out, taps = oracle_run
+    for i in range(6):
+        for j in range(2):
+            err = np.abs(taps[f"geo.layer{i}"][j] - g[f"feat.geo.layer{i}.{j}"][0]).max()
+            assert err < ATOL, f"geo.layer{i}.{j}: {err:.2e}"
+    for k in ("src_node_feats", "tgt_node_feats", "src_point_feats", "tgt_point_feats"):
+        assert np.abs(out[k] - g["out." + k]).max() < ATOL, k
+    for k in ("src_nodes", "tgt_nodes"):
+        assert np.array_equal(out[k], g["out." + k])
+
+
+def test_geo_embedding_stage(golden_stages):
+    s = golden_stages
+    d, a = R.geo_embedding_indices(s["geo.points"][0])
+    np.testing.assert_allclose(d, s["geo.d_idx"][0], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(a, s["geo.a_idx"][0], rtol=0, atol=2e-6)
+    W = R.Weights(R.closed_form_state())
+    e = R.geo_embedding(W, "backbone.global_transformer.embedding", s["geo.points"][0], 256)
+    np.testing.assert_allclose(e, s["geo.emb"][0], rtol=0, atol=ATOL)
+
+
+def test_partition_and_matching(oracle_run, golden_stages):
+    g, out, taps = oracle_run
+    for side in ("src", "tgt"):
+        assert np.array_equal(out[f"_{side}_node_knn_indices"], g[f"part.{side}.knn_indices"])
+        assert np.array_equal(out[f"_{side}_node_knn_masks"], g[f"part.{side}.knn_masks"])
+    assert sorted(zip(out["tgt_node_corr_indices"].tolist(), out["src_node_corr_indices"].tolist())) == \
+        sorted(zip(g["out.tgt_node_corr_indices"].tolist(), g["out.src_node_corr_indices"].tolist()))
+    s = golden_stages
+    for tag in ("p0", "p1"):
+        p2n, m, knn, km = R.point_to_node_partition(s[f"part.{tag}.points"], s[f"part.{tag}.nodes"], 64)
+        assert np.array_equal(p2n, s[f"part.{tag}.point_to_node"])
+        assert np.array_equal(knn, s[f"part.{tag}.knn_indices"]) and np.array_equal(km, s[f"part.{tag}.knn_masks"])
+    ri, si, sc = R.coarse_matching(s["coarse.ref_f"], s["coarse.src_f"], s["coarse.ref_m"], s["coarse.src_m"], 256)
+    assert np.array_equal(ri, s["coarse.ref_idx"]) and np.array_equal(si, s["coarse.src_idx"])
+    np.testing.assert_allclose(sc, s["coarse.scores"], rtol=1e-4)
+
+
+def test_ot_and_fine_stage(golden_stages):
+    s = golden_stages
+    ot = R.optimal_transport(s["ot.scores"], s["ot.row_masks"], s["ot.col_masks"], float(s["ot.alpha"]))
+    rm = np.concatenate([s["ot.row_masks"], np.ones((8, 1), bool)], 1)
+    cm = np.concatenate([s["ot.col_masks"], np.ones((8, 1), bool)], 1)
+    valid = rm[:, :, None] & cm[:, None, :]
+    assert np.abs(ot - s["ot.out"])[valid].max() < 1e-4
+    for k, mutual in ((3, True), (2, True), (3, False)):
+        tag = f"fine.k{k}.m{int(mutual)}"
+        r, c, sc = R.fine_matching(s["fine.ref_pts"], s["fine.src_pts"], s["ot.row_masks"], s["ot.col_masks"],
+                                   s["ot.out"][:, :-1, :-1], k, mutual)
+        assert np.array_equal(r, s[tag + ".ref"]) and np.array_equal(c, s[tag + ".src"])
+        np.testing.assert_allclose(sc, s[tag + ".scores"], rtol=1e-5)

@@ -99,7 +99,8 @@ def test_knn_golden(golden_pair):
     o = torch.tensor([p.shape[0]], dtype=torch.int32).cuda()
     idx, dist = P.knnquery(9, p, p, o, o)
     assert np.array_equal(idx.cpu().numpy(), g["knn.0.idx"])
-    np.testing.assert_array_equal(dist.cpu().numpy(), g["knn.0.dist"])
+    # torch-CPU sqrt (Sleef) is not always correctly rounded: 1-ulp slack on the euclidean distances only
+    np.testing.assert_allclose(dist.cpu().numpy(), g["knn.0.dist"], rtol=2e-7, atol=0)
 
 
 def test_knn_ppf_fused_matches_golden(golden_pair):
