@@ -31,6 +31,9 @@ typedef struct RoitrGemm {
     const float* bias; float alpha; int relu;
     float* C; int ldc;
     int batch; long sA, sW, sC, sBias, sAidx, sWidx;
+    /* optional ragged batching: batch b multiplies row segment (seg_a0 + b) of A with row segment (seg_w0 + b) of W,
+     * segments given by the cumulative int32 `seg_off`; M / N then only bound the grid. */
+    const int* seg_off; int seg_a0, seg_w0;
 } RoitrGemm;
 int roitr_gemm(const RoitrGemm* g, roitr_stream_t stream);
 
@@ -113,12 +116,14 @@ int roitr_point_to_node_partition(int b, int n_points, int n_nodes, const float*
 
 /* model/modules.py:141-178 CoarseMatching (ref = tgt, src = src as called at RIGA_v2.py:121).
  * feats (n_nodes, C) L2-normalised; outputs (pairs, num_corr): node indices local to their cloud (-1 beyond
- * n_corr[pair]), scores.  scratch: pairs * scratch_stride floats, stride >= roitr_coarse_scratch_floats(). */
+ * n_corr[pair]), scores.  scratch: pairs * scratch_stride floats, stride >= roitr_coarse_scratch_floats().
+ * xy: optional precomputed feature dot products, pair b at xy + b*xy_stride, row-major (n_tgt, ld = xy_ld). */
 typedef struct RoitrCoarse {
     int pairs, C, num_corr, dual_norm, max_ref, max_src;
     const float* feats; const int* node_offset; const int* node_masks;
     float* scratch; long scratch_stride;
     int* tgt_corr; int* src_corr; float* corr_scores; int* n_corr;
+    const float* xy; long xy_stride; int xy_ld;
 } RoitrCoarse;
 size_t roitr_coarse_scratch_floats(int n_ref, int n_src);
 int roitr_coarse_matching(const RoitrCoarse* a, roitr_stream_t stream);

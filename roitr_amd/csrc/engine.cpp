@@ -108,6 +108,8 @@ struct Engine {
     char* pinned[RING] = {nullptr, nullptr, nullptr, nullptr}; size_t pinned_cap[RING] = {0, 0, 0, 0};
     hipEvent_t pinned_ev[RING] = {nullptr, nullptr, nullptr, nullptr};
     int ring_pos = 0;
+    hipStream_t side = nullptr;      // FPS chain runs here, beside the level-1 encoder work
+    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     std::string err;
 };
 
@@ -326,6 +328,8 @@ extern "C" void roitr_engine_destroy(void* h)
     if (!E) return;
     if (E->warena.base) (void)hipFree(E->warena.base);
     if (E->arena.base) (void)hipFree(E->arena.base);
+    if (E->side) (void)hipStreamDestroy(E->side);
+    for (int i = 0; i < 5; ++i) if (E->ev[i]) (void)hipEventDestroy(E->ev[i]);
     for (int i = 0; i < Engine::RING; ++i) {
         if (E->pinned[i]) (void)hipHostFree(E->pinned[i]);
         if (E->pinned_ev[i]) (void)hipEventDestroy(E->pinned_ev[i]);
@@ -497,7 +501,7 @@ extern "C" int roitr_engine_forward(void* h, const RoitrForwardIO* io, hipStream
         size_t need = (size_t)T1 * 4 * (64 * f * 14 + 256 * f * 2 + 600) + (size_t)etot * C4 * 4 * 11 + (size_t)T4 * C4 * 4 * 40 +
                       (size_t)B * P_ * (LIM * LIM * 3 + (LIM + 1) * (LIM + 1) + LIM * 16) * 4 + ((size_t)64 << 20);
         for (int l = 0; l < 4; ++l) need += roitr_knn_workspace_bytes(NC, V.T[l], T1) + 1024;
-        need += (size_t)B * roitr_coarse_scratch_floats(V.nmax[3], V.nmax[3]) * 4;
+        need += (size_t)B * (roitr_coarse_scratch_floats(V.nmax[3], V.nmax[3]) + (size_t)V.nmax[3] * V.nmax[3]) * 4 + 1024;
         if (need > E.arena.cap) {
             ROITR_HIP(hipStreamSynchronize(st));
             if (E.arena.base) ROITR_HIP(hipFree(E.arena.base));
@@ -540,8 +544,10 @@ extern "C" int roitr_engine_forward(void* h, const RoitrForwardIO* io, hipStream
     D.eoff = (long*)(ddesc + ((desc_ints * 4 + 15) & ~(size_t)15));
 
     roitr_prof_begin(ROITR_PROF_PH_FORWARD, 0.0, st);
-    roitr_prof_begin(ROITR_PROF_PH_GEOM, 0.0, st);
-    // ---------------- hierarchy geometry: FPS, kNN groups, PPF  (model/model.py:56-80, 30-42)
+    // ---------------- hierarchy: FPS chain on a side stream, per level kNN groups + PPF + encoder on the main one
+    // (model/model.py:56-80, 30-42, 195-205).  The FPS chain depends on nothing but the input coordinates and is a
+    // long serial kernel on 2B workgroups, so it runs beside the level-1 geometry and encoder instead of in front
+    // of them; level l's work waits for "level l sampled" only.
     const float* p[4]; const float* nrm[4];
     p[0] = io->points_geom; nrm[0] = io->normals;
     int* down[4] = {nullptr, nullptr, nullptr, nullptr};  // FPS indices into level l-1 (global rows)
@@ -549,59 +555,65 @@ extern "C" int roitr_engine_forward(void* h, const RoitrForwardIO* io, hipStream
     int* g_td[4]; float* ppf_td[4];                        // TransitionDown groups (level l nodes over level l-1 points)
     void* knn_ws[4];
     bool grid[4];
-    float* fps_tmp = A.get<float>(T1);
-    for (int l = 0; l < 4; ++l) {
-        const int K = E.nsample[l];
-        if (l > 0) {
+    float* xe[4];
+    if (!E.side) {
+        ROITR_HIP(hipStreamCreateWithFlags(&E.side, hipStreamNonBlocking));
+        for (int i = 0; i < 5; ++i) ROITR_HIP(hipEventCreateWithFlags(&E.ev[i], hipEventDisableTiming));
+    }
+    {
+        float* fps_tmp = A.get<float>(T1);
+        for (int l = 1; l < 4; ++l) {
             down[l] = A.get<int>(V.T[l]);
-            float* pl = A.get<float>((size_t)V.T[l] * 3);
-            float* nl = A.get<float>((size_t)V.T[l] * 3);
-            if (A.fail) break;
-            // tmp = 1e10 (functions/pointops.py:22)
-            ROITR_HIP(hipMemsetD32Async((hipDeviceptr_t)fps_tmp, 0x501502F9 /* bits of 1e10f */, V.T[l - 1], st));
-            roitr_prof_next_bytes(ROITR_PROF_FPS, 12.0 * V.T[l - 1] + 4.0 * V.T[l] + 8.0 * V.T[l - 1]);
-            CHK(roitr_furthestsampling(NC, V.nmax[l - 1], p[l - 1], D.off[l - 1], D.off[l], fps_tmp, down[l], st));
-            CHK(tap(E, st, "fps." + std::to_string(l + 1), down[l], sizeof(int) * V.T[l]));
-            CHK(roitr_gather_rows(V.T[l], 3, p[l - 1], down[l], 0, pl, st));
-            CHK(roitr_gather_rows(V.T[l], 3, nrm[l - 1], down[l], 0, nl, st));
-            p[l] = pl; nrm[l] = nl;
+            p[l] = A.get<float>((size_t)V.T[l] * 3);
+            nrm[l] = A.get<float>((size_t)V.T[l] * 3);
         }
-        // grid over this level's points (refs for: own self-kNN, next level's TD query, finer level's 3-NN)
-        const int mcap = l == 0 ? T1 : V.T[l - 1];
-        knn_ws[l] = A.get<char>(roitr_knn_workspace_bytes(NC, V.T[l], mcap));
-        grid[l] = V.T[l] > GRID_MIN_POINTS * NC;
-        if (A.fail) break;
-        if (grid[l]) CHK(roitr_knn_build_grid(NC, V.T[l], mcap, p[l], D.off[l], knn_ws[l], st));
-        g_self[l] = A.get<int>((size_t)V.T[l] * K);
-        ppf_self[l] = A.get<float>((size_t)V.T[l] * K * 4);
-        if (A.fail) break;
-        CHK(roitr_knnquery_ex(NC, V.T[l], V.T[l], K + 1, p[l], p[l], D.off[l], D.off[l], nullptr, nullptr, g_self[l], ppf_self[l], nrm[l],
-                              nrm[l], grid[l] ? 1 : 0, mcap, knn_ws[l], st));
-        CHK(tap(E, st, "group.self." + std::to_string(l + 1), g_self[l], sizeof(int) * (size_t)V.T[l] * K));
-        CHK(tap(E, st, "ppf.self." + std::to_string(l + 1), ppf_self[l], sizeof(float) * (size_t)V.T[l] * K * 4));
-        if (l > 0) {
-            g_td[l] = A.get<int>((size_t)V.T[l] * K);
-            ppf_td[l] = A.get<float>((size_t)V.T[l] * K * 4);
-            if (A.fail) break;
-            const int mcap_prev = l - 1 == 0 ? T1 : V.T[l - 2];
-            CHK(roitr_knnquery_ex(NC, V.T[l - 1], V.T[l], K + 1, p[l - 1], p[l], D.off[l - 1], D.off[l], nullptr, nullptr, g_td[l],
-                                  ppf_td[l], nrm[l - 1], nrm[l], grid[l - 1] ? 1 : 0, mcap_prev, knn_ws[l - 1], st));
-            CHK(tap(E, st, "group.td." + std::to_string(l + 1), g_td[l], sizeof(int) * (size_t)V.T[l] * K));
-            CHK(tap(E, st, "ppf.td." + std::to_string(l + 1), ppf_td[l], sizeof(float) * (size_t)V.T[l] * K * 4));
-        } else {
-            g_td[0] = g_self[0]; ppf_td[0] = ppf_self[0];  // stride 1: the same kNN (model/model.py:75 vs :31)
+        if (A.fail) { roitr_set_error("arena exhausted (sampling)", __FILE__, __LINE__); return ROITR_ERR_ARG; }
+        ROITR_HIP(hipEventRecord(E.ev[0], st));  // inputs + descriptors are in place
+        ROITR_HIP(hipStreamWaitEvent(E.side, E.ev[0], 0));
+        for (int l = 1; l < 4; ++l) {
+            // tmp = 1e10 (functions/pointops.py:22)
+            ROITR_HIP(hipMemsetD32Async((hipDeviceptr_t)fps_tmp, 0x501502F9 /* bits of 1e10f */, V.T[l - 1], E.side));
+            roitr_prof_next_bytes(ROITR_PROF_FPS, 12.0 * V.T[l - 1] + 4.0 * V.T[l] + 8.0 * V.T[l - 1]);
+            CHK(roitr_furthestsampling(NC, V.nmax[l - 1], p[l - 1], D.off[l - 1], D.off[l], fps_tmp, down[l], E.side));
+            CHK(roitr_gather_rows(V.T[l], 3, p[l - 1], down[l], 0, (float*)p[l], E.side));
+            CHK(roitr_gather_rows(V.T[l], 3, nrm[l - 1], down[l], 0, (float*)nrm[l], E.side));
+            ROITR_HIP(hipEventRecord(E.ev[l], E.side));
         }
     }
-    if (A.fail) { roitr_set_error("arena exhausted (geometry)", __FILE__, __LINE__); return ROITR_ERR_ARG; }
-
-    roitr_prof_end(ROITR_PROF_PH_GEOM, st);
     roitr_prof_begin(ROITR_PROF_PH_ENC, 0.0, st);
-    // ---------------- encoder
-    float* xe[4];
     {
         const float* xin = io->feats;
         for (int l = 0; l < 4; ++l) {
-            const int pl = E.planes[l], K = E.nsample[l];
+            const int K = E.nsample[l], pl = E.planes[l];
+            if (l > 0) {
+                ROITR_HIP(hipStreamWaitEvent(st, E.ev[l], 0));
+                CHK(tap(E, st, "fps." + std::to_string(l + 1), down[l], sizeof(int) * V.T[l]));
+            }
+            // grid over this level's points (refs for: own self-kNN, next level's TD query, finer level's 3-NN)
+            const int mcap = l == 0 ? T1 : V.T[l - 1];
+            knn_ws[l] = A.get<char>(roitr_knn_workspace_bytes(NC, V.T[l], mcap));
+            grid[l] = V.T[l] > GRID_MIN_POINTS * NC;
+            g_self[l] = A.get<int>((size_t)V.T[l] * K);
+            ppf_self[l] = A.get<float>((size_t)V.T[l] * K * 4);
+            if (A.fail) break;
+            if (grid[l]) CHK(roitr_knn_build_grid(NC, V.T[l], mcap, p[l], D.off[l], knn_ws[l], st));
+            CHK(roitr_knnquery_ex(NC, V.T[l], V.T[l], K + 1, p[l], p[l], D.off[l], D.off[l], nullptr, nullptr, g_self[l], ppf_self[l], nrm[l],
+                                  nrm[l], grid[l] ? 1 : 0, mcap, knn_ws[l], st));
+            CHK(tap(E, st, "group.self." + std::to_string(l + 1), g_self[l], sizeof(int) * (size_t)V.T[l] * K));
+            CHK(tap(E, st, "ppf.self." + std::to_string(l + 1), ppf_self[l], sizeof(float) * (size_t)V.T[l] * K * 4));
+            if (l > 0) {
+                g_td[l] = A.get<int>((size_t)V.T[l] * K);
+                ppf_td[l] = A.get<float>((size_t)V.T[l] * K * 4);
+                if (A.fail) break;
+                const int mcap_prev = l - 1 == 0 ? T1 : V.T[l - 2];
+                CHK(roitr_knnquery_ex(NC, V.T[l - 1], V.T[l], K + 1, p[l - 1], p[l], D.off[l - 1], D.off[l], nullptr, nullptr, g_td[l],
+                                      ppf_td[l], nrm[l - 1], nrm[l], grid[l - 1] ? 1 : 0, mcap_prev, knn_ws[l - 1], st));
+                CHK(tap(E, st, "group.td." + std::to_string(l + 1), g_td[l], sizeof(int) * (size_t)V.T[l] * K));
+                CHK(tap(E, st, "ppf.td." + std::to_string(l + 1), ppf_td[l], sizeof(float) * (size_t)V.T[l] * K * 4));
+            } else {
+                g_td[0] = g_self[0]; ppf_td[0] = ppf_self[0];  // stride 1: the same kNN (model/model.py:75 vs :31)
+            }
+            // ---- encoder level l
             float* a = A.get<float>((size_t)V.T[l] * pl);
             float* b = A.get<float>((size_t)V.T[l] * pl);
             if (A.fail) break;
@@ -814,15 +826,24 @@ extern "C" int roitr_engine_forward(void* h, const RoitrForwardIO* io, hipStream
     float* o_sc = io->out_scores ? io->out_scores : A.get<float>(cap);
     const long cstride = (long)roitr_coarse_scratch_floats(V.nmax[3], V.nmax[3]);
     float* cscratch = A.get<float>((size_t)B * cstride);
+    const long xystride = (long)V.nmax[3] * V.nmax[3];
+    float* cxy = A.get<float>((size_t)B * xystride);
     if (A.fail) { roitr_set_error("arena exhausted (matching)", __FILE__, __LINE__); return ROITR_ERR_ARG; }
 
     CHK(roitr_point_to_node_partition(NC, T1, T4, pts_out, D.off[0], node_xyz, D.off[3], D.cloud_of_node, LIM, p2n, p2nd, node_masks, kidx,
                                       kmask, st));
+    {   // all tgt_b x src_b feature dot products in one ragged-batched GEMM (rows: tgt cloud B+b, cols: src cloud b)
+        RoitrGemm g; memset(&g, 0, sizeof(g));
+        g.M = V.nmax[3]; g.N = V.nmax[3]; g.K = C4; g.A = node_feats; g.lda = C4; g.W = node_feats; g.ldw = C4; g.alpha = 1.f;
+        g.C = cxy; g.ldc = V.nmax[3]; g.batch = B; g.sC = xystride; g.seg_off = D.off[3]; g.seg_a0 = B; g.seg_w0 = 0;
+        CHK(roitr_gemm(&g, st));
+    }
     {
         RoitrCoarse c; memset(&c, 0, sizeof(c));
         c.pairs = B; c.C = C4; c.num_corr = P_; c.dual_norm = 1; c.max_ref = V.nmax[3]; c.max_src = V.nmax[3];
         c.feats = node_feats; c.node_offset = D.off[3]; c.node_masks = node_masks; c.scratch = cscratch; c.scratch_stride = cstride;
         c.tgt_corr = tgt_corr; c.src_corr = src_corr; c.corr_scores = cscore; c.n_corr = n_corr;
+        c.xy = cxy; c.xy_stride = xystride; c.xy_ld = V.nmax[3];
         CHK(roitr_coarse_matching(&c, st));
     }
     {

@@ -70,6 +70,14 @@ __global__ __launch_bounds__(256) void gemm_kernel(RoitrGemm g)
     const int wm = wave >> 1, wn = wave & 1;
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
     const int r = tid >> 2, kq = (tid & 3) * 8;
+    if (g.seg_off) {  // ragged batch: this batch's row segments of A and W
+        const int ia = g.seg_a0 + bz, iw = g.seg_w0 + bz;
+        const int a0 = ia == 0 ? 0 : g.seg_off[ia - 1], w0 = iw == 0 ? 0 : g.seg_off[iw - 1];
+        g.M = g.seg_off[ia] - a0; g.N = g.seg_off[iw] - w0;
+        A += (size_t)a0 * g.lda; W += (size_t)w0 * g.ldw;
+        if (A2) A2 += (size_t)a0 * g.lda;
+        if (m0 >= g.M || n0 >= g.N) return;  // block-uniform
+    }
 
     const float* arow = nullptr; const float* arow2 = nullptr; const float* wrow = nullptr;
     {

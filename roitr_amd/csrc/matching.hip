@@ -54,20 +54,61 @@ __global__ __launch_bounds__(256) void p2n_assign_kernel(int n_points, const flo
     node_masks[bi] = 1;
 }
 
-// B: one block per node: the `limit` nearest OWNED points, ascending (distance, index); pad = n_c (cloud size)
+// B: one block per node: the `limit` nearest OWNED points, ascending (distance, index); pad = n_c (cloud size).
+// Owned points are compacted into LDS in one pass over the cloud and bitonic-sorted there (a node owns
+// ~N/n = 64 points on average); a node owning more than P2N_CAP points falls back to repeated arg-min.
+constexpr int P2N_CAP = 2048;
 __global__ __launch_bounds__(256) void p2n_topk_kernel(const int* __restrict__ pt_offset, const int* __restrict__ node_offset,
                                                        const int* __restrict__ cloud_of_node, const int* __restrict__ p2n,
                                                        const float* __restrict__ p2n_dist, int limit, int* __restrict__ knn_idx,
                                                        int* __restrict__ knn_mask)
 {
+    __shared__ unsigned long long keys[P2N_CAP];
     __shared__ unsigned long long red[4];
     __shared__ unsigned long long last_s;
+    __shared__ int cnt_s;
     const int node = blockIdx.x;
     const int c = cloud_of_node[node];
     const int ps = c == 0 ? 0 : pt_offset[c - 1], pe = pt_offset[c];
     const int local = node - (c == 0 ? 0 : node_offset[c - 1]);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    unsigned long long last = 0ull;  // keys are > 0 (distance >= 1e-12)
+    if (tid == 0) cnt_s = 0;
+    __syncthreads();
+    for (int j = ps + tid; j < pe; j += 256) {
+        if (p2n[j] == local) {
+            const int pos = atomicAdd(&cnt_s, 1);
+            if (pos < P2N_CAP) keys[pos] = ((unsigned long long)__float_as_uint(p2n_dist[j]) << 32) | (unsigned)(j - ps);
+        }
+    }
+    __syncthreads();
+    const int count = cnt_s;
+    if (count <= P2N_CAP) {
+        int cap = 64;
+        while (cap < count) cap <<= 1;
+        for (int e = count + tid; e < cap; e += 256) keys[e] = ~0ull;
+        __syncthreads();
+        for (int k = 2; k <= cap; k <<= 1) {
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                for (int e = tid; e < cap; e += 256) {
+                    const int q = e ^ j;
+                    if (q > e) {
+                        const unsigned long long x = keys[e], y = keys[q];
+                        const bool up = (e & k) == 0;
+                        if ((x > y) == up) { keys[e] = y; keys[q] = x; }
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        for (int t = tid; t < limit; t += 256) {
+            const bool ok = t < count;
+            knn_idx[(size_t)node * limit + t] = ok ? (int)(unsigned)keys[t] : (pe - ps);
+            knn_mask[(size_t)node * limit + t] = ok ? 1 : 0;
+        }
+        return;
+    }
+    // ---- rare: more owned points than the LDS buffer holds
+    unsigned long long last = 0ull;
     bool first = true;
     for (int t = 0; t < limit; ++t) {
         unsigned long long best = ~0ull;
@@ -85,16 +126,11 @@ __global__ __launch_bounds__(256) void p2n_topk_kernel(const int* __restrict__ p
             unsigned long long bb = red[0];
             for (int w = 1; w < 4; ++w) bb = red[w] < bb ? red[w] : bb;
             last_s = bb;
-            const bool ok = bb != ~0ull;
-            knn_idx[(size_t)node * limit + t] = ok ? (int)(unsigned)bb : (pe - ps);
-            knn_mask[(size_t)node * limit + t] = ok ? 1 : 0;
+            knn_idx[(size_t)node * limit + t] = (int)(unsigned)bb;
+            knn_mask[(size_t)node * limit + t] = 1;
         }
         __syncthreads();
         last = last_s; first = false;
-        if (last == ~0ull) {  // exhausted: pad the rest
-            for (int u = t + 1 + tid; u < limit; u += 256) { knn_idx[(size_t)node * limit + u] = pe - ps; knn_mask[(size_t)node * limit + u] = 0; }
-            break;
-        }
     }
 }
 
@@ -123,15 +159,19 @@ __global__ __launch_bounds__(1024) void coarse_match_kernel(RoitrCoarse a)
         (i < nr ? rowsum : colsum)[i < nr ? i : i - nr] = s;  // temporarily: norms
     }
     __syncthreads();
+    const float* XY = a.xy ? a.xy + (size_t)pair * a.xy_stride : nullptr;
     for (int e = tid; e < nr * nsr; e += 1024) {
         const int i = e / nsr, j = e % nsr;
         const bool ok = a.node_masks[t0 + i] && a.node_masks[s0 + j];
         float v = -1.f;
         if (ok) {
-            const float* fr = a.feats + (size_t)(t0 + i) * C;
-            const float* fs = a.feats + (size_t)(s0 + j) * C;
             float xy = 0.f;
-            for (int k = 0; k < C; ++k) xy = __fmaf_rn(fr[k], fs[k], xy);
+            if (XY) xy = XY[(size_t)i * a.xy_ld + j];  // k-ordered fma chain from the MFMA GEMM: same value as below
+            else {
+                const float* fr = a.feats + (size_t)(t0 + i) * C;
+                const float* fs = a.feats + (size_t)(s0 + j) * C;
+                for (int k = 0; k < C; ++k) xy = __fmaf_rn(fr[k], fs[k], xy);
+            }
             const float d = fmaxf((-2.0f * xy + rowsum[i]) + colsum[j], 1e-12f);
             v = expf(-d);
         }

@@ -31,14 +31,31 @@ struct Slot {
     float x, y, z, pad;
 };
 
+// Wave-wide max of a signed 64-bit key with DPP row shifts / row broadcasts (VALU-rate cross-lane moves;
+// a __shfl_xor butterfly lowers to ds_bpermute, one LDS round trip per step, ~6x the latency on this
+// serial critical path).  Lanes without a DPP source keep their own value (old = src, bound_ctrl = 0), which is
+// harmless for an idempotent max.  After the row_shr steps lane 15 of every 16-lane row holds the row max,
+// row_bcast:15 / :31 fold the rows, lane 63 ends with the wave max.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ long long dpp_max_step(long long v)
+{
+    const int lo = (int)v, hi = (int)(v >> 32);
+    const int lo2 = __builtin_amdgcn_update_dpp(lo, lo, CTRL, ROW_MASK, 0xf, false);
+    const int hi2 = __builtin_amdgcn_update_dpp(hi, hi, CTRL, ROW_MASK, 0xf, false);
+    const long long w = (long long)(((unsigned long long)(unsigned)hi2 << 32) | (unsigned)lo2);
+    return w > v ? w : v;
+}
+
 __device__ __forceinline__ long long wave_max_i64(long long v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const long long w = __shfl_xor(v, o, 64);
-        v = w > v ? w : v;
-    }
-    return v;
+    v = dpp_max_step<0x111, 0xf>(v);  // row_shr:1
+    v = dpp_max_step<0x112, 0xf>(v);  // row_shr:2
+    v = dpp_max_step<0x114, 0xf>(v);  // row_shr:4
+    v = dpp_max_step<0x118, 0xf>(v);  // row_shr:8
+    v = dpp_max_step<0x142, 0xa>(v);  // row_bcast:15 -> rows 1,3
+    v = dpp_max_step<0x143, 0xc>(v);  // row_bcast:31 -> rows 2,3
+    const int lo = __builtin_amdgcn_readlane((int)v, 63), hi = __builtin_amdgcn_readlane((int)(v >> 32), 63);
+    return (long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
 }
 
 // Key = (float bits of d2) << 32 | tie-break.  d2 >= 0 for real points, so the bits order like

@@ -44,7 +44,7 @@ class _Coarse(ctypes.Structure):
     _fields_ = [("pairs", ctypes.c_int), ("C", ctypes.c_int), ("num_corr", ctypes.c_int), ("dual_norm", ctypes.c_int),
                 ("max_ref", ctypes.c_int), ("max_src", ctypes.c_int), ("feats", _P), ("node_offset", _P), ("node_masks", _P),
                 ("scratch", _P), ("scratch_stride", ctypes.c_long), ("tgt_corr", _P), ("src_corr", _P), ("corr_scores", _P),
-                ("n_corr", _P)]
+                ("n_corr", _P), ("xy", _P), ("xy_stride", ctypes.c_long), ("xy_ld", ctypes.c_int)]
 
 
 class _OT(ctypes.Structure):
@@ -95,7 +95,7 @@ def coarse_matching(ref_feats, src_feats, ref_masks, src_masks, num_corresponden
     cs = torch.zeros(P, dtype=torch.float32, device=dev)
     nc = torch.zeros(1, dtype=torch.int32, device=dev)
     a = _Coarse(1, feats.shape[1], P, int(dual_normalization), nr, ns, L.ptr(feats), L.ptr(off), L.ptr(masks), L.ptr(scratch),
-                stride, L.ptr(tc), L.ptr(sc), L.ptr(cs), L.ptr(nc))
+                stride, L.ptr(tc), L.ptr(sc), L.ptr(cs), L.ptr(nc), L.ptr(None), 0, 0)
     L.check(lib.roitr_coarse_matching(ctypes.byref(a), L.stream_ptr()), "coarse_matching")
     n = int(nc.item())
     return tc[:n].long(), sc[:n].long(), cs[:n]
