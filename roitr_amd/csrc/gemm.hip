@@ -6,28 +6,31 @@
 // model/transformer/*.py, model/model.py, model/RIGA_v2.py:64-68, and the einsum of RIGA_v2.py:150).
 // v_mfma_f32_32x32x2_f32: exact fp32 FMA chains in k order (bit-reproducible, no TF32-style
 // truncation exists on gfx950), 64 FLOP/clk/SIMD.  64x64 block tile, 4 waves (one 32x32 MFMA tile
-// each), BK = 32, operands staged K-major in LDS with a +1 pad so that both the staging writes and
-// the per-lane MFMA operand reads are bank-conflict free; the next K-slab is prefetched into
-// registers while the current one feeds the MFMAs.
+// each), BK = 32.  The 32x32x2 MFMA wants, per lane (m = lane&31, kh = lane>>5), the operand element
+// A[m][2*kk + kh] for kk = 0..15: the LDS image is therefore [kh][row][kk] (even / odd k planes, 16 kk contiguous,
+// row pitch 20 floats) so that a lane fetches its 16 operands of a K-slab with four conflict-free ds_read_b128 and
+// the stager writes its 8 consecutive k as two ds_write_b128.  All 32 operands of a slab are in VGPRs before the
+// 16 back-to-back MFMAs start (no LDS latency inside the dependent accumulator chain -- that chain, not HBM, is
+// what bounds the many small-M launches of this path); the next K-slab is prefetched from HBM/L2 into registers
+// while the current one feeds the MFMAs.
 //
 // Row gathers on either operand (with "index >= limit -> zero row", which is how the reference's
 // padded patches are built, RIGA_v2.py:129-142) and an elementwise addend on A (x + pos of the
 // cross-attention, geoattention.py:44-45) are fused into the staging loads.
 #include "common.h"
+#include "prof.h"
 #include "roitr_engine.h"
 
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int BM = 64, BN = 64, BK = 32, LDP = 65;
+constexpr int BM = 64, BN = 64, BK = 32, LDR = 20;  // LDR: row pitch (floats) of the [kh][row][kk] LDS image
 
-struct RowSrc {
-    const float* p;  // row pointer or null (zero row)
-    const float* p2;
-};
-
-__device__ __forceinline__ void load8(const float* __restrict__ p, const float* __restrict__ p2, int k, int K, bool vec_ok, float (&v)[8])
+// 8 consecutive k of one row into registers (zero row when p == nullptr; scalar tail when unaligned / past K).
+// No arithmetic here: the consumer of these registers is the NEXT iteration's LDS write, so the loads stay in
+// flight across the MFMA block.
+__device__ __forceinline__ void load8(const float* __restrict__ p, int k, int K, bool vec_ok, float (&v)[8])
 {
     if (p == nullptr) {
 #pragma unroll
@@ -38,25 +41,24 @@ __device__ __forceinline__ void load8(const float* __restrict__ p, const float* 
         const float4 a = *reinterpret_cast<const float4*>(p + k);
         const float4 b = *reinterpret_cast<const float4*>(p + k + 4);
         v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
-        if (p2) {
-            const float4 c = *reinterpret_cast<const float4*>(p2 + k);
-            const float4 d = *reinterpret_cast<const float4*>(p2 + k + 4);
-            v[0] += c.x; v[1] += c.y; v[2] += c.z; v[3] += c.w; v[4] += d.x; v[5] += d.y; v[6] += d.z; v[7] += d.w;
-        }
     } else {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            float x = 0.f;
-            if (k + i < K) { x = p[k + i]; if (p2) x += p2[k + i]; }
-            v[i] = x;
-        }
+        for (int i = 0; i < 8; ++i) v[i] = (k + i < K) ? p[k + i] : 0.f;
     }
 }
 
+// FAST: K % 32 == 0 (<= ZERO_ROW_LEN) and 16-byte aligned rows -> the staging loads are unconditional float4 loads
+// (rows that do not exist are redirected to a resident all-zero row), and a scheduling barrier after the MFMA block
+// keeps every use of the prefetched registers behind it, so nothing forces a vmcnt wait between issuing the
+// prefetch and the MFMAs.  The generic variant keeps bounds-checked scalar tails.
+constexpr int ZERO_ROW_LEN = 2048;
+__device__ __attribute__((aligned(16))) float g_zero_row[ZERO_ROW_LEN];
+
+template <bool FAST>
 __global__ __launch_bounds__(256) void gemm_kernel(RoitrGemm g)
 {
-    __shared__ float As[BK][LDP];
-    __shared__ float Bs[BK][LDP];
+    __shared__ __attribute__((aligned(16))) float As[2 * BM * LDR];
+    __shared__ __attribute__((aligned(16))) float Bs[2 * BN * LDR];
     const int bz = blockIdx.z;
     const float* A = g.A + (size_t)bz * g.sA;
     const float* A2 = g.A2 ? g.A2 + (size_t)bz * g.sA : nullptr;
@@ -102,25 +104,59 @@ __global__ __launch_bounds__(256) void gemm_kernel(RoitrGemm g)
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
 
-    float av[8], wv[8];
-    load8(arow, arow2, kq, g.K, a_vec, av);
-    load8(wrow, nullptr, kq, g.K, w_vec, wv);
+    float av[8], a2v[8], wv[8];
+    if (FAST) {
+        if (!arow) arow = g_zero_row;
+        if (!arow2) arow2 = g_zero_row;
+        if (!wrow) wrow = g_zero_row;
+    }
+    auto fetch = [&](int k) {
+        if (FAST) {
+            const float4 a0 = *reinterpret_cast<const float4*>(arow + k), a1 = *reinterpret_cast<const float4*>(arow + k + 4);
+            const float4 w0 = *reinterpret_cast<const float4*>(wrow + k), w1 = *reinterpret_cast<const float4*>(wrow + k + 4);
+            av[0] = a0.x; av[1] = a0.y; av[2] = a0.z; av[3] = a0.w; av[4] = a1.x; av[5] = a1.y; av[6] = a1.z; av[7] = a1.w;
+            wv[0] = w0.x; wv[1] = w0.y; wv[2] = w0.z; wv[3] = w0.w; wv[4] = w1.x; wv[5] = w1.y; wv[6] = w1.z; wv[7] = w1.w;
+            if (A2) {  // kernel-argument uniform
+                const float4 c0 = *reinterpret_cast<const float4*>(arow2 + k), c1 = *reinterpret_cast<const float4*>(arow2 + k + 4);
+                a2v[0] = c0.x; a2v[1] = c0.y; a2v[2] = c0.z; a2v[3] = c0.w; a2v[4] = c1.x; a2v[5] = c1.y; a2v[6] = c1.z; a2v[7] = c1.w;
+            }
+        } else {
+            load8(arow, k, g.K, a_vec, av);
+            load8(arow2, k, g.K, a_vec, a2v);
+            load8(wrow, k, g.K, w_vec, wv);
+        }
+    };
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a2v[i] = 0.f;
+    fetch(kq);
+    const int kh = lane >> 5, ml = lane & 31;
+    const float4* ar = reinterpret_cast<const float4*>(As + (kh * BM + wm * 32 + ml) * LDR);
+    const float4* br = reinterpret_cast<const float4*>(Bs + (kh * BN + wn * 32 + ml) * LDR);
+    float4* aw0 = reinterpret_cast<float4*>(As + (0 * BM + r) * LDR + (kq >> 1));
+    float4* aw1 = reinterpret_cast<float4*>(As + (1 * BM + r) * LDR + (kq >> 1));
+    float4* bw0 = reinterpret_cast<float4*>(Bs + (0 * BN + r) * LDR + (kq >> 1));
+    float4* bw1 = reinterpret_cast<float4*>(Bs + (1 * BN + r) * LDR + (kq >> 1));
     for (int k0 = 0; k0 < g.K; k0 += BK) {
         __syncthreads();
+        if (!FAST || A2) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) { As[kq + i][r] = av[i]; Bs[kq + i][r] = wv[i]; }
+            for (int i = 0; i < 8; ++i) av[i] += a2v[i];
+        }
+        *aw0 = make_float4(av[0], av[2], av[4], av[6]); *aw1 = make_float4(av[1], av[3], av[5], av[7]);
+        *bw0 = make_float4(wv[0], wv[2], wv[4], wv[6]); *bw1 = make_float4(wv[1], wv[3], wv[5], wv[7]);
         __syncthreads();
-        if (k0 + BK < g.K) {
-            load8(arow, arow2, k0 + BK + kq, g.K, a_vec, av);
-            load8(wrow, nullptr, k0 + BK + kq, g.K, w_vec, wv);
-        }
-        const int kh = lane >> 5, ml = lane & 31;
+        if (k0 + BK < g.K) fetch(k0 + BK + kq);
+        float4 af[4], bf[4];
 #pragma unroll
-        for (int kk = 0; kk < BK / 2; ++kk) {
-            const float a = As[kk * 2 + kh][wm * 32 + ml];
-            const float b = Bs[kk * 2 + kh][wn * 32 + ml];
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+        for (int i = 0; i < 4; ++i) { af[i] = ar[i]; bf[i] = br[i]; }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[i].x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[i].y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[i].z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[i].w, acc, 0, 0, 0);
         }
+        if (FAST) __builtin_amdgcn_sched_barrier(0);  // consumers of the prefetched registers stay below the MFMAs
     }
     const int col = n0 + wn * 32 + (lane & 31);
     if (col < g.N) {
@@ -144,7 +180,13 @@ extern "C" int roitr_gemm(const RoitrGemm* g, hipStream_t stream)
     if (g->M <= 0 || g->N <= 0 || g->batch <= 0) return ROITR_OK;
     if (g->K <= 0 || !g->A || !g->W || !g->C) return ROITR_ERR_ARG;
     dim3 grid(div_up(g->N, BN), div_up(g->M, BM), g->batch);
-    gemm_kernel<<<grid, 256, 0, stream>>>(*g);
+    auto al16 = [](const void* p, long stride_floats) { return ((uintptr_t)p & 15) == 0 && (stride_floats % 4) == 0; };
+    const bool fast = g->K % BK == 0 && g->K <= ZERO_ROW_LEN && g->lda % 4 == 0 && g->ldw % 4 == 0 && al16(g->A, g->sA) && al16(g->W, g->sW) &&
+                      (!g->A2 || al16(g->A2, g->sA));
+    roitr_prof_begin(ROITR_PROF_GEMM, 2.0 * g->M * g->N * (double)g->K * g->batch, stream);
+    if (fast) gemm_kernel<true><<<grid, 256, 0, stream>>>(*g);
+    else gemm_kernel<false><<<grid, 256, 0, stream>>>(*g);
+    roitr_prof_end(ROITR_PROF_GEMM, stream);
     ROITR_LAUNCH_CHECK();
     return ROITR_OK;
 }

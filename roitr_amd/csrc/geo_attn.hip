@@ -14,6 +14,7 @@
 //     proj_p(E) / proj_vp(E) of geoattention.py:104-105 (n^2 C^2 MACs each, 3.3 GFLOP per self layer at
 //     n = 78) are never formed; what remains on E is two streaming passes (n^2 C MACs each).
 #include "common.h"
+#include "prof.h"
 #include "roitr_engine.h"
 
 namespace {
@@ -235,7 +236,11 @@ extern "C" int roitr_mha(const RoitrMha* a, hipStream_t stream)
     if (a->heads > 8 || a->C % a->heads || c % 4 || a->ldk % 4 || a->C % 4) return ROITR_ERR_UNSUPPORTED;
     size_t floats = (size_t)a->C + (a->E ? (size_t)a->heads * a->C : 0) + (size_t)a->heads * a->nk_max * (a->E ? 2 : 1) + 8;
     if (floats * 4 > 150 * 1024) return ROITR_ERR_UNSUPPORTED;
+    static const hipError_t attr_ = hipFuncSetAttribute((const void*)mha_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    (void)attr_;
+    roitr_prof_begin(ROITR_PROF_MHA, 0.0, stream);
     mha_kernel<<<a->q_rows, 256, floats * sizeof(float), stream>>>(*a);
+    roitr_prof_end(ROITR_PROF_MHA, stream);
     ROITR_LAUNCH_CHECK();
     return ROITR_OK;
 }

@@ -492,6 +492,8 @@ extern "C" int roitr_coarse_matching(const RoitrCoarse* a, hipStream_t stream)
     long cap = 1;
     while (cap < (long)a->max_ref * a->max_src) cap <<= 1;
     if (cap * 8 > 128 * 1024 || a->max_ref + a->max_src > 1024) return ROITR_ERR_UNSUPPORTED;
+    static const hipError_t attr_ = hipFuncSetAttribute((const void*)coarse_match_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    (void)attr_;
     coarse_match_kernel<<<a->pairs, 1024, cap * 8, stream>>>(*a);
     ROITR_LAUNCH_CHECK();
     return ROITR_OK;

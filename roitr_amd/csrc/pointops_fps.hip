@@ -23,6 +23,7 @@
 #include "prof.h"
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 
 namespace {
 
@@ -31,36 +32,49 @@ struct Slot {
     float x, y, z, pad;
 };
 
-// Wave-wide max of a signed 64-bit key with DPP row shifts / row broadcasts (VALU-rate cross-lane moves;
-// a __shfl_xor butterfly lowers to ds_bpermute, one LDS round trip per step, ~6x the latency on this
-// serial critical path).  Lanes without a DPP source keep their own value (old = src, bound_ctrl = 0), which is
-// harmless for an idempotent max.  After the row_shr steps lane 15 of every 16-lane row holds the row max,
-// row_bcast:15 / :31 fold the rows, lane 63 ends with the wave max.
+// ---- cross-lane maxima with DPP row shifts / row broadcasts (VALU-rate; a __shfl_xor butterfly lowers to
+// ds_bpermute = one LDS round trip per step on this serial critical path).  Lanes without a DPP source keep
+// their own value (old = src, bound_ctrl = 0), harmless for an idempotent max.  After the row_shr steps lane 15
+// of every 16-lane row holds the row max; row_bcast:15 / :31 fold the rows; lane 63 ends with the wave max.
 template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ long long dpp_max_step(long long v)
+__device__ __forceinline__ float dpp_fmax(float v)
 {
-    const int lo = (int)v, hi = (int)(v >> 32);
-    const int lo2 = __builtin_amdgcn_update_dpp(lo, lo, CTRL, ROW_MASK, 0xf, false);
-    const int hi2 = __builtin_amdgcn_update_dpp(hi, hi, CTRL, ROW_MASK, 0xf, false);
-    const long long w = (long long)(((unsigned long long)(unsigned)hi2 << 32) | (unsigned)lo2);
+    const int i = __float_as_int(v);
+    return fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(i, i, CTRL, ROW_MASK, 0xf, false)));
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned dpp_umax(unsigned v)
+{
+    const unsigned w = (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, ROW_MASK, 0xf, false);
     return w > v ? w : v;
 }
-
+__device__ __forceinline__ float wave_fmax(float v)
+{
+    v = dpp_fmax<0x111, 0xf>(v); v = dpp_fmax<0x112, 0xf>(v); v = dpp_fmax<0x114, 0xf>(v); v = dpp_fmax<0x118, 0xf>(v);
+    v = dpp_fmax<0x142, 0xa>(v); v = dpp_fmax<0x143, 0xc>(v);
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+__device__ __forceinline__ unsigned wave_umax(unsigned v)
+{
+    v = dpp_umax<0x111, 0xf>(v); v = dpp_umax<0x112, 0xf>(v); v = dpp_umax<0x114, 0xf>(v); v = dpp_umax<0x118, 0xf>(v);
+    v = dpp_umax<0x142, 0xa>(v); v = dpp_umax<0x143, 0xc>(v);
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
 __device__ __forceinline__ long long wave_max_i64(long long v)
 {
-    v = dpp_max_step<0x111, 0xf>(v);  // row_shr:1
-    v = dpp_max_step<0x112, 0xf>(v);  // row_shr:2
-    v = dpp_max_step<0x114, 0xf>(v);  // row_shr:4
-    v = dpp_max_step<0x118, 0xf>(v);  // row_shr:8
-    v = dpp_max_step<0x142, 0xa>(v);  // row_bcast:15 -> rows 1,3
-    v = dpp_max_step<0x143, 0xc>(v);  // row_bcast:31 -> rows 2,3
-    const int lo = __builtin_amdgcn_readlane((int)v, 63), hi = __builtin_amdgcn_readlane((int)(v >> 32), 63);
-    return (long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const long long w = __shfl_xor(v, o, 64);
+        v = w > v ? w : v;
+    }
+    return v;
 }
 
-// Key = (float bits of d2) << 32 | tie-break.  d2 >= 0 for real points, so the bits order like
-// the values; empty register slots carry d2 = -1 (sign bit set => negative key => never wins).
-// tie-break = ((1023 - bitrev((k-start) mod bs_ref)) << 21 | (0x1FFFFF - (k-start))) + 1, larger wins.
+// The reference order "max d, then min bitrev((k-start) mod bs_ref), then min k" is evaluated as two chained
+// 32-bit maxima instead of one 64-bit key: first the maximum distance (v_max_f32, no serial compare/select chain),
+// then, among the elements that attain it, the maximum tie-break word
+//     tb = ((1023 - bitrev((k-start) mod bs_ref)) << 21 | (0x1FFFFF - (k-start))) + 1      (larger = preferred).
+// Distances are >= 0; register slots that hold no point carry d2 = -1 and can never attain a maximum >= 0.
 __device__ __forceinline__ unsigned tie_field(int koff, int bs_ref_mask, int bs_ref_bits)
 {
     const unsigned t = (unsigned)(koff & bs_ref_mask);
@@ -68,13 +82,19 @@ __device__ __forceinline__ unsigned tie_field(int koff, int bs_ref_mask, int bs_
     return ((1023u - rev) << 21 | (0x1FFFFFu - (unsigned)koff)) + 1u;
 }
 
+constexpr int FPS_IDX_CAP = 4096;    // selected indices parked in LDS (written out once at the end)
+constexpr int FPS_PTS_CAP = 8192;    // clouds up to this size keep an xyz copy in LDS for the winner lookup
+
 template <int BLOCK, int PPT>
 __global__ __launch_bounds__(BLOCK) void fps_kernel(const float* __restrict__ xyz, const int* __restrict__ offset,
                                                     const int* __restrict__ new_offset, float* __restrict__ tmp,
-                                                    int* __restrict__ idx, int bs_ref_mask, int bs_ref_bits)
+                                                    int* __restrict__ idx, int bs_ref_mask, int bs_ref_bits, int lds_pts)
 {
     constexpr int NW = BLOCK / 64;
-    __shared__ Slot slots[2][NW];
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float2* slots = reinterpret_cast<float2*>(smem);                       // [2][NW] : (max d2, tie word as float bits)
+    int* sidx = reinterpret_cast<int*>(smem + 2 * NW * sizeof(float2));    // [FPS_IDX_CAP]
+    float4* spts = reinterpret_cast<float4*>(smem + 2 * NW * sizeof(float2) + FPS_IDX_CAP * sizeof(int));  // [lds_pts]
 
     const int bid = blockIdx.x;
     const int start_n = bid == 0 ? 0 : offset[bid - 1];
@@ -85,13 +105,13 @@ __global__ __launch_bounds__(BLOCK) void fps_kernel(const float* __restrict__ xy
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
+    const bool pts_in_lds = n <= lds_pts;
 
     float px[PPT], py[PPT], pz[PPT], pt[PPT];
     // (k-start) mod bs_ref only depends on j mod 4 because bs_ref <= 4*BLOCK for every dispatch below
     unsigned tba[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
-        tba[r] = tie_field(tid + r * BLOCK, bs_ref_mask, bs_ref_bits) + (unsigned)(r * BLOCK);
+    for (int r = 0; r < 4; ++r) tba[r] = tie_field(tid + r * BLOCK, bs_ref_mask, bs_ref_bits) + (unsigned)(r * BLOCK);
 #pragma unroll
     for (int j = 0; j < PPT; ++j) {
         const int koff = tid + j * BLOCK;
@@ -99,6 +119,7 @@ __global__ __launch_bounds__(BLOCK) void fps_kernel(const float* __restrict__ xy
             const float* p = xyz + (size_t)(start_n + koff) * 3;
             px[j] = p[0]; py[j] = p[1]; pz[j] = p[2];
             pt[j] = tmp[start_n + koff];
+            if (pts_in_lds) spts[koff] = make_float4(px[j], py[j], pz[j], 0.f);
         } else {
             px[j] = py[j] = pz[j] = 0.f;
             pt[j] = -1.f;
@@ -111,49 +132,56 @@ __global__ __launch_bounds__(BLOCK) void fps_kernel(const float* __restrict__ xy
         const float* p = xyz + (size_t)start_n * 3;  // `old` starts at the segment's first point
         ox = p[0]; oy = p[1]; oz = p[2];
     }
+    __syncthreads();
 
     for (int jm = start_m + 1; jm < end_m; ++jm) {
-        long long best = -1ll;
+        float dmax = -1.f;
 #pragma unroll
         for (int j = 0; j < PPT; ++j) {
-            const float d = sqdist3(px[j], py[j], pz[j], ox, oy, oz);
-            const float d2 = fminf(d, pt[j]);
+            const float d2 = fminf(sqdist3(px[j], py[j], pz[j], ox, oy, oz), pt[j]);
             pt[j] = d2;
+            dmax = fmaxf(dmax, d2);
+        }
+        const float wd = wave_fmax(dmax);
+        unsigned btb = 0u;
+#pragma unroll
+        for (int j = 0; j < PPT; ++j) {
             const unsigned tb = tba[j & 3] - (unsigned)(j * BLOCK);
-            const long long key = (long long)((unsigned long long)__float_as_uint(d2) << 32 | tb);
-            best = key > best ? key : best;
+            const unsigned c = pt[j] == wd ? tb : 0u;
+            btb = c > btb ? c : btb;
         }
-        const long long wbest = wave_max_i64(best);
-        Slot* buf = slots[jm & 1];
-        if (best == wbest && (wbest >= 0 || lane == 0)) {
-            // this lane owns the wave's winner: recover its register slot, publish key + coordinates
-            float wx = 0.f, wy = 0.f, wz = 0.f;
-            const unsigned wtb = (unsigned)wbest;
+        const unsigned wtb = wave_umax(btb);
+        float2* buf = slots + (jm & 1) * NW;
+        if (lane == 0) buf[wave] = make_float2(wd, __uint_as_float(wtb));
+        // LDS-only barrier: wait for this wave's LDS write, not for outstanding global traffic
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        float gd = -1.f;
+        float2 sl[NW];
 #pragma unroll
-            for (int j = 0; j < PPT; ++j) {
-                const bool hit = (tba[j & 3] - (unsigned)(j * BLOCK)) == wtb;
-                wx = hit ? px[j] : wx; wy = hit ? py[j] : wy; wz = hit ? pz[j] : wz;
-            }
-            buf[wave].key = wbest; buf[wave].x = wx; buf[wave].y = wy; buf[wave].z = wz;
-        }
-        __syncthreads();
-        long long gbest = buf[0].key;
-        int gw = 0;
+        for (int w = 0; w < NW; ++w) { sl[w] = buf[w]; gd = fmaxf(gd, sl[w].x); }
+        unsigned gtb = 0u;
 #pragma unroll
-        for (int w = 1; w < NW; ++w) {
-            const long long k = buf[w].key;
-            if (k > gbest) { gbest = k; gw = w; }
+        for (int w = 0; w < NW; ++w) {
+            const unsigned c = sl[w].x == gd ? __float_as_uint(sl[w].y) : 0u;
+            gtb = c > gtb ? c : gtb;
         }
         int old = start_n;
-        if (gbest >= 0) {
-            old = start_n + (int)(0x1FFFFFu - (((unsigned)gbest - 1u) & 0x1FFFFFu));
-            ox = buf[gw].x; oy = buf[gw].y; oz = buf[gw].z;
+        if (gd >= 0.f) old = start_n + (int)(0x1FFFFFu - ((gtb - 1u) & 0x1FFFFFu));
+        if (pts_in_lds) {
+            const float4 q = spts[old - start_n];
+            ox = q.x; oy = q.y; oz = q.z;
         } else if (n > 0) {
-            const float* p = xyz + (size_t)start_n * 3;
+            const float* p = xyz + (size_t)old * 3;
             ox = p[0]; oy = p[1]; oz = p[2];
         }
-        if (tid == 0) idx[jm] = old;
+        if (tid == 0) {
+            if (jm - start_m < FPS_IDX_CAP) sidx[jm - start_m] = old;
+            else idx[jm] = old;
+        }
     }
+    __syncthreads();
+    for (int j = 1 + tid; j < end_m - start_m && j < FPS_IDX_CAP; j += BLOCK) idx[start_m + j] = sidx[j];
 
 #pragma unroll
     for (int j = 0; j < PPT; ++j) {
@@ -203,6 +231,11 @@ __global__ __launch_bounds__(BLOCK) void fps_stream_kernel(const float* __restri
     }
 }
 
+size_t fps_lds_bytes(int block, int lds_pts)
+{
+    return (size_t)2 * (block / 64) * sizeof(float2) + FPS_IDX_CAP * sizeof(int) + (size_t)lds_pts * sizeof(float4);
+}
+
 // cuda_utils.h:11-14: the block size the reference would launch, same double-precision formula
 int ref_block_size(int n)
 {
@@ -221,26 +254,50 @@ extern "C" int roitr_furthestsampling(int b, int n_max, const float* xyz, const 
     const int mask = ref_block_size(n_max) - 1;
     int bits = 0;
     while ((1 << bits) <= mask) ++bits;
+    const int lds_pts = n_max <= FPS_PTS_CAP ? n_max : 0;
+    // experiment knob: ROITR_FPS_BLOCK forces the workgroup size (register-resident variants only)
+    static const int forced = [] { const char* e = getenv("ROITR_FPS_BLOCK"); return e ? atoi(e) : 0; }();
 #define FPS_CASE(BLK, P)                                                                              \
-    if (n_max <= (BLK) * (P)) {                                                                       \
+    if (n_max <= (BLK) * (P) && (forced == 0 || forced == (BLK))) {                                   \
+        static const hipError_t attr_ = hipFuncSetAttribute((const void*)fps_kernel<BLK, P>,          \
+            hipFuncAttributeMaxDynamicSharedMemorySize, (int)fps_lds_bytes(BLK, FPS_PTS_CAP));        \
+        (void)attr_;                                                                                  \
         roitr_prof_begin(ROITR_PROF_FPS, -1.0, stream);                                               \
-        fps_kernel<BLK, P><<<b, BLK, 0, stream>>>(xyz, offset, new_offset, tmp, idx, mask, bits);     \
+        fps_kernel<BLK, P><<<b, BLK, fps_lds_bytes(BLK, lds_pts), stream>>>(xyz, offset, new_offset, tmp, idx, mask, bits, lds_pts); \
         roitr_prof_end(ROITR_PROF_FPS, stream);                                                       \
         ROITR_LAUNCH_CHECK();                                                                         \
         return ROITR_OK;                                                                              \
     }
-    FPS_CASE(64, 2)
-    FPS_CASE(256, 2)
-    FPS_CASE(256, 4)
-    FPS_CASE(256, 8)
-    FPS_CASE(256, 12)
-    FPS_CASE(256, 16)
-    FPS_CASE(256, 20)
-    FPS_CASE(256, 24)
-    FPS_CASE(256, 32)
-    FPS_CASE(512, 24)
-    FPS_CASE(1024, 16)
-    FPS_CASE(1024, 24)
+    if (forced == 0) {
+        FPS_CASE(64, 2)
+        FPS_CASE(256, 2)
+        FPS_CASE(256, 4)
+        FPS_CASE(256, 8)
+        FPS_CASE(256, 12)
+        FPS_CASE(256, 16)
+        FPS_CASE(256, 20)
+        FPS_CASE(256, 24)
+        FPS_CASE(256, 32)
+        FPS_CASE(512, 24)
+        FPS_CASE(512, 32)
+    } else {
+        FPS_CASE(64, 2)
+        FPS_CASE(128, 4)
+        FPS_CASE(128, 16)
+        FPS_CASE(128, 40)
+        FPS_CASE(256, 4)
+        FPS_CASE(256, 8)
+        FPS_CASE(256, 20)
+        FPS_CASE(256, 32)
+        FPS_CASE(512, 2)
+        FPS_CASE(512, 4)
+        FPS_CASE(512, 10)
+        FPS_CASE(512, 16)
+        FPS_CASE(1024, 1)
+        FPS_CASE(1024, 2)
+        FPS_CASE(1024, 5)
+        FPS_CASE(1024, 8)
+    }
 #undef FPS_CASE
     fps_stream_kernel<1024><<<b, 1024, 0, stream>>>(xyz, offset, new_offset, tmp, idx, mask, bits);
     ROITR_LAUNCH_CHECK();

@@ -3,7 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
-#define ROITR_PROF_CLASSES 12
+#define ROITR_PROF_CLASSES 16
 enum {
     ROITR_PROF_FPS = 0,        // fps_kernel, one launch
     ROITR_PROF_KNN = 1,        // knn_grid_kernel / knn_brute_kernel (the query kernel incl. fused PPF), one launch
@@ -16,7 +16,9 @@ enum {
     ROITR_PROF_PH_MATCH = 8,
     ROITR_PROF_PH_FORWARD = 9,
     ROITR_PROF_OT = 10,        // ot_kernel
-    ROITR_PROF_LOCAL_ATTN = 11 // local_attn_kernel
+    ROITR_PROF_LOCAL_ATTN = 11,// local_attn_kernel
+    ROITR_PROF_GEMM = 12,      // gemm_kernel: the "bytes" field carries FLOPs (2*M*N*K*batch)
+    ROITR_PROF_MHA = 13        // mha_kernel
 };
 
 void roitr_prof_begin(int cls, double bytes, hipStream_t st);

@@ -1,0 +1,57 @@
+"""CPU, world_size 2 over gloo: the pair partition and the single result gather of SURVEY.md 8e."""
+import os
+import subprocess
+import sys
+import textwrap
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = textwrap.dedent("""
+    import os, sys, json
+    sys.path.insert(0, %r)
+    import torch, torch.distributed as dist
+    from roitr_amd.shard import pairs_for_rank, gather_counts, gather_result_records
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    mine = pairs_for_rank(7, rank, world)
+    counts = gather_counts(sum(mine))
+    recs = [(i, torch.arange(i + 1, dtype=torch.float32) * (rank + 1)) for i in mine]
+    merged = gather_result_records(recs)
+    out = {"rank": rank, "mine": mine, "counts": counts,
+           "merged": None if merged is None else {str(k): v.tolist() for k, v in sorted(merged.items())}}
+    print("RESULT " + json.dumps(out), flush=True)
+    dist.destroy_process_group()
+""") % ROOT
+
+
+def test_pairs_for_rank_partition():
+    sys.path.insert(0, ROOT)
+    from roitr_amd.shard import pairs_for_rank
+    for world in (1, 2, 4, 8):
+        parts = [pairs_for_rank(1623, r, world) for r in range(world)]
+        flat = sorted(i for p in parts for i in p)
+        assert flat == list(range(1623))                      # every pair exactly once (3DMatch has 1623 pairs)
+        assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
+        assert all(i % world == r for r, p in enumerate(parts) for i in p)
+
+
+def test_two_process_gather_gloo(tmp_path):
+    import json
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29533", str(script)]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=240)
+    assert r.returncode == 0, r.stderr[-2000:]
+    res = [json.loads(l.split("RESULT ", 1)[1]) for l in r.stdout.splitlines() if "RESULT " in l]
+    assert len(res) == 2
+    by_rank = {x["rank"]: x for x in res}
+    assert by_rank[0]["mine"] == [0, 2, 4, 6] and by_rank[1]["mine"] == [1, 3, 5]
+    assert by_rank[0]["counts"] == by_rank[1]["counts"] == [12, 9]
+    assert by_rank[1]["merged"] is None
+    merged = by_rank[0]["merged"]
+    assert sorted(map(int, merged)) == list(range(7))
+    for i in range(7):
+        scale = 1 if i % 2 == 0 else 2
+        assert merged[str(i)] == [float(v * scale) for v in range(i + 1)]
