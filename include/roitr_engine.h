@@ -158,6 +158,31 @@ typedef struct RoitrFine {
 } RoitrFine;
 int roitr_fine_matching(const RoitrFine* a, roitr_stream_t stream);
 
+/* ------------------------------------------------------------------ ground-truth side outputs (need rot/trans) */
+/* Padded clouds for lib/utils.py:506-510: out_pts has n_points + 2*pairs rows -- every cloud followed by its pad row
+ * (the zero row of RIGA_v2.py:86-87), source clouds (and their pad rows) transformed by rot/trans;
+ * out_offset (3*pairs): cumulative padded sizes of the 2*pairs clouds, then the pairs target offsets relative to
+ * the first target row. */
+int roitr_build_padded_clouds(int pairs, int n_points, const float* pts, const int* pt_offset, const float* rot,
+                              const float* trans, float* out_pts, int* out_offset, roitr_stream_t stream);
+/* lib/utils.py:511-527.  d2_padded: squared distance of every padded point to its nearest neighbour in the
+ * partner cloud (kNN(1) over the padded clouds). */
+int roitr_node_occlusion_score(int n_nodes, int limit, const int* cloud_of_node, const int* pt_offset, const int* knn_idx,
+                               const int* knn_mask, const int* node_masks, const float* d2_padded, float overlap_thres,
+                               float* out, roitr_stream_t stream);
+/* lib/utils.py:530-614 (ref = tgt, src = src).  overlap: scratch (pairs, mat_stride >= max_nodes^2);
+ * out_idx (pairs, mat_stride, 2) [ref, src] local node indices in torch.nonzero order, out_overlap, out_count (pairs). */
+typedef struct RoitrNodeCorr {
+    int pairs, limit, max_nodes;
+    float pos_radius;
+    const float* nodes; const int* node_offset; const int* node_masks;
+    const float* points; const int* pt_offset; const int* knn_idx; const int* knn_mask;
+    const float* rot; const float* trans;
+    float* overlap; long mat_stride;
+    int* out_idx; float* out_overlap; int* out_count;
+} RoitrNodeCorr;
+int roitr_node_correspondences(const RoitrNodeCorr* a, roitr_stream_t stream);
+
 /* ------------------------------------------------------------------ the whole-pair engine */
 /* One engine = one set of weights + its workspace on the current device.  Drives the complete test-mode
  * forward of model/RIGA_v2.py:58-175 for a batch of B independent pairs with HIP kernels only.
@@ -202,7 +227,10 @@ typedef struct RoitrForwardIO {
     float* out_tgt_pts; float* out_src_pts; float* out_scores; int* out_patch;  /* capacity B*P*L*fine_topk rows */
     int* fine_offsets;         /* (B*P) first output row of every patch */
     int* n_out;                /* (1) total correspondences */
-    float* gt_tgt_occ; float* gt_src_occ;      /* (T4 halves) node occlusion scores, need rot/trans */
+    float* gt_node_occ;        /* (T4) node occlusion scores, src clouds then tgt clouds; needs rot/trans */
+    int* gt_corr_idx;          /* (B, nmax4^2, 2) [tgt node, src node]; needs rot/trans */
+    float* gt_corr_overlaps;   /* (B, nmax4^2) */
+    int* gt_corr_count;        /* (B) */
 } RoitrForwardIO;
 
 void* roitr_engine_create(const RoitrEngineConfig* cfg);

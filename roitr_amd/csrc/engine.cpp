@@ -501,7 +501,8 @@ extern "C" int roitr_engine_forward(void* h, const RoitrForwardIO* io, hipStream
         size_t need = (size_t)T1 * 4 * (64 * f * 14 + 256 * f * 2 + 600) + (size_t)etot * C4 * 4 * 11 + (size_t)T4 * C4 * 4 * 40 +
                       (size_t)B * P_ * (LIM * LIM * 3 + (LIM + 1) * (LIM + 1) + LIM * 16) * 4 + ((size_t)64 << 20);
         for (int l = 0; l < 4; ++l) need += roitr_knn_workspace_bytes(NC, V.T[l], T1) + 1024;
-        need += (size_t)B * (roitr_coarse_scratch_floats(V.nmax[3], V.nmax[3]) + (size_t)V.nmax[3] * V.nmax[3]) * 4 + 1024;
+        need += (size_t)B * (roitr_coarse_scratch_floats(V.nmax[3], V.nmax[3]) + (size_t)2 * V.nmax[3] * V.nmax[3]) * 4 + 1024;
+        need += 2 * roitr_knn_workspace_bytes(B, T1 + NC, T1 + NC) + (size_t)(T1 + NC) * 16 + 4096;
         if (need > E.arena.cap) {
             ROITR_HIP(hipStreamSynchronize(st));
             if (E.arena.base) ROITR_HIP(hipFree(E.arena.base));
@@ -874,6 +875,44 @@ extern "C" int roitr_engine_forward(void* h, const RoitrForwardIO* io, hipStream
         fm.flags = flags; fm.counts = counts; fm.offsets = offsets; fm.n_out = n_out;
         fm.out_row_pts = o_t; fm.out_col_pts = o_s; fm.out_scores = o_sc; fm.out_patch = io->out_patch;
         CHK(roitr_fine_matching(&fm, st));
+    }
+    // ---------------- ground-truth side outputs (RIGA_v2.py:91-116), only when rot / trans are given
+    if (io->rot && io->trans && (io->gt_node_occ || io->gt_corr_idx)) {
+        const int Tp = T1 + NC;                  // padded rows
+        const int Ts = V.off[0][B - 1];          // source rows
+        const int Tsp = Ts + B, Ttp = Tp - Tsp;  // padded source / target rows
+        float* pad = A.get<float>((size_t)Tp * 3);
+        int* poff = A.get<int>((size_t)3 * B + 4);
+        float* d2p = A.get<float>(Tp);
+        void* ws_s = A.get<char>(roitr_knn_workspace_bytes(B, Tsp, Ttp));
+        void* ws_t = A.get<char>(roitr_knn_workspace_bytes(B, Ttp, Tsp));
+        if (A.fail) { roitr_set_error("arena exhausted (gt)", __FILE__, __LINE__); return ROITR_ERR_ARG; }
+        CHK(roitr_build_padded_clouds(B, T1, pts_out, D.off[0], io->rot, io->trans, pad, poff, st));
+        const float* src_p = pad; const float* tgt_p = pad + (size_t)Tsp * 3;
+        const int* off_s = poff; const int* off_t = poff + 2 * B;
+        const int use_grid = (Tsp > GRID_MIN_POINTS * B) ? 1 : 0;
+        if (io->gt_node_occ) {
+            // kNN(1) of every padded target point among the transformed padded source points, and back (l.509-510)
+            if (use_grid) CHK(roitr_knn_build_grid(B, Tsp, Ttp, src_p, off_s, ws_s, st));
+            CHK(roitr_knnquery_ex(B, Tsp, Ttp, 1, src_p, tgt_p, off_s, off_t, nullptr, d2p + Tsp, nullptr, nullptr, nullptr, nullptr,
+                                  use_grid, Ttp, ws_s, st));
+            if (use_grid) CHK(roitr_knn_build_grid(B, Ttp, Tsp, tgt_p, off_t, ws_t, st));
+            CHK(roitr_knnquery_ex(B, Ttp, Tsp, 1, tgt_p, src_p, off_t, off_s, nullptr, d2p, nullptr, nullptr, nullptr, nullptr, use_grid,
+                                  Tsp, ws_t, st));
+            CHK(roitr_node_occlusion_score(T4, LIM, D.cloud_of_node, D.off[0], kidx, kmask, node_masks, d2p, E.cfg.occlusion_radius,
+                                           io->gt_node_occ, st));
+        }
+        if (io->gt_corr_idx && io->gt_corr_overlaps && io->gt_corr_count) {
+            const long ms = (long)V.nmax[3] * V.nmax[3];
+            float* om = A.get<float>((size_t)B * ms);
+            if (A.fail) { roitr_set_error("arena exhausted (gt)", __FILE__, __LINE__); return ROITR_ERR_ARG; }
+            RoitrNodeCorr nc; memset(&nc, 0, sizeof(nc));
+            nc.pairs = B; nc.limit = LIM; nc.max_nodes = V.nmax[3]; nc.pos_radius = E.cfg.matching_radius;
+            nc.nodes = node_xyz; nc.node_offset = D.off[3]; nc.node_masks = node_masks; nc.points = pts_out; nc.pt_offset = D.off[0];
+            nc.knn_idx = kidx; nc.knn_mask = kmask; nc.rot = io->rot; nc.trans = io->trans; nc.overlap = om; nc.mat_stride = ms;
+            nc.out_idx = io->gt_corr_idx; nc.out_overlap = io->gt_corr_overlaps; nc.out_count = io->gt_corr_count;
+            CHK(roitr_node_correspondences(&nc, st));
+        }
     }
     roitr_prof_end(ROITR_PROF_PH_MATCH, st);
     roitr_prof_end(ROITR_PROF_PH_FORWARD, st);

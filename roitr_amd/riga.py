@@ -140,7 +140,8 @@ class _CForwardIO(ctypes.Structure):
                 ("node_knn_mask", _P), ("tgt_corr", _P), ("src_corr", _P), ("corr_scores", _P), ("n_corr", _P),
                 ("tgt_knn_pts", _P), ("src_knn_pts", _P), ("tgt_knn_masks", _P), ("src_knn_masks", _P),
                 ("matching_scores", _P), ("out_tgt_pts", _P), ("out_src_pts", _P), ("out_scores", _P), ("out_patch", _P),
-                ("fine_offsets", _P), ("n_out", _P), ("gt_tgt_occ", _P), ("gt_src_occ", _P)]
+                ("fine_offsets", _P), ("n_out", _P), ("gt_node_occ", _P), ("gt_corr_idx", _P), ("gt_corr_overlaps", _P),
+                ("gt_corr_count", _P)]
 
 
 def _cfg_get(config, key, default=None):
@@ -326,13 +327,18 @@ class RIGA_v2(nn.Module):
                    tgt_knn_masks=z((B, P, Lm), i32), src_knn_masks=z((B, P, Lm), i32), matching_scores=z((B, P, Lm + 1, Lm + 1)),
                    out_tgt_pts=z((cap, 3)), out_src_pts=z((cap, 3)), out_scores=z((cap,)), out_patch=z((cap,), i32),
                    fine_offsets=z((B * P,), i32), n_out=z((1,), i32))
+        n4max = max(n4)
+        have_gt = want_gt and pairs[0].get("rot") is not None
+        if have_gt:
+            out.update(gt_node_occ=z((T4,)), gt_corr_idx=z((B, n4max * n4max, 2), i32), gt_corr_overlaps=z((B, n4max * n4max)),
+                       gt_corr_count=z((B,), i32))
         io = _CForwardIO()
         io.pairs = B
         arr = (ctypes.c_int * (2 * B))(*n_all)
         io.n_points = ctypes.cast(arr, ctypes.POINTER(ctypes.c_int))
         io.points_geom, io.normals, io.feats, io.points_out = L.ptr(geom), L.ptr(nrm), L.ptr(feats), L.ptr(pout)
         rot = trans = None
-        if want_gt and pairs[0].get("rot") is not None:
+        if have_gt:
             rot = torch.stack([p["rot"].reshape(3, 3).to(f32) for p in pairs]).contiguous()
             trans = torch.stack([p["trans"].reshape(3).to(f32) for p in pairs]).contiguous()
         io.rot, io.trans = L.ptr(rot), L.ptr(trans)
@@ -341,8 +347,9 @@ class RIGA_v2(nn.Module):
         L.check(L.lib().roitr_engine_forward(self._engine, ctypes.byref(io), L.stream_ptr()), "engine_forward")
         # ---- unpack per pair (host sync happens here, on the counts)
         # one D2H transfer for all the counts: [first output row of every pair | total | n_corr per pair]
-        meta = torch.cat([out["fine_offsets"].view(B, P)[:, 0], out["n_out"], out["n_corr"]]).tolist()
-        starts, n_corr = meta[:B + 1], meta[B + 1:]
+        parts = [out["fine_offsets"].view(B, P)[:, 0], out["n_out"], out["n_corr"]] + ([out["gt_corr_count"]] if have_gt else [])
+        meta = torch.cat(parts).tolist()
+        starts, n_corr, gt_cnt = meta[:B + 1], meta[B + 1:2 * B + 1], meta[2 * B + 1:]
         o_pts = np.cumsum([0] + n_all)
         o_nod = np.cumsum([0] + n4)
         results = []
@@ -358,10 +365,13 @@ class RIGA_v2(nn.Module):
             r["tgt_point_feats"] = out["point_feats"][o_pts[tc]:o_pts[tc + 1]]
             r["src_node_feats"] = out["node_feats"][o_nod[sc]:o_nod[sc + 1]]
             r["tgt_node_feats"] = out["node_feats"][o_nod[tc]:o_nod[tc + 1]]
-            r["gt_node_corr_indices"] = None
-            r["gt_node_corr_overlaps"] = None
-            r["gt_tgt_node_occ"] = None
-            r["gt_src_node_occ"] = None
+            if have_gt:
+                r["gt_node_corr_indices"] = lambda b=b: out["gt_corr_idx"][b, :gt_cnt[b]].long()
+                r["gt_node_corr_overlaps"] = out["gt_corr_overlaps"][b, :gt_cnt[b]]
+                r["gt_tgt_node_occ"] = out["gt_node_occ"][o_nod[tc]:o_nod[tc + 1]]
+                r["gt_src_node_occ"] = out["gt_node_occ"][o_nod[sc]:o_nod[sc + 1]]
+            else:
+                r["gt_node_corr_indices"] = r["gt_node_corr_overlaps"] = r["gt_tgt_node_occ"] = r["gt_src_node_occ"] = None
             r["src_node_corr_indices"] = lambda b=b, nc=nc: out["src_corr"][b, :nc].long()
             r["tgt_node_corr_indices"] = lambda b=b, nc=nc: out["tgt_corr"][b, :nc].long()
             r["src_node_corr_knn_points"] = out["src_knn_pts"][b, :nc]

@@ -163,3 +163,12 @@ def test_coarse_and_ot(run):
 def test_final_correspondences_count(run):
     g, out, taps, sizes = run
     assert out["corr_scores"].shape[0] == g["out.corr_scores"].shape[0]
+
+
+def test_gt_side_outputs(run):
+    """get_node_occlusion_score / get_node_correspondences (lib/utils.py:474-614) as captured from the reference."""
+    g, out, taps, sizes = run
+    np.testing.assert_allclose(out["gt_tgt_node_occ"].cpu().numpy(), g["out.gt_tgt_node_occ"], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(out["gt_src_node_occ"].cpu().numpy(), g["out.gt_src_node_occ"], rtol=0, atol=1e-6)
+    assert np.array_equal(out["gt_node_corr_indices"].cpu().numpy(), g["out.gt_node_corr_indices"])
+    np.testing.assert_allclose(out["gt_node_corr_overlaps"].cpu().numpy(), g["out.gt_node_corr_overlaps"], rtol=0, atol=1e-6)
