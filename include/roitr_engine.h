@@ -127,6 +127,8 @@ typedef struct RoitrCoarse {
 } RoitrCoarse;
 size_t roitr_coarse_scratch_floats(int n_ref, int n_src);
 int roitr_coarse_matching(const RoitrCoarse* a, roitr_stream_t stream);
+/* model/modules.py:75-124 AdaptiveSuperPointMatching (4DMatch); needs a->xy; a->num_corr = output capacity per pair */
+int roitr_adaptive_matching(const RoitrCoarse* a, int min_num, float threshold, roitr_stream_t stream);
 
 /* model/RIGA_v2.py:125-147: per patch correspondence the `limit` point rows / points / masks of both sides.
  * rows index the concatenated point arrays (-1 = the zero pad row). */
@@ -199,7 +201,8 @@ typedef struct RoitrEngineConfig {
     int n_geo_layers;      /* len(transformer_architecture) */
     int geo_is_cross[16];  /* 0 = 'self', 1 = 'cross' */
     float matching_radius; /* coarse_matching.matching_radius (GT helpers) */
-    int adaptive_coarse;   /* 1 = AdaptiveSuperPointMatching (4DMatch) -- not implemented yet */
+    int adaptive_coarse;   /* 1 = AdaptiveSuperPointMatching (4DMatch): num_corr is then its min_num_correspondences and
+                              the per-pair patch capacity becomes n_tgt_nodes_max * n_src_nodes_max */
     float occlusion_radius;/* lib/utils.py:485 overlap_thres */
 } RoitrEngineConfig;
 

@@ -470,10 +470,10 @@ extern "C" int roitr_engine_forward(void* h, const RoitrForwardIO* io, hipStream
 {
     Engine& E = *(Engine*)h;
     if (!E.finalized) { roitr_set_error("engine not finalized", __FILE__, __LINE__); return ROITR_ERR_ARG; }
-    if (E.cfg.adaptive_coarse) { roitr_set_error("AdaptiveSuperPointMatching (4DMatch) not implemented", __FILE__, __LINE__); return ROITR_ERR_UNSUPPORTED; }
     const int B = io->pairs, NC = 2 * B;
     if (B <= 0) return 0;
-    const int f = E.cfg.factor, C4 = 256 * f, P_ = E.cfg.num_corr, LIM = E.cfg.point_limit;
+    const int f = E.cfg.factor, C4 = 256 * f, LIM = E.cfg.point_limit;
+    int P_ = E.cfg.num_corr;
 
     // ---------------- level geometry (host), descriptors to the device
     Levels V;
@@ -491,6 +491,7 @@ extern "C" int roitr_engine_forward(void* h, const RoitrForwardIO* io, hipStream
         V.T[l] = acc;
     }
     const int T1 = V.T[0], T4 = V.T[3];
+    if (E.cfg.adaptive_coarse) P_ = V.nmax[3] * V.nmax[3];  // every node pair may be selected (modules.py:111-112)
     if (V.nmax[3] > 1024) { roitr_set_error("more than 1024 superpoints per cloud", __FILE__, __LINE__); return ROITR_ERR_UNSUPPORTED; }
     std::vector<long> eoff(NC);
     long etot = 0;
@@ -845,7 +846,8 @@ extern "C" int roitr_engine_forward(void* h, const RoitrForwardIO* io, hipStream
         c.feats = node_feats; c.node_offset = D.off[3]; c.node_masks = node_masks; c.scratch = cscratch; c.scratch_stride = cstride;
         c.tgt_corr = tgt_corr; c.src_corr = src_corr; c.corr_scores = cscore; c.n_corr = n_corr;
         c.xy = cxy; c.xy_stride = xystride; c.xy_ld = V.nmax[3];
-        CHK(roitr_coarse_matching(&c, st));
+        if (E.cfg.adaptive_coarse) CHK(roitr_adaptive_matching(&c, E.cfg.num_corr, 0.75f, st));
+        else CHK(roitr_coarse_matching(&c, st));
     }
     {
         RoitrPatch pg; memset(&pg, 0, sizeof(pg));

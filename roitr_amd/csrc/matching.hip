@@ -238,6 +238,106 @@ __global__ __launch_bounds__(1024) void coarse_match_kernel(RoitrCoarse a)
     if (tid == 0) a.n_corr[pair] = num;
 }
 
+// ------------------------------------------------------------------ AdaptiveSuperPointMatching (model/modules.py:75-124)
+// 4DMatch coarse matching, called like CoarseMatching (first argument = tgt side, RIGA_v2.py:121).
+// dist = sqrt(clamp(2 - 2 xy, 1e-12)) over mask-valid pairs; if fewer than min(num, #valid) pairs satisfy
+// dist <= threshold: the `min` smallest distances (ascending, flat index on ties), else ALL pairs under the threshold in
+// row-major order.  scores = exp(-dist).  Output capacity per pair: num_corr slots (= n_t * n_s in the engine).
+__global__ __launch_bounds__(1024) void adaptive_match_kernel(RoitrCoarse a, int min_num, float threshold)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned long long keys[];
+    __shared__ int wsum[16];
+    __shared__ int carry_s, below_s;
+    const int pair = blockIdx.x, B = a.pairs;
+    const int sc = pair, tc = B + pair;
+    const int s0 = sc == 0 ? 0 : a.node_offset[sc - 1], nsr = a.node_offset[sc] - s0;
+    const int t0 = a.node_offset[tc - 1], nr = a.node_offset[tc] - t0;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float* M = a.scratch + (size_t)pair * a.scratch_stride;
+    const float* XY = a.xy + (size_t)pair * a.xy_stride;
+    const int total = nr * nsr;
+    if (tid == 0) { carry_s = 0; below_s = 0; }
+    __syncthreads();
+    int nvalid_local = 0, below_local = 0;
+    for (int e = tid; e < total; e += 1024) {
+        const int i = e / nsr, j = e % nsr;
+        float v = -1.f;
+        if (a.node_masks[t0 + i] && a.node_masks[s0 + j]) {
+            v = sqrtf(fmaxf(2.0f - 2.0f * XY[(size_t)i * a.xy_ld + j], 1e-12f));
+            nvalid_local++;
+            below_local += v <= threshold ? 1 : 0;
+        }
+        M[e] = v;
+    }
+    atomicAdd(&below_s, below_local);
+    atomicAdd(&carry_s, nvalid_local);
+    __syncthreads();
+    const int below = below_s, nvalid = carry_s;
+    __syncthreads();
+    const int kmin = min(min_num, nvalid);
+    if (below < kmin) {
+        // top-kmin smallest distances
+        int cap = 1;
+        while (cap < total) cap <<= 1;
+        for (int e = tid; e < cap; e += 1024) {
+            unsigned long long key = ~0ull;
+            if (e < total && M[e] >= 0.f) key = ((unsigned long long)__float_as_uint(M[e]) << 32) | (unsigned)e;
+            keys[e] = key;
+        }
+        __syncthreads();
+        for (int k = 2; k <= cap; k <<= 1) {
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                for (int e = tid; e < cap; e += 1024) {
+                    const int p = e ^ j;
+                    if (p > e) {
+                        const unsigned long long x = keys[e], y = keys[p];
+                        const bool up = (e & k) == 0;
+                        if ((x > y) == up) { keys[e] = y; keys[p] = x; }
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        for (int t = tid; t < kmin; t += 1024) {
+            const unsigned long long key = keys[t];
+            const int e = (int)(unsigned)key;
+            a.tgt_corr[(size_t)pair * a.num_corr + t] = e / nsr;
+            a.src_corr[(size_t)pair * a.num_corr + t] = e % nsr;
+            a.corr_scores[(size_t)pair * a.num_corr + t] = expf(-__uint_as_float((unsigned)(key >> 32)));
+        }
+        if (tid == 0) a.n_corr[pair] = kmin;
+        return;
+    }
+    // all pairs under the threshold, row-major (torch.nonzero order)
+    if (tid == 0) carry_s = 0;
+    __syncthreads();
+    for (int base = 0; base < total; base += 1024) {
+        const int e = base + tid;
+        const float v = e < total ? M[e] : -1.f;
+        const int f = (v >= 0.f && v <= threshold) ? 1 : 0;
+        int incl = f;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        int wb = 0;
+        for (int w = 0; w < wave; ++w) wb += wsum[w];
+        const int carry = carry_s;
+        if (f) {
+            const int pos = carry + wb + incl - 1;
+            if (pos < a.num_corr) {
+                a.tgt_corr[(size_t)pair * a.num_corr + pos] = e / nsr;
+                a.src_corr[(size_t)pair * a.num_corr + pos] = e % nsr;
+                a.corr_scores[(size_t)pair * a.num_corr + pos] = expf(-v);
+            }
+        }
+        __syncthreads();
+        if (tid == 1023) carry_s = carry + wb + incl;
+        __syncthreads();
+    }
+    if (tid == 0) a.n_corr[pair] = min(carry_s, a.num_corr);
+}
+
 // ------------------------------------------------------------------ patch assembly (RIGA_v2.py:125-147)
 // per (pair, corr p, slot i): global feature-row index (or -1 = zero pad), knn point, mask, for both sides
 __global__ void patch_gather_kernel(RoitrPatch a)
@@ -495,6 +595,20 @@ extern "C" int roitr_coarse_matching(const RoitrCoarse* a, hipStream_t stream)
     static const hipError_t attr_ = hipFuncSetAttribute((const void*)coarse_match_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
     (void)attr_;
     coarse_match_kernel<<<a->pairs, 1024, cap * 8, stream>>>(*a);
+    ROITR_LAUNCH_CHECK();
+    return ROITR_OK;
+}
+
+extern "C" int roitr_adaptive_matching(const RoitrCoarse* a, int min_num, float threshold, hipStream_t stream)
+{
+    if (a->pairs <= 0) return ROITR_OK;
+    if (!a->xy) return ROITR_ERR_ARG;
+    long cap = 1;
+    while (cap < (long)a->max_ref * a->max_src) cap <<= 1;
+    if (cap * 8 > 128 * 1024) return ROITR_ERR_UNSUPPORTED;
+    static const hipError_t attr_ = hipFuncSetAttribute((const void*)adaptive_match_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    (void)attr_;
+    adaptive_match_kernel<<<a->pairs, 1024, cap * 8, stream>>>(*a, min_num, threshold);
     ROITR_LAUNCH_CHECK();
     return ROITR_OK;
 }

@@ -142,3 +142,51 @@ def fine_matching(ref_knn_points, src_knn_points, ref_knn_masks, src_knn_masks, 
     L.check(L.lib().roitr_fine_matching(ctypes.byref(a), L.stream_ptr()), "fine_matching")
     n = int(n_out.item())
     return o_r[:n], o_c[:n], o_s[:n]
+
+
+class _Gemm(ctypes.Structure):
+    _fields_ = [("M", ctypes.c_int), ("N", ctypes.c_int), ("K", ctypes.c_int), ("A", _P), ("A2", _P), ("lda", ctypes.c_int),
+                ("a_idx", _P), ("a_limit", ctypes.c_int), ("W", _P), ("ldw", ctypes.c_int), ("w_idx", _P), ("w_limit", ctypes.c_int),
+                ("bias", _P), ("alpha", ctypes.c_float), ("relu", ctypes.c_int), ("C", _P), ("ldc", ctypes.c_int),
+                ("batch", ctypes.c_int), ("sA", ctypes.c_long), ("sW", ctypes.c_long), ("sC", ctypes.c_long),
+                ("sBias", ctypes.c_long), ("sAidx", ctypes.c_long), ("sWidx", ctypes.c_long), ("seg_off", _P),
+                ("seg_a0", ctypes.c_int), ("seg_w0", ctypes.c_int)]
+
+
+def linear(x, weight, bias=None, relu=False, alpha=1.0):
+    """act(alpha * x @ weight.T + bias) on the fp32 MFMA GEMM (the kernel behind every nn.Linear of the path)."""
+    x, weight = x.contiguous().float(), weight.contiguous().float()
+    M, K = x.shape
+    N = weight.shape[0]
+    out = torch.empty((M, N), dtype=torch.float32, device=x.device)
+    b = bias.contiguous().float() if bias is not None else None
+    g = _Gemm(M, N, K, L.ptr(x), L.ptr(None), K, L.ptr(None), 0, L.ptr(weight), K, L.ptr(None), 0, L.ptr(b), float(alpha), int(relu),
+              L.ptr(out), N, 1, 0, 0, 0, 0, 0, 0, L.ptr(None), 0, 0)
+    L.check(L.lib().roitr_gemm(ctypes.byref(g), L.stream_ptr()), "gemm")
+    return out
+
+
+def adaptive_superpoint_matching(src_feats, tgt_feats, src_masks, tgt_masks, min_num_correspondences=128, similarity_threshold=0.75):
+    """model/modules.py:81-124 AdaptiveSuperPointMatching.forward (argument names as in the reference: the FIRST set
+    indexes the first returned index list).  Returns (src_corr_indices, tgt_corr_indices, corr_scores)."""
+    dev = src_feats.device
+    na, nb = src_feats.shape[0], tgt_feats.shape[0]
+    lib = L.lib()
+    lib.roitr_coarse_scratch_floats.restype = ctypes.c_size_t
+    xy = linear(src_feats, tgt_feats)                       # (na, nb) feature dot products
+    feats = torch.cat([tgt_feats, src_feats], 0).contiguous().float()      # engine cloud order: [second set, first set]
+    masks = torch.cat([tgt_masks, src_masks], 0).to(torch.int32).contiguous()
+    off = torch.tensor([nb, nb + na], dtype=torch.int32, device=dev)
+    stride = lib.roitr_coarse_scratch_floats(na, nb)
+    scratch = torch.empty(stride, dtype=torch.float32, device=dev)
+    cap = na * nb
+    ia = torch.zeros(cap, dtype=torch.int32, device=dev)
+    ib = torch.zeros(cap, dtype=torch.int32, device=dev)
+    sc = torch.zeros(cap, dtype=torch.float32, device=dev)
+    nc = torch.zeros(1, dtype=torch.int32, device=dev)
+    a = _Coarse(1, feats.shape[1], cap, 0, na, nb, L.ptr(feats), L.ptr(off), L.ptr(masks), L.ptr(scratch), stride, L.ptr(ia), L.ptr(ib),
+                L.ptr(sc), L.ptr(nc), L.ptr(xy), 0, nb)
+    L.check(lib.roitr_adaptive_matching(ctypes.byref(a), int(min_num_correspondences), ctypes.c_float(similarity_threshold),
+                                        L.stream_ptr()), "adaptive_matching")
+    n = int(nc.item())
+    return ia[:n].long(), ib[:n].long(), sc[:n]

@@ -317,7 +317,9 @@ class RIGA_v2(nn.Module):
         n4 = [self.level_sizes(n)[3] for n in n_all]
         T4 = sum(n4)
         C = 256 * self.factor
-        P, Lm = self.num_est_coarse_corr, self.point_per_patch
+        n4max = max(n4)
+        P = self.num_est_coarse_corr if self.factor == 1 else n4max * n4max   # adaptive matching: every node pair may qualify
+        Lm = self.point_per_patch
         cap = B * P * Lm * self.fine_topk
         z = lambda shape, dt=f32: torch.empty(shape, dtype=dt, device=dev)  # every buffer is fully written by the engine
         i32 = torch.int32
@@ -327,7 +329,6 @@ class RIGA_v2(nn.Module):
                    tgt_knn_masks=z((B, P, Lm), i32), src_knn_masks=z((B, P, Lm), i32), matching_scores=z((B, P, Lm + 1, Lm + 1)),
                    out_tgt_pts=z((cap, 3)), out_src_pts=z((cap, 3)), out_scores=z((cap,)), out_patch=z((cap,), i32),
                    fine_offsets=z((B * P,), i32), n_out=z((1,), i32))
-        n4max = max(n4)
         have_gt = want_gt and pairs[0].get("rot") is not None
         if have_gt:
             out.update(gt_node_occ=z((T4,)), gt_corr_idx=z((B, n4max * n4max, 2), i32), gt_corr_overlaps=z((B, n4max * n4max)),

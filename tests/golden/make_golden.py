@@ -81,6 +81,7 @@ def load_ref_config(benchmark="3DMatch"):
 def build_reference_model(benchmark="3DMatch"):
     from model.RIGA_v2 import create_model
     cfg = load_ref_config(benchmark)
+    cfg["mode"] = "test"
     model = create_model(cfg)
     with torch.no_grad():
         for k, p in model.named_parameters():
@@ -370,5 +371,38 @@ def stage_goldens(model):
     return rec
 
 
+def fdmatch_golden(n=1024):
+    """4DMatch settings (factor 2, AdaptiveSuperPointMatching, top-2 fine matching): end-to-end outputs only."""
+    model, cfg = build_reference_model("4DMatch")
+    pair = make_pair(n, config=4, pair_index=0)
+    T = {k: torch.from_numpy(v) for k, v in pair.items()}
+    with torch.no_grad():
+        out = model.forward(T["src_points"], T["tgt_points"], T["src_feats"], T["tgt_feats"], T["src_normals"], T["tgt_normals"],
+                            T["rot"], T["trans"], T["raw_src_pcd"])
+    rec = {f"in.{k}": v for k, v in pair.items()}
+    for k, v in out.items():
+        a = t2n(v)
+        if a.dtype == np.int64:
+            a = a.astype(np.int32)
+        if k in ("src_point_feats", "tgt_point_feats"):
+            rec[f"out.{k}.every8"] = a[::8].copy()
+        elif k == "matching_scores":
+            rec["out.matching_scores.every8"] = a[::8].copy()
+        elif k in ("src_node_corr_knn_points", "tgt_node_corr_knn_points"):
+            rec[f"out.{k}.every8"] = a[::8].copy()
+        else:
+            rec[f"out.{k}"] = a
+    path = os.path.join(HERE, f"pair_4dmatch_n{n}.npz")
+    np.savez_compressed(path, **rec)
+    print("wrote", path, "%.2f MB" % (os.path.getsize(path) / 1e6), "coarse corr:", rec["out.src_node_corr_indices"].shape,
+          "fine corr:", rec["out.corr_scores"].shape)
+
+
 if __name__ == "__main__":
-    main()
+    if "--fdmatch" in sys.argv:
+        sys.argv.remove("--fdmatch")
+        install_stubs()
+        torch.manual_seed(0)
+        fdmatch_golden()
+    else:
+        main()

@@ -10,7 +10,7 @@ def build_model(benchmark="3DMatch"):
     cfg = test_config(benchmark)
     model = create_model(cfg)
     sd = model.state_dict()
-    for k, shape, kind in state_dict_layout(model.factor, model.architecture):
+    for k, shape, kind in state_dict_layout(model.factor, model.architecture):  # factor 2 for 4DMatch
         if kind == "param":
             sd[k].copy_(torch.from_numpy(closed_form_param(k, tuple(shape))))
     model = model.cuda().eval()

@@ -122,3 +122,11 @@ def test_ot_and_fine_stage(golden_stages):
                                    s["ot.out"][:, :-1, :-1], k, mutual)
         assert np.array_equal(r, s[tag + ".ref"]) and np.array_equal(c, s[tag + ".src"])
         np.testing.assert_allclose(sc, s[tag + ".scores"], rtol=1e-5)
+
+
+def test_adaptive_matching_stage(golden_stages):
+    s = golden_stages
+    for tag, mn in (("adaptive", 128), ("adaptive_nz", 32)):
+        ia, ib, sc = R.adaptive_matching(s["coarse.ref_f"], s["coarse.src_f"], s["coarse.ref_m"], s["coarse.src_m"], mn, 0.75)
+        assert np.array_equal(ia, s[f"{tag}.a_idx"]) and np.array_equal(ib, s[f"{tag}.b_idx"])
+        np.testing.assert_allclose(sc, s[f"{tag}.scores"], rtol=1e-5)
