@@ -1,0 +1,53 @@
+"""`python -m roitr_amd.main <config.yaml> [--pretrain ckpt.pth] [--synthetic N_PAIRS] [--n-points N]`
+
+Test-mode entry mirroring main.py:16-139 of the reference for `mode: test`: load the flattened YAML config,
+build the model, load the checkpoint, run the tester.  Under torch.distributed.run every rank takes its share of
+the pairs (one process per GPU, RCCL for the final gather)."""
+import argparse
+import os
+
+import torch
+
+from .config import Config, load_config
+from .riga import create_model
+from .tester import SyntheticPairs, Tester, load_pretrain
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("config")
+    ap.add_argument("--pretrain", default=None)
+    ap.add_argument("--synthetic", type=int, default=8, help="number of synthetic pairs (no datasets ship with this repo)")
+    ap.add_argument("--n-points", type=int, default=5000)
+    ap.add_argument("--snapshot-dir", default="snapshot")
+    ap.add_argument("--pairs-per-forward", type=int, default=8)
+    args = ap.parse_args()
+    config = Config(load_config(args.config))
+    rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+    torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", 0)))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.distributed.init_process_group("nccl")
+    model = create_model(config).cuda()
+    ckpt = args.pretrain or config.get("pretrain")
+    if ckpt and os.path.exists(ckpt):
+        load_pretrain(model, ckpt)
+    else:
+        from .riga import state_dict_layout
+        from .weights import closed_form_param
+        sd = model.state_dict()
+        for k, shape, kind in state_dict_layout(model.factor, model.architecture):
+            if kind == "param":
+                sd[k].copy_(torch.from_numpy(closed_form_param(k, tuple(shape))))
+        print(f"[roitr_amd] checkpoint {ckpt!r} not found: using closed-form weights (roitr_amd/weights.py)")
+    data = SyntheticPairs(args.synthetic, args.n_points)
+    counts = Tester(config, model, data, args.snapshot_dir, args.pairs_per_forward, rank, world).test()
+    if rank == 0:
+        print(f"[roitr_amd] wrote {args.synthetic} result files under {args.snapshot_dir}/{config.benchmark}; "
+              f"correspondences per rank: {counts}")
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,87 @@
+"""Test-mode harness: the loop of lib/tester.py:19-69 (reference) on the MI355X engine.
+
+Per pair it writes `{snapshot_dir}/{benchmark}/{idx}.pth` with exactly the keys the reference's tester saves
+(lib/tester.py:56-69) so that registration/evaluate_registration_c2f.py can consume the files unchanged.
+Differences by design: pairs are sharded over ranks by their GLOBAL index (pair i -> rank i mod W, the file name
+keeps the global index -- the reference's DDP test mode would overwrite files), several
+pairs go through the engine per forward (`pairs_per_forward`), and checkpoints load through the same
+'module.'-stripping rule as lib/trainer.py:94-130.
+"""
+import os
+
+import torch
+
+from .shard import gather_counts, pairs_for_rank
+
+
+def load_pretrain(model, path):
+    """lib/trainer.py:94-130 `_load_pretrain`: state['state_dict'], 'module.' prefixes stripped, strict load."""
+    state = torch.load(path, map_location="cpu")
+    sd = state["state_dict"] if "state_dict" in state else state
+    sd = {(k[len("module."):] if k.startswith("module.") else k): v for k, v in sd.items()}
+    model.load_state_dict(sd, strict=True)
+    return model
+
+
+class Tester:
+    def __init__(self, config, model, dataset, snapshot_dir="snapshot", pairs_per_forward=8, rank=0, world=1):
+        self.config, self.model, self.dataset = config, model, dataset
+        self.snapshot_dir = snapshot_dir
+        self.pairs_per_forward = pairs_per_forward
+        self.rank, self.world = rank, world
+
+    def _to_device(self, item, device):
+        out = {}
+        for k, v in item.items():
+            out[k] = v.to(device) if torch.is_tensor(v) else v
+        return out
+
+    def test(self, limit=None):
+        benchmark = self.config["benchmark"] if isinstance(self.config, dict) else self.config.benchmark
+        out_dir = os.path.join(self.snapshot_dir, str(benchmark))
+        os.makedirs(out_dir, exist_ok=True)
+        n = len(self.dataset) if limit is None else min(limit, len(self.dataset))
+        mine = pairs_for_rank(n, self.rank, self.world)
+        device = next(self.model.parameters()).device
+        self.model.eval()
+        total_corr = 0
+        with torch.no_grad():
+            for s in range(0, len(mine), self.pairs_per_forward):
+                ids = mine[s:s + self.pairs_per_forward]
+                items = [self._to_device(self.dataset[i], device) for i in ids]
+                pairs = [dict(src_pcd=it["src_points"].contiguous(), tgt_pcd=it["tgt_points"].contiguous(),
+                              src_feats=it["src_feats"].contiguous(), tgt_feats=it["tgt_feats"].contiguous(),
+                              src_normals=it["src_normals"].contiguous(), tgt_normals=it["tgt_normals"].contiguous(),
+                              rot=it["rot"], trans=it["trans"], src_raw_pcd=it["raw_src_pcd"].contiguous()) for it in items]
+                outs = self.model.forward_batch(pairs)
+                for idx, it, p, o in zip(ids, items, pairs, outs):
+                    data = dict()  # lib/tester.py:56-69
+                    data["src_raw_pcd"] = p["src_raw_pcd"].cpu()
+                    data["src_pcd"], data["tgt_pcd"] = p["src_pcd"].cpu(), p["tgt_pcd"].cpu()
+                    data["src_nodes"], data["tgt_nodes"] = o["src_nodes"].cpu(), o["tgt_nodes"].cpu()
+                    data["src_node_desc"], data["tgt_node_desc"] = o["src_node_feats"].cpu(), o["tgt_node_feats"].cpu()
+                    data["src_point_desc"], data["tgt_point_desc"] = o["src_point_feats"].cpu(), o["tgt_point_feats"].cpu()
+                    data["src_corr_pts"], data["tgt_corr_pts"] = o["src_corr_points"].cpu(), o["tgt_corr_points"].cpu()
+                    data["confidence"] = o["corr_scores"].cpu()
+                    data["gt_tgt_node_occ"] = o["gt_tgt_node_occ"].cpu()
+                    data["gt_src_node_occ"] = o["gt_src_node_occ"].cpu()
+                    data["rot"], data["trans"] = p["rot"].cpu(), p["trans"].cpu()
+                    if benchmark in ("4DMatch", "4DLoMatch") and "metric_index" in it:
+                        data["metric_index_list"] = it["metric_index"]
+                    torch.save(data, os.path.join(out_dir, f"{idx}.pth"))
+                    total_corr += int(o["corr_scores"].shape[0])
+        return gather_counts(total_corr)
+
+
+class SyntheticPairs(torch.utils.data.Dataset):
+    """Stand-in for dataset/tdmatch.py (no 3DMatch data in this image): seeded synthetic pairs with the same keys."""
+
+    def __init__(self, n_pairs, n_points=5000, config=2):
+        self.n_pairs, self.n_points, self.config = n_pairs, n_points, config
+
+    def __len__(self):
+        return self.n_pairs
+
+    def __getitem__(self, i):
+        from .synthetic import make_pair
+        return {k: torch.from_numpy(v) for k, v in make_pair(self.n_points, config=self.config, pair_index=i).items()}

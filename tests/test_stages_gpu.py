@@ -84,3 +84,32 @@ def test_forward_at_5000_matches_oracle():
     sc = out["corr_scores"].cpu().numpy()
     assert (sc > 0.05).all()
     assert abs(len(sc) - len(ref["corr_scores"])) <= max(3, 0.02 * len(ref["corr_scores"]))
+
+
+def test_tester_writes_reference_result_files(tmp_path):
+    """lib/tester.py:56-69 file format, checkpoint round trip through the 'module.' prefix rule."""
+    from gpu_util import build_model
+    from roitr_amd.config import test_config
+    from roitr_amd.riga import create_model
+    from roitr_amd.tester import SyntheticPairs, Tester, load_pretrain
+    src = build_model()
+    ckpt = tmp_path / "model.pth"
+    torch.save({"epoch": 1, "state_dict": {"module." + k: v.cpu() for k, v in src.state_dict().items()}}, ckpt)
+    model = load_pretrain(create_model(test_config("3DMatch")), str(ckpt)).cuda()
+    counts = Tester(test_config("3DMatch"), model, SyntheticPairs(3, 1024, config=1), str(tmp_path), pairs_per_forward=2).test()
+    assert len(counts) == 1
+    for i in range(3):
+        d = torch.load(tmp_path / "3DMatch" / f"{i}.pth")
+        assert set(d) == {"src_raw_pcd", "src_pcd", "tgt_pcd", "src_nodes", "tgt_nodes", "src_node_desc", "tgt_node_desc",
+                          "src_point_desc", "tgt_point_desc", "src_corr_pts", "tgt_corr_pts", "confidence", "gt_tgt_node_occ",
+                          "gt_src_node_occ", "rot", "trans"}
+        assert d["src_point_desc"].shape == (1024, 256) and d["src_nodes"].shape == (16, 3)
+        assert d["src_corr_pts"].shape[0] == d["confidence"].shape[0] == d["tgt_corr_pts"].shape[0]
+    # batched forward == single forward, bit for bit (pairs are independent; every kernel is row-local)
+    from roitr_amd.synthetic import make_pair
+    from gpu_util import pair_to_device
+    a = torch.load(tmp_path / "3DMatch" / "1.pth")
+    with torch.no_grad():
+        o = model.forward(**pair_to_device(make_pair(1024, config=1, pair_index=1)))
+    assert torch.equal(o["src_point_feats"].cpu(), a["src_point_desc"]) and torch.equal(o["tgt_node_feats"].cpu(), a["tgt_node_desc"])
+    assert torch.equal(o["corr_scores"].cpu(), a["confidence"])
