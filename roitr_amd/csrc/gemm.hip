@@ -184,6 +184,9 @@ extern "C" int roitr_gemm(const RoitrGemm* g, hipStream_t stream)
     const bool fast = g->K % BK == 0 && g->K <= ZERO_ROW_LEN && g->lda % 4 == 0 && g->ldw % 4 == 0 && al16(g->A, g->sA) && al16(g->W, g->sW) &&
                       (!g->A2 || al16(g->A2, g->sA));
     roitr_prof_begin(ROITR_PROF_GEMM, 2.0 * g->M * g->N * (double)g->K * g->batch, stream);
+    // Measured and dropped (A/B on the 32-pair bench): a 128x128 / 128x64 multi-accumulator tile (7.6 vs 7.4 ms of GEMM
+    // per forward) and two K-slabs per barrier pair (7.9 vs 7.5 ms): these launches are bounded by HBM writes at
+    // level 1 and by short K, not by the LDS->MFMA feed or the prefetch round trip.
     if (fast) gemm_kernel<true><<<grid, 256, 0, stream>>>(*g);
     else gemm_kernel<false><<<grid, 256, 0, stream>>>(*g);
     roitr_prof_end(ROITR_PROF_GEMM, stream);
