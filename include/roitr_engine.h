@@ -182,6 +182,7 @@ typedef struct RoitrNodeCorr {
     const float* rot; const float* trans;
     float* overlap; long mat_stride;
     int* out_idx; float* out_overlap; int* out_count;
+    int n_nodes; float* nodes_t; float* radius;   /* scratch: (n_nodes,3) and (n_nodes) */
 } RoitrNodeCorr;
 int roitr_node_correspondences(const RoitrNodeCorr* a, roitr_stream_t stream);
 

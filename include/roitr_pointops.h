@@ -66,6 +66,9 @@ size_t roitr_knn_workspace_bytes(int b, int n, int m);
 
 /* Counting-sorts the reference clouds into per-cloud uniform grids inside `ws`. */
 int roitr_knn_build_grid(int b, int n, int m_capacity, const float* xyz, const int* offset, void* ws, roitr_stream_t stream);
+/* same, with the mean points-per-cell the cell size is chosen for (<= 0: default 6; ~ (k+1)/3 for the largest k queried) */
+int roitr_knn_build_grid_ex(int b, int n, int m_capacity, const float* xyz, const int* offset, void* ws, float target_occupancy,
+                            roitr_stream_t stream);
 
 /* Exact kNN.  Any of idx/dist2/group_idx/ppf may be NULL.
  *   group_idx (m, nsample-1): columns 1.. of idx  == pointops.queryandgroup(nsample-1, ..., return_idx=True)

@@ -907,12 +907,15 @@ extern "C" int roitr_engine_forward(void* h, const RoitrForwardIO* io, hipStream
         if (io->gt_corr_idx && io->gt_corr_overlaps && io->gt_corr_count) {
             const long ms = (long)V.nmax[3] * V.nmax[3];
             float* om = A.get<float>((size_t)B * ms);
+            float* nt_ = A.get<float>((size_t)T4 * 3);
+            float* nr_ = A.get<float>(T4);
             if (A.fail) { roitr_set_error("arena exhausted (gt)", __FILE__, __LINE__); return ROITR_ERR_ARG; }
             RoitrNodeCorr nc; memset(&nc, 0, sizeof(nc));
             nc.pairs = B; nc.limit = LIM; nc.max_nodes = V.nmax[3]; nc.pos_radius = E.cfg.matching_radius;
             nc.nodes = node_xyz; nc.node_offset = D.off[3]; nc.node_masks = node_masks; nc.points = pts_out; nc.pt_offset = D.off[0];
             nc.knn_idx = kidx; nc.knn_mask = kmask; nc.rot = io->rot; nc.trans = io->trans; nc.overlap = om; nc.mat_stride = ms;
             nc.out_idx = io->gt_corr_idx; nc.out_overlap = io->gt_corr_overlaps; nc.out_count = io->gt_corr_count;
+            nc.n_nodes = T4; nc.nodes_t = nt_; nc.radius = nr_;
             CHK(roitr_node_correspondences(&nc, st));
         }
     }

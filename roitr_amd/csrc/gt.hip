@@ -83,6 +83,32 @@ __global__ void occ_score_kernel(int n_nodes, int limit, const int* __restrict__
     out[node] = s / (m + 1e-10f) * (node_masks[node] ? 1.f : 0.f);
 }
 
+// per node: its (transformed, for source nodes) position and the radius of its patch = max masked |p_k - node|
+// (lib/utils.py:577-582), so that the pair kernel can apply the enclosing-sphere test before touching any point
+__global__ __launch_bounds__(64) void node_radius_kernel(RoitrNodeCorr a, float* __restrict__ nodes_t, float* __restrict__ radius)
+{
+    const int node = blockIdx.x, k = threadIdx.x;
+    const int B = a.pairs, L = a.limit;
+    int c = 0;
+    while (c < 2 * B - 1 && node >= a.node_offset[c]) ++c;
+    const int p0 = c == 0 ? 0 : a.pt_offset[c - 1], pn = a.pt_offset[c] - p0;
+    float nx = a.nodes[(size_t)node * 3], ny = a.nodes[(size_t)node * 3 + 1], nz = a.nodes[(size_t)node * 3 + 2];
+    const bool src = c < B;
+    const float* R = a.rot + (size_t)(src ? c : 0) * 9; const float* T = a.trans + (size_t)(src ? c : 0) * 3;
+    if (src) transform3(R, T, nx, ny, nz, nx, ny, nz);
+    float d = 0.f;
+    if (k < L && a.knn_mask[(size_t)node * L + k]) {
+        const int li = a.knn_idx[(size_t)node * L + k];
+        float x = 0.f, y = 0.f, z = 0.f;
+        if (li < pn) { const float* p = a.points + (size_t)(p0 + li) * 3; x = p[0]; y = p[1]; z = p[2]; }
+        if (src) transform3(R, T, x, y, z, x, y, z);
+        const float dx = x - nx, dy = y - ny, dz = z - nz;
+        d = sqrtf(dx * dx + dy * dy + dz * dz);
+    }
+    d = wave_max(d);
+    if (k == 0) { nodes_t[(size_t)node * 3] = nx; nodes_t[(size_t)node * 3 + 1] = ny; nodes_t[(size_t)node * 3 + 2] = nz; radius[node] = d; }
+}
+
 // one block per (pair, ref node i, src node j): overlap ratio of the two patches (0 when pruned / masked)
 __global__ __launch_bounds__(256) void node_corr_kernel(RoitrNodeCorr a)
 {
@@ -101,6 +127,11 @@ __global__ __launch_bounds__(256) void node_corr_kernel(RoitrNodeCorr a)
     const int rnode = t0 + i, snode = s0 + j;
     const float* R = a.rot + (size_t)pair * 9; const float* T = a.trans + (size_t)pair * 3;
     if (!(a.node_masks[rnode] && a.node_masks[snode])) { if (tid == 0) outm[(size_t)i * ns + j] = 0.f; return; }
+    {   // enclosing-sphere prune (l.577-586) from the per-node records, before any point is loaded
+        const float* rn = a.nodes_t + (size_t)rnode * 3; const float* sn_ = a.nodes_t + (size_t)snode * 3;
+        const float nd0 = sqrtf(square_distance3(rn[0], rn[1], rn[2], sn_[0], sn_[1], sn_[2]));
+        if (!(a.radius[rnode] + a.radius[snode] + a.pos_radius - nd0 > 0.f)) { if (tid == 0) outm[(size_t)i * ns + j] = 0.f; return; }
+    }
     const int tp0 = a.pt_offset[tc - 1], tn = a.pt_offset[tc] - tp0;
     const int sp0 = sc == 0 ? 0 : a.pt_offset[sc - 1], sn = a.pt_offset[sc] - sp0;
     const float rnx = a.nodes[(size_t)rnode * 3], rny = a.nodes[(size_t)rnode * 3 + 1], rnz = a.nodes[(size_t)rnode * 3 + 2];
@@ -220,6 +251,9 @@ extern "C" int roitr_node_correspondences(const RoitrNodeCorr* a, hipStream_t st
 {
     if (a->pairs <= 0) return ROITR_OK;
     if (a->limit != 64) return ROITR_ERR_UNSUPPORTED;
+    if (!a->nodes_t || !a->radius) return ROITR_ERR_ARG;
+    node_radius_kernel<<<a->n_nodes, 64, 0, stream>>>(*a, a->nodes_t, a->radius);
+    ROITR_LAUNCH_CHECK();
     node_corr_kernel<<<dim3(a->max_nodes, a->max_nodes, a->pairs), 256, 0, stream>>>(*a);
     ROITR_LAUNCH_CHECK();
     node_corr_compact_kernel<<<a->pairs, 1024, 0, stream>>>(*a);

@@ -25,6 +25,7 @@
 #include "common.h"
 #include "prof.h"
 #include <math.h>
+#include <stdlib.h>
 
 #define KNN_FILL 1e10f  // knnquery_cuda_kernel.cu:89
 #define GRID_MAX_CELLS 16384
@@ -425,6 +426,166 @@ __global__ __launch_bounds__(256) void knn_grid_kernel(int m, int nsample, const
     finish_query<NR>(L, o, q, nsample, lane, xyz, Q);
 }
 
+// Queries that are not the reference points themselves: counting-sort their indices by the cell of the REFERENCE grid
+// they fall into (one workgroup per cloud), so that the lane kernel walks them in cell order too.
+__global__ __launch_bounds__(1024) void sort_queries_kernel(const float* __restrict__ new_xyz, const int* __restrict__ new_offset,
+                                                            const RoitrGrid* __restrict__ grids, int* __restrict__ qorder)
+{
+    __shared__ int cnt[GRID_MAX_CELLS];
+    __shared__ int wave_tot[16];
+    const int c = blockIdx.x;
+    const int start = c == 0 ? 0 : new_offset[c - 1], end = new_offset[c];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const RoitrGrid g = grids[c];
+    const int ncell = g.nx * g.ny * g.nz;
+    auto cell_of = [&](int k) {
+        const float x = new_xyz[(size_t)k * 3], y = new_xyz[(size_t)k * 3 + 1], z = new_xyz[(size_t)k * 3 + 2];
+        const int cx = (int)fminf(fmaxf((x - g.ox) * g.inv_h, 0.f), (float)(g.nx - 1));
+        const int cy = (int)fminf(fmaxf((y - g.oy) * g.inv_h, 0.f), (float)(g.ny - 1));
+        const int cz = (int)fminf(fmaxf((z - g.oz) * g.inv_h, 0.f), (float)(g.nz - 1));
+        return (cz * g.ny + cy) * g.nx + cx;
+    };
+    for (int k = tid; k < GRID_MAX_CELLS; k += 1024) cnt[k] = 0;
+    __syncthreads();
+    for (int k = start + tid; k < end; k += 1024) atomicAdd(&cnt[cell_of(k)], 1);
+    __syncthreads();
+    constexpr int PER = GRID_MAX_CELLS / 1024;
+    int loc[PER], sum = 0;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) { const int k = tid * PER + j; loc[j] = k < ncell ? cnt[k] : 0; sum += loc[j]; }
+    int incl = sum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o, 64); if (lane >= o) incl += v; }
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    int run = incl - sum;
+    for (int w = 0; w < wave; ++w) run += wave_tot[w];
+#pragma unroll
+    for (int j = 0; j < PER; ++j) { const int k = tid * PER + j; if (k < ncell) cnt[k] = run; run += loc[j]; }
+    __syncthreads();
+    for (int k = start + tid; k < end; k += 1024) qorder[start + atomicAdd(&cnt[cell_of(k)], 1)] = k;
+}
+
+// ---------------------------------------------------------------- grid query, one LANE per query
+// For large query counts (tens of thousands and up: every level-1/2 call of a multi-pair batch) a wave per query
+// spends ~40x more instructions than the arithmetic needs.  Here every lane owns a query and its own sorted list in
+// registers (L = template capacity >= nsample+1); lanes walk the same Chebyshev rings over the same grid.  Self
+// queries are taken in CELL ORDER (the counting-sorted order), so the 64 lanes of a wave search neighbouring cells:
+// their trip counts agree and their candidate loads hit the same cache lines.  Same exactness rule as the wave
+// kernel: ties among the best nsample+1 distances -> the query goes to the replay kernel.
+template <int L>
+__global__ __launch_bounds__(256) void knn_lane_kernel(int m, int nsample, int b, const float* __restrict__ xyz,
+                                                       const float* __restrict__ new_xyz, const int* __restrict__ offset,
+                                                       const int* __restrict__ new_offset, const RoitrGrid* __restrict__ grids,
+                                                       const int* __restrict__ cell_start, const float4* __restrict__ sorted, KnnOut o,
+                                                       int self_sorted, const int* __restrict__ qorder)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= m) return;
+    const int q = self_sorted ? __float_as_int(sorted[t].w) : (qorder ? qorder[t] : t);
+    int lo = 0, hi = b - 1;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (q < new_offset[mid]) hi = mid; else lo = mid + 1; }
+    const int seg = lo;
+    const int start = seg == 0 ? 0 : offset[seg - 1];
+    const RoitrGrid g = grids[seg];
+    const int* cs = cell_start + (size_t)seg * (GRID_MAX_CELLS + 1);
+    const float qx = new_xyz[(size_t)q * 3], qy = new_xyz[(size_t)q * 3 + 1], qz = new_xyz[(size_t)q * 3 + 2];
+    float d[L]; int id[L];
+#pragma unroll
+    for (int j = 0; j < L; ++j) { d[j] = KNN_FILL; id[j] = start; }
+    int c0[3];
+    {
+        const float tq[3] = {(qx - g.ox) * g.inv_h, (qy - g.oy) * g.inv_h, (qz - g.oz) * g.inv_h};
+        const int dim[3] = {g.nx, g.ny, g.nz};
+#pragma unroll
+        for (int a = 0; a < 3; ++a) c0[a] = (int)fminf(fmaxf(tq[a], 0.f), (float)(dim[a] - 1));
+    }
+    auto offer = [&](float dd, int ci) {
+        if (dd < d[L - 1]) {
+#pragma unroll
+            for (int j = L - 1; j > 0; --j) {
+                const bool sh = d[j - 1] > dd, here = d[j] > dd;
+                d[j] = sh ? d[j - 1] : (here ? dd : d[j]);
+                id[j] = sh ? id[j - 1] : (here ? ci : id[j]);
+            }
+            const bool h0 = d[0] > dd;
+            d[0] = h0 ? dd : d[0]; id[0] = h0 ? ci : id[0];
+        }
+    };
+    auto scan = [&](int s, int e) {
+        // four candidate loads in flight per lane (clamped addresses, masked distances): the loop is otherwise one
+        // dependent L2 round trip per candidate
+        for (int p = s; p < e; p += 4) {
+            const float4 c0_ = sorted[p], c1_ = sorted[min(p + 1, e - 1)], c2_ = sorted[min(p + 2, e - 1)], c3_ = sorted[min(p + 3, e - 1)];
+            const float d0 = sqdist3(qx, qy, qz, c0_.x, c0_.y, c0_.z);
+            const float d1 = p + 1 < e ? sqdist3(qx, qy, qz, c1_.x, c1_.y, c1_.z) : INFINITY;
+            const float d2_ = p + 2 < e ? sqdist3(qx, qy, qz, c2_.x, c2_.y, c2_.z) : INFINITY;
+            const float d3 = p + 3 < e ? sqdist3(qx, qy, qz, c3_.x, c3_.y, c3_.z) : INFINITY;
+            offer(d0, __float_as_int(c0_.w)); offer(d1, __float_as_int(c1_.w));
+            offer(d2_, __float_as_int(c2_.w)); offer(d3, __float_as_int(c3_.w));
+        }
+    };
+    const float margin = 2e-4f * g.h;
+    const int maxr = max(max(g.nx, g.ny), g.nz);
+    for (int r = 0; r <= maxr; ++r) {
+        const int x0 = max(c0[0] - r, 0), x1 = min(c0[0] + r, g.nx - 1);
+        const int y0 = max(c0[1] - r, 0), y1 = min(c0[1] + r, g.ny - 1);
+        const int z0 = max(c0[2] - r, 0), z1 = min(c0[2] + r, g.nz - 1);
+        for (int cz = z0; cz <= z1; ++cz) {
+            for (int cy = y0; cy <= y1; ++cy) {
+                const int rowbase = (cz * g.ny + cy) * g.nx;
+                const bool face = (r == 0) || (cy == c0[1] - r) || (cy == c0[1] + r) || (cz == c0[2] - r) || (cz == c0[2] + r);
+                if (face) scan(cs[rowbase + x0], cs[rowbase + x1 + 1]);
+                else {
+                    const int xa = c0[0] - r, xb = c0[0] + r;
+                    if (xa >= 0) scan(cs[rowbase + xa], cs[rowbase + xa + 1]);
+                    if (xb < g.nx) scan(cs[rowbase + xb], cs[rowbase + xb + 1]);
+                }
+            }
+        }
+        float dmin = INFINITY;
+        if (x0 > 0) dmin = fminf(dmin, qx - __fmaf_rn((float)x0, g.h, g.ox));
+        if (x1 < g.nx - 1) dmin = fminf(dmin, __fmaf_rn((float)(x1 + 1), g.h, g.ox) - qx);
+        if (y0 > 0) dmin = fminf(dmin, qy - __fmaf_rn((float)y0, g.h, g.oy));
+        if (y1 < g.ny - 1) dmin = fminf(dmin, __fmaf_rn((float)(y1 + 1), g.h, g.oy) - qy);
+        if (z0 > 0) dmin = fminf(dmin, qz - __fmaf_rn((float)z0, g.h, g.oz));
+        if (z1 < g.nz - 1) dmin = fminf(dmin, __fmaf_rn((float)(z1 + 1), g.h, g.oz) - qz);
+        if (dmin == INFINITY) break;
+        float tau = d[L - 1];  // the (nsample+1)-th best must be final before stopping
+#pragma unroll
+        for (int j = 0; j < L - 1; ++j) tau = (j == nsample) ? d[j] : tau;
+        const float dm = dmin - margin;
+        if (dm > 0.f && tau < dm * dm) break;
+    }
+    bool tie = false;
+#pragma unroll
+    for (int j = 0; j + 1 < L; ++j) tie |= (j < nsample) && (d[j] == d[j + 1]) && (d[j] < KNN_FILL);
+    if (tie) {
+        const int slot = atomicAdd(o.tie_count, 1);
+        o.tie_list[slot] = q;
+        return;
+    }
+#pragma unroll
+    for (int j = 0; j < L; ++j) {
+        if (j < nsample) {
+            if (o.idx) o.idx[(size_t)q * nsample + j] = id[j];
+            if (o.dist2) o.dist2[(size_t)q * nsample + j] = d[j];
+            if (j >= 1 && o.group_idx) o.group_idx[(size_t)q * (nsample - 1) + j - 1] = id[j];
+        }
+    }
+    if (o.ppf) {  // neighbour indices are read back from the row this lane just wrote
+        const float* qn = o.query_normals + (size_t)q * 3;
+        const float nx = qn[0], ny = qn[1], nz = qn[2];
+        for (int j = 0; j < nsample - 1; ++j) {
+            const int gi = o.group_idx[(size_t)q * (nsample - 1) + j];
+            const float* pp = xyz + (size_t)gi * 3;
+            const float* pn = o.ref_normals + (size_t)gi * 3;
+            reinterpret_cast<float4*>(o.ppf)[(size_t)q * (nsample - 1) + j] =
+                ppf4(qx, qy, qz, nx, ny, nz, pp[0], pp[1], pp[2], pn[0], pn[1], pn[2]);
+        }
+    }
+}
+
 // ---------------------------------------------------------------- exact replay of tied queries
 // knnquery_cuda_kernel.cu:65-108 restated for one wave: the heap lives in LDS, every lane runs the
 // same (uniform) heap code; 64 distances are evaluated per step and only those below the root are
@@ -513,12 +674,13 @@ extern "C" size_t roitr_knn_workspace_bytes(int b, int n, int m)
     ints += (size_t)b * 8 + (size_t)b * (GRID_MAX_CELLS + 1);
     ints = (ints + 3) & ~(size_t)3;
     ints += (size_t)n * 4;
+    ints += (size_t)m;  // query order (lane kernel, non-self queries)
     return ints * 4 + 64;
 }
 
 namespace {
 struct WsView {
-    int* tie_count; int* tie_list; RoitrGrid* grids; int* cell_start; float4* sorted;
+    int* tie_count; int* tie_list; RoitrGrid* grids; int* cell_start; float4* sorted; int* qorder;
 };
 WsView carve(void* ws, int b, int n, int m)
 {
@@ -531,19 +693,32 @@ WsView carve(void* ws, int b, int n, int m)
     v.cell_start = p + ints; ints += (size_t)b * (GRID_MAX_CELLS + 1);
     ints = (ints + 3) & ~(size_t)3;
     v.sorted = (float4*)(p + ints);
-    (void)n;
+    ints += (size_t)n * 4;
+    v.qorder = (b > 0 && n > 0) ? p + ints : nullptr;
     return v;
 }
 }  // namespace
 
 // Builds the per-cloud uniform grids for `xyz` (b clouds, n points) into `ws`; reusable by any number
 // of roitr_knnquery_grid calls on the same reference cloud set (same b, n, m-capacity carve).
+extern "C" int roitr_knn_build_grid_ex(int b, int n, int m_capacity, const float* xyz, const int* offset, void* ws, float target_occupancy,
+                                       hipStream_t stream);
 extern "C" int roitr_knn_build_grid(int b, int n, int m_capacity, const float* xyz, const int* offset, void* ws, hipStream_t stream)
+{
+    return roitr_knn_build_grid_ex(b, n, m_capacity, xyz, offset, ws, 0.f, stream);
+}
+
+// target_occupancy: mean points per grid cell the cell size is chosen for (<= 0: default).  The ring-1 neighbourhood
+// (27 cells) should hold the k+1 nearest neighbours of almost every query: ~ (k+1)/3 points per cell.
+extern "C" int roitr_knn_build_grid_ex(int b, int n, int m_capacity, const float* xyz, const int* offset, void* ws, float target_occupancy,
+                                       hipStream_t stream)
 {
     if (b <= 0 || n <= 0) return ROITR_OK;
     WsView v = carve(ws, b, n, m_capacity);
+    static const float rho_env = [] { const char* e = getenv("ROITR_KNN_RHO"); return e ? (float)atof(e) : 0.f; }();
+    const float rho = rho_env > 0.f ? rho_env : (target_occupancy > 0.f ? target_occupancy : 6.0f);
     roitr_prof_begin(ROITR_PROF_GRID, 12.0 * n + 16.0 * n, stream);
-    grid_build_kernel<<<b, 1024, 0, stream>>>(xyz, offset, v.grids, v.cell_start, v.sorted, 3.0f);
+    grid_build_kernel<<<b, 1024, 0, stream>>>(xyz, offset, v.grids, v.cell_start, v.sorted, rho);
     roitr_prof_end(ROITR_PROF_GRID, stream);
     ROITR_LAUNCH_CHECK();
     return ROITR_OK;
@@ -570,6 +745,28 @@ extern "C" int roitr_knnquery_ex(int b, int n, int m, int nsample, const float* 
         bytes += ((idx ? 4.0 * nsample : 0.0) + (dist2 ? 4.0 * nsample : 0.0) + (group_idx ? 4.0 * kk : 0.0) + (ppf ? 16.0 * kk : 0.0)) * m;
         roitr_prof_begin(ROITR_PROF_KNN, bytes, stream);
     }
+    static const int lane_min = [] { const char* e = getenv("ROITR_KNN_LANE_MIN"); return e ? atoi(e) : 8192; }();
+    const bool lane_ok = use_grid && m >= lane_min && (!ppf || group_idx) && b > 0;
+    const int self_sorted = (new_xyz == xyz && new_offset == offset && m == n) ? 1 : 0;
+    // non-self queries: walk them in reference-cell order; the order array reuses the tie list's tail
+    // (tie slots are handed out from the front; a query is either listed as a tie or not, so m slots suffice for both
+    //  only if disjoint -> the order array lives in its own region carved behind the sorted points)
+    int* qorder = nullptr;
+    if (lane_ok && !self_sorted && v.qorder) {
+        qorder = v.qorder;
+        sort_queries_kernel<<<b, 1024, 0, stream>>>(new_xyz, new_offset, v.grids, qorder);
+    }
+#define LANE_CASE(LC)                                                                                                        \
+    knn_lane_kernel<LC><<<div_up(m, 256), 256, 0, stream>>>(m, nsample, b, xyz, new_xyz, offset, new_offset, v.grids, v.cell_start, \
+                                                             v.sorted, o, self_sorted, qorder)
+    if (lane_ok && nsample + 1 <= 34) {
+        const int need = nsample + 1;
+        if (need <= 2) LANE_CASE(2); else if (need <= 4) LANE_CASE(4); else if (need <= 10) LANE_CASE(10);
+        else if (need <= 18) LANE_CASE(18); else LANE_CASE(34);
+    } else if (lane_ok && m >= 4 * lane_min) {
+        if (nsample + 1 <= 66) LANE_CASE(66); else LANE_CASE(101);
+    } else
+#undef LANE_CASE
     if (use_grid) {
         if (nsample + 1 <= 64)
             knn_grid_kernel<1><<<blocks, 256, 0, stream>>>(m, nsample, xyz, new_xyz, offset, new_offset, v.grids, v.cell_start, v.sorted, o);
