@@ -53,6 +53,9 @@ int roitr_interp3_add(int n, int C, const float* feat, const int* idx, const flo
 int roitr_segment_mean(int b, int C, const float* x, const int* offset, float* out, roitr_stream_t stream);
 /* SinusoidalPositionalEmbedding (positional_encoding.py:38-62): out (rows, C) */
 int roitr_sinusoid(long rows, int C, const float* vals, const float* div_term, float* out, roitr_stream_t stream);
+/* Fused positional_encoding.py:139-154: out[r,:] = proj_d(sinusoid(d_idx[r])) + max_k proj_a(sinusoid(a_idx[r,k])) */
+int roitr_geo_embed(long rows, int C, int angle_k, const float* d_idx, const float* a_idx, const float* div_term,
+                    const float* Wd, const float* bd, const float* Wa, const float* ba, float* out, roitr_stream_t stream);
 /* E = P_d + max_k P_a[:, k, :] (positional_encoding.py:146-152) */
 int roitr_geo_combine(long rows, int C, int k, const float* pd, const float* pa, float* out, roitr_stream_t stream);
 int roitr_gather_rows(long rows, int C, const float* in, const int* idx, int limit, float* out, roitr_stream_t stream);
@@ -75,6 +78,7 @@ typedef struct RoitrLocalAttn {
     const float* wvpe; const float* bvpe;
     float scale;
     float* out; int ldo;
+    const void* node_order;   /* optional float4[M] (x,y,z,index-as-bits): visiting order, e.g. roitr_knn_sorted_points() */
 } RoitrLocalAttn;
 int roitr_local_attention(const RoitrLocalAttn* a, roitr_stream_t stream);
 int roitr_build_pfold(int H, int heads, const float* wpe, const float* bpe, float* pfold, roitr_stream_t stream);

@@ -70,6 +70,10 @@ int roitr_knn_build_grid(int b, int n, int m_capacity, const float* xyz, const i
 int roitr_knn_build_grid_ex(int b, int n, int m_capacity, const float* xyz, const int* offset, void* ws, float target_occupancy,
                             roitr_stream_t stream);
 
+/* The counting-sorted reference points inside a built workspace: float4 (x, y, z, original index as int bits), n entries,
+ * cell-major order.  Valid after roitr_knn_build_grid on (b, n, m_capacity, ws). */
+const void* roitr_knn_sorted_points(int b, int n, int m_capacity, void* ws);
+
 /* Exact kNN.  Any of idx/dist2/group_idx/ppf may be NULL.
  *   group_idx (m, nsample-1): columns 1.. of idx  == pointops.queryandgroup(nsample-1, ..., return_idx=True)
  *                             (functions/pointops.py:88-89: kNN(k+1), drop column 0)

@@ -240,7 +240,7 @@ struct Dev {  // device-resident descriptors
 
 // LocalPPFTransformer.forward (ppftransformer.py:227-253) on N_in input rows -> M node rows
 int local_transformer(Engine& E, hipStream_t st, const LocalT& L, int N_in, const float* x, int M, const int* node_idx, const int* group,
-                      const float* ppf, int K, float* out)
+                      const float* ppf, int K, float* out, const void* order = nullptr)
 {
     Arena& A = E.arena;
     const size_t mark = A.off;
@@ -270,7 +270,7 @@ int local_transformer(Engine& E, hipStream_t st, const LocalT& L, int N_in, cons
     memset(&a, 0, sizeof(a));
     a.M = M; a.K = K; a.H = H; a.heads = HEADS; a.q = q; a.ldq = ldq; a.k = k; a.ldk = ldkv; a.v = v; a.ldv = ldkv;
     a.group_idx = group; a.ppf = ppf; a.wvpe = L.wvpe; a.bvpe = L.bvpe; a.scale = 1.0f / sqrtf((float)(H / HEADS));
-    a.out = att; a.ldo = H;
+    a.out = att; a.ldo = H; a.node_order = order;
     CHK(roitr_local_attention(&a, st));
     CHK(gemm(st, M, att, L.lin, hid));
     CHK(roitr_add_layernorm(M, H, hid, f, node_idx, L.norm_w, L.norm_b, nullptr, 0, 1e-5f, y, st));
@@ -280,13 +280,14 @@ int local_transformer(Engine& E, hipStream_t st, const LocalT& L, int N_in, cons
 }
 
 // RIPointTransformerBlock.forward (model/model.py:131-142): relu(bn2(transformer(x)) + x)
-int block(Engine& E, hipStream_t st, const LocalT& L, int M, const float* x, const int* group, const float* ppf, int K, float* out)
+int block(Engine& E, hipStream_t st, const LocalT& L, int M, const float* x, const int* group, const float* ppf, int K, float* out,
+          const void* order = nullptr)
 {
     Arena& A = E.arena;
     const size_t mark = A.off;
     float* t = A.get<float>((size_t)M * L.out_dim);
     if (A.fail) return ROITR_ERR_ARG;
-    CHK(local_transformer(E, st, L, M, x, M, nullptr, group, ppf, K, t));
+    CHK(local_transformer(E, st, L, M, x, M, nullptr, group, ppf, K, t, order));
     CHK(roitr_add_layernorm(M, L.out_dim, t, nullptr, nullptr, L.bn2_w, L.bn2_b, x, 1, 1e-5f, out, st));
     A.off = mark;
     return 0;
@@ -557,6 +558,7 @@ extern "C" int roitr_engine_forward(void* h, const RoitrForwardIO* io, hipStream
     int* g_td[4]; float* ppf_td[4];                        // TransitionDown groups (level l nodes over level l-1 points)
     void* knn_ws[4];
     bool grid[4];
+    const void* order[4] = {nullptr, nullptr, nullptr, nullptr};  // cell-order visiting order of each level's points
     float* xe[4];
     if (!E.side) {
         ROITR_HIP(hipStreamCreateWithFlags(&E.side, hipStreamNonBlocking));
@@ -598,7 +600,10 @@ extern "C" int roitr_engine_forward(void* h, const RoitrForwardIO* io, hipStream
             g_self[l] = A.get<int>((size_t)V.T[l] * K);
             ppf_self[l] = A.get<float>((size_t)V.T[l] * K * 4);
             if (A.fail) break;
-            if (grid[l]) CHK(roitr_knn_build_grid(NC, V.T[l], mcap, p[l], D.off[l], knn_ws[l], st));
+            if (grid[l]) {
+                CHK(roitr_knn_build_grid(NC, V.T[l], mcap, p[l], D.off[l], knn_ws[l], st));
+                order[l] = roitr_knn_sorted_points(NC, V.T[l], mcap, knn_ws[l]);
+            }
             CHK(roitr_knnquery_ex(NC, V.T[l], V.T[l], K + 1, p[l], p[l], D.off[l], D.off[l], nullptr, nullptr, g_self[l], ppf_self[l], nrm[l],
                                   nrm[l], grid[l] ? 1 : 0, mcap, knn_ws[l], st));
             CHK(tap(E, st, "group.self." + std::to_string(l + 1), g_self[l], sizeof(int) * (size_t)V.T[l] * K));
@@ -620,11 +625,11 @@ extern "C" int roitr_engine_forward(void* h, const RoitrForwardIO* io, hipStream
             float* b = A.get<float>((size_t)V.T[l] * pl);
             if (A.fail) break;
             const int n_in = l == 0 ? T1 : V.T[l - 1];
-            CHK(local_transformer(E, st, E.enc[l][0], n_in, xin, V.T[l], l == 0 ? nullptr : down[l], g_td[l], ppf_td[l], K, a));
+            CHK(local_transformer(E, st, E.enc[l][0], n_in, xin, V.T[l], l == 0 ? nullptr : down[l], g_td[l], ppf_td[l], K, a, order[l]));
             CHK(tap(E, st, "enc" + std::to_string(l + 1) + ".0", a, sizeof(float) * (size_t)V.T[l] * pl));
             float* cur = a; float* nxt = b;
             for (int bi = 1; bi < E.nblocks[l]; ++bi) {
-                CHK(block(E, st, E.enc[l][bi], V.T[l], cur, g_self[l], ppf_self[l], K, nxt));
+                CHK(block(E, st, E.enc[l][bi], V.T[l], cur, g_self[l], ppf_self[l], K, nxt, order[l]));
                 CHK(tap(E, st, "enc" + std::to_string(l + 1) + "." + std::to_string(bi), nxt, sizeof(float) * (size_t)V.T[l] * pl));
                 float* t = cur; cur = nxt; nxt = t;
             }
@@ -641,19 +646,12 @@ extern "C" int roitr_engine_forward(void* h, const RoitrForwardIO* io, hipStream
         const size_t mark = A.off;
         float* d_idx = A.get<float>(etot);
         float* a_idx = A.get<float>((size_t)etot * 3);
-        float* S = A.get<float>((size_t)etot * 3 * C4);
-        float* Pd = A.get<float>((size_t)etot * C4);
-        float* Pa = A.get<float>((size_t)etot * 3 * C4);
         float* Emb = A.get<float>((size_t)etot * C4);
         if (A.fail) { roitr_set_error("arena exhausted (geo embedding)", __FILE__, __LINE__); return ROITR_ERR_ARG; }
         CHK(roitr_geo_indices(T4, p[3], D.off[3], D.cloud_of_node, D.eoff, 0.2f, 15.0f, 3, V.nmax[3], d_idx, a_idx, st));
         CHK(tap(E, st, "geo.d_idx", d_idx, sizeof(float) * etot));
         CHK(tap(E, st, "geo.a_idx", a_idx, sizeof(float) * etot * 3));
-        CHK(roitr_sinusoid(etot, C4, d_idx, E.geo_div, S, st));
-        CHK(gemm(st, (int)etot, S, E.proj_d, Pd));
-        CHK(roitr_sinusoid(etot * 3, C4, a_idx, E.geo_div, S, st));
-        CHK(gemm(st, (int)(etot * 3), S, E.proj_a, Pa));
-        CHK(roitr_geo_combine(etot, C4, 3, Pd, Pa, Emb, st));
+        CHK(roitr_geo_embed(etot, C4, 3, d_idx, a_idx, E.geo_div, E.proj_d.w, E.proj_d.b, E.proj_a.w, E.proj_a.b, Emb, st));
         CHK(tap(E, st, "geo.emb", Emb, sizeof(float) * (size_t)etot * C4));
 
         float* fcur = A.get<float>((size_t)T4 * C4);
@@ -749,7 +747,7 @@ extern "C" int roitr_engine_forward(void* h, const RoitrForwardIO* io, hipStream
         CHK(gemm(st, T4, pl, pl, xe[3], pl, U.l1.w, 2 * pl, nullptr, y, pl));
         CHK(roitr_add_layernorm(T4, pl, y, um, D.cloud_of_node, U.l1n_w, U.l1n_b, nullptr, 1, 1e-5f, x0, st));
         CHK(tap(E, st, "dec4.0", x0, sizeof(float) * (size_t)T4 * pl));
-        CHK(block(E, st, E.dec[3], T4, x0, g_self[3], ppf_self[3], E.nsample[3], xd[3]));
+        CHK(block(E, st, E.dec[3], T4, x0, g_self[3], ppf_self[3], E.nsample[3], xd[3], order[3]));
         CHK(tap(E, st, "dec4.1", xd[3], sizeof(float) * (size_t)T4 * pl));
     }
     for (int l = 2; l >= 0; --l) {
@@ -776,7 +774,7 @@ extern "C" int roitr_engine_forward(void* h, const RoitrForwardIO* io, hipStream
                               grid[l + 1] ? 1 : 0, mcap_c, knn_ws[l + 1], st));
         CHK(roitr_interp3_add(Tl, pl, b1, i3, d3, a1, x0, st));
         CHK(tap(E, st, "dec" + std::to_string(l + 1) + ".0", x0, sizeof(float) * (size_t)Tl * pl));
-        CHK(block(E, st, E.dec[l], Tl, x0, g_self[l], ppf_self[l], E.nsample[l], xd[l]));
+        CHK(block(E, st, E.dec[l], Tl, x0, g_self[l], ppf_self[l], E.nsample[l], xd[l], order[l]));
         CHK(tap(E, st, "dec" + std::to_string(l + 1) + ".1", xd[l], sizeof(float) * (size_t)Tl * pl));
     }
 

@@ -21,35 +21,51 @@
 
 namespace {
 
+// K = neighbours per node (8 / 16), HV = H / 64 (channels per lane in phase 2).  Memory round trips per node are the
+// critical path (72 % of wave time was s_waitcnt in the first version), so everything that only depends on the node
+// id is requested up front (neighbour indices, q row, ppf), and everything that only depends on the neighbour
+// indices -- the key slices AND the value rows -- is requested together: two dependent round trips instead of four.
+template <int K, int HV>
 __global__ __launch_bounds__(256) void local_attn_kernel(RoitrLocalAttn a)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int node = blockIdx.x * 4 + wave;
-    const int H = a.H, K = a.K, NH = a.heads, c = H / NH;
+    // nodes are visited in the grid's cell order when one is given: consecutive waves then gather overlapping
+    // neighbour sets, so a k/v row is re-used from L2 instead of being fetched once per referencing node
+    const int slot = blockIdx.x * 4 + wave;
+    const bool valid = slot < a.M;  // whole-wave predicate (no early exit: block barriers below)
+    const int node = (a.node_order && valid) ? __float_as_int(reinterpret_cast<const float4*>(a.node_order)[slot].w) : (valid ? slot : 0);
+    constexpr int H = 64 * HV;
+    const int NH = a.heads, c = H / NH;
     float* qs = smem + (size_t)wave * (H + 5 * NH + 64 + 4 * NH + 64);  // q row | qp | probs | pbar | ppf
     float* qp = qs + H;
     float* pr = qp + 5 * NH;
     float* pb = pr + 64;
     float* pf = pb + 4 * NH;
-    const bool valid = node < a.M;  // whole-wave predicate (no early exit: block barriers below)
 
-    const float* qrow = a.q + (size_t)(valid ? node : 0) * a.ldq;
-    for (int i = lane; i < H + 5 * NH; i += 64) qs[i] = valid ? qrow[i] : 0.f;
-    if (lane < K && valid) {
+    // ---- round trip 1: everything addressed by the node id
+    const int h = lane / K, k = lane % K;
+    const bool act = valid && lane < NH * K;
+    const int g = a.group_idx[(size_t)node * K + k];
+    const float* qrow = a.q + (size_t)node * a.ldq;
+    for (int i = lane; i < H + 5 * NH; i += 64) qs[i] = qrow[i];
+    if (lane < K) {
         const float4 f = reinterpret_cast<const float4*>(a.ppf)[(size_t)node * K + lane];
         pf[lane * 4 + 0] = f.x; pf[lane * 4 + 1] = f.y; pf[lane * 4 + 2] = f.z; pf[lane * 4 + 3] = f.w;
     }
+    // ---- round trip 2: value rows (lane = channel) and key slices (lane = head, neighbour), all in flight together
+    float vr[K][HV];
+#pragma unroll
+    for (int kk = 0; kk < K; ++kk) {
+        const int gk = __builtin_amdgcn_readlane(g, kk);  // lane kk (head 0) holds neighbour kk
+        const float* vrow = a.v + (size_t)gk * a.ldv + lane;
+#pragma unroll
+        for (int i = 0; i < HV; ++i) vr[kk][i] = vrow[64 * i];
+    }
+    const float* krow = a.k + (size_t)g * a.ldk + (act ? h : 0) * c;
     __syncthreads();
-
-    // ---- phase 1: lane = h*K + k
-    const int h = lane / K, k = lane % K;
-    const bool act = valid && lane < NH * K;
     float score = -INFINITY;
-    int g = 0;
     if (act) {
-        g = a.group_idx[(size_t)node * K + k];
-        const float* krow = a.k + (size_t)g * a.ldk + h * c;
         const float* qh = qs + h * c;
         float dot = 0.f;
         for (int i = 0; i < c; i += 4) {
@@ -61,16 +77,18 @@ __global__ __launch_bounds__(256) void local_attn_kernel(RoitrLocalAttn a)
         const float sp = qph[0] * pf[k * 4] + qph[1] * pf[k * 4 + 1] + qph[2] * pf[k * 4 + 2] + qph[3] * pf[k * 4 + 3] + qph[4];
         score = (dot + sp) * a.scale;
     }
-    // softmax over k inside each K-lane group (K is a power of two: 8 or 16)
+    // softmax over k inside each K-lane group
     float mx = score;
+#pragma unroll
     for (int o = 1; o < K; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
     const float e = act ? expf(score - mx) : 0.f;  // accurate exp: the reference softmax is libm-exact
     float sum = e;
+#pragma unroll
     for (int o = 1; o < K; o <<= 1) sum += __shfl_xor(sum, o, 64);
     const float p = act ? e / sum : 0.f;
     // pbar[h][j] = sum_k p * ppf[k][j]
-    float b0 = p * pf[(act ? k : 0) * 4 + 0], b1 = p * pf[(act ? k : 0) * 4 + 1], b2 = p * pf[(act ? k : 0) * 4 + 2],
-          b3 = p * pf[(act ? k : 0) * 4 + 3];
+    float b0 = p * pf[k * 4 + 0], b1 = p * pf[k * 4 + 1], b2 = p * pf[k * 4 + 2], b3 = p * pf[k * 4 + 3];
+#pragma unroll
     for (int o = 1; o < K; o <<= 1) {
         b0 += __shfl_xor(b0, o, 64); b1 += __shfl_xor(b1, o, 64); b2 += __shfl_xor(b2, o, 64); b3 += __shfl_xor(b3, o, 64);
     }
@@ -78,18 +96,17 @@ __global__ __launch_bounds__(256) void local_attn_kernel(RoitrLocalAttn a)
         pr[lane] = p;
         if (k == 0) { pb[h * 4 + 0] = b0; pb[h * 4 + 1] = b1; pb[h * 4 + 2] = b2; pb[h * 4 + 3] = b3; }
     }
-    // neighbour indices for phase 2, one per lane k < K
-    int* gi = reinterpret_cast<int*>(pf);  // ppf no longer needed after pbar: reuse
-    __syncthreads();
-    if (act && h == 0) gi[k] = g;
     __syncthreads();
     if (!valid) return;
 
-    // ---- phase 2: lane = channel
-    for (int ch = lane; ch < H; ch += 64) {
+    // ---- phase 2: lane = channel, value rows already in registers
+#pragma unroll
+    for (int i = 0; i < HV; ++i) {
+        const int ch = lane + 64 * i;
         const int hh = ch / c;
         float acc = 0.f;
-        for (int kk = 0; kk < K; ++kk) acc += pr[hh * K + kk] * a.v[(size_t)gi[kk] * a.ldv + ch];
+#pragma unroll
+        for (int kk = 0; kk < K; ++kk) acc += pr[hh * K + kk] * vr[kk][i];
         const float4 w = reinterpret_cast<const float4*>(a.wvpe)[ch];
         acc += w.x * pb[hh * 4] + w.y * pb[hh * 4 + 1] + w.z * pb[hh * 4 + 2] + w.w * pb[hh * 4 + 3] + a.bvpe[ch];
         a.out[(size_t)node * a.ldo + ch] = acc;
@@ -121,7 +138,12 @@ extern "C" int roitr_local_attention(const RoitrLocalAttn* a, hipStream_t stream
     if (per_wave % 4) return ROITR_ERR_UNSUPPORTED;  // keeps every wave's q row 16-byte aligned
     // algorithmic bytes: q row + K gathered k and v rows + ppf + idx in, one row out
     roitr_prof_begin(ROITR_PROF_LOCAL_ATTN, (double)a->M * ((a->H + 20.0) * 4 + a->K * (2.0 * a->H * 4 + 20.0) + a->H * 4.0), stream);
-    local_attn_kernel<<<div_up(a->M, 4), 256, lds, stream>>>(*a);
+    const int hv = a->H / 64;
+    if (a->H % 64 || (a->K != 8 && a->K != 16) || (hv != 1 && hv != 2 && hv != 4 && hv != 8)) return ROITR_ERR_UNSUPPORTED;
+#define LA_CASE(KK, HH) local_attn_kernel<KK, HH><<<div_up(a->M, 4), 256, lds, stream>>>(*a)
+    if (a->K == 8) { if (hv == 1) LA_CASE(8, 1); else if (hv == 2) LA_CASE(8, 2); else if (hv == 4) LA_CASE(8, 4); else LA_CASE(8, 8); }
+    else { if (hv == 1) LA_CASE(16, 1); else if (hv == 2) LA_CASE(16, 2); else if (hv == 4) LA_CASE(16, 4); else LA_CASE(16, 8); }
+#undef LA_CASE
     roitr_prof_end(ROITR_PROF_LOCAL_ATTN, stream);
     ROITR_LAUNCH_CHECK();
     return ROITR_OK;

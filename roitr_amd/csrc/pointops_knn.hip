@@ -724,6 +724,11 @@ extern "C" int roitr_knn_build_grid_ex(int b, int n, int m_capacity, const float
     return ROITR_OK;
 }
 
+extern "C" const void* roitr_knn_sorted_points(int b, int n, int m_capacity, void* ws)
+{
+    return carve(ws, b, n, m_capacity).sorted;
+}
+
 // The general entry point.  use_grid != 0 requires a prior roitr_knn_build_grid on the same ws.
 // Outputs idx / dist2 / group_idx / ppf are each optional (null = not wanted).
 extern "C" int roitr_knnquery_ex(int b, int n, int m, int nsample, const float* xyz, const float* new_xyz, const int* offset,
