@@ -147,7 +147,7 @@ def roofline(prof, B, N):
     launches = max(p["launches"], 1)
     avg_ms = p["ms"] / launches
     per_launch = p["bytes"] / launches
-    if name == "gemm_kernel":
+    if name in ("gemm_kernel", "geo_embed_kernel"):
         achieved = p["bytes"] / (p["ms"] * 1e-3) / 1e12 if p["ms"] > 0 else 0.0
         return {"bound": "mfma", "kernel": name, "achieved": round(achieved, 3), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 5), "traffic": None, "avg_launch_ms": round(avg_ms, 5),

@@ -174,93 +174,6 @@ __global__ __launch_bounds__(256) void gemm_kernel(RoitrGemm g)
 }
 
 
-// ---------------------------------------------------------------------------------------------------------------
-// Fused GeometricStructureEmbedding.forward (positional_encoding.py:139-154):
-//     E[r, :] = proj_d(sinusoid(d_idx[r])) + max_k proj_a(sinusoid(a_idx[r, k]))          r = (cloud, i, j) pair row
-// as ONE kernel.  The sinusoidal embedding (l.38-62: [sin(v*w_0), cos(v*w_0), sin(v*w_1), ...]) is generated straight
-// into the MFMA A-operand LDS image by the staging threads -- it never exists in HBM -- and the four projections of
-// a 64-row tile (distance, three angles) run back to back on the same accumulator registers with the max / add folded
-// into the epilogue.  Replaces 2 sinusoid launches + 2 GEMMs + 1 combine launch and 7 (rows x C) fp32 intermediates.
-// Same k-ordered fma chains as gemm_kernel: results are bitwise those of the unfused sequence.
-__global__ __launch_bounds__(256) void geo_embed_kernel(long rows, int C, int angle_k, const float* __restrict__ d_idx,
-                                                        const float* __restrict__ a_idx, const float* __restrict__ div_term,
-                                                        const float* __restrict__ Wd, const float* __restrict__ bd,
-                                                        const float* __restrict__ Wa, const float* __restrict__ ba, float* __restrict__ out)
-{
-    __shared__ __attribute__((aligned(16))) float As[2 * BM * LDR];
-    __shared__ __attribute__((aligned(16))) float Bs[2 * BN * LDR];
-    __shared__ float divs[512];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const long m0 = (long)blockIdx.y * BM;
-    const int n0 = blockIdx.x * BN;
-    const int r = tid >> 2, kq = (tid & 3) * 8;
-    for (int i = tid; i < C / 2; i += 256) divs[i] = div_term[i];
-    const long arow = m0 + r;
-    const bool arow_ok = arow < rows;
-    const int kh = lane >> 5, ml = lane & 31;
-    const float4* ar = reinterpret_cast<const float4*>(As + (kh * BM + wm * 32 + ml) * LDR);
-    const float4* br = reinterpret_cast<const float4*>(Bs + (kh * BN + wn * 32 + ml) * LDR);
-    float4* aw0 = reinterpret_cast<float4*>(As + (0 * BM + r) * LDR + (kq >> 1));
-    float4* aw1 = reinterpret_cast<float4*>(As + (1 * BM + r) * LDR + (kq >> 1));
-    float4* bw0 = reinterpret_cast<float4*>(Bs + (0 * BN + r) * LDR + (kq >> 1));
-    float4* bw1 = reinterpret_cast<float4*>(Bs + (1 * BN + r) * LDR + (kq >> 1));
-    f32x16 res, amax;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) { res[i] = 0.f; amax[i] = 0.f; }
-    __syncthreads();
-    for (int pass = 0; pass <= angle_k; ++pass) {
-        const float* W = pass == 0 ? Wd : Wa;
-        const float* wrow = (n0 + r < C) ? W + (size_t)(n0 + r) * C : g_zero_row;
-        float val = 0.f;
-        if (arow_ok) val = pass == 0 ? d_idx[arow] : a_idx[arow * angle_k + (pass - 1)];
-        f32x16 acc;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-        float4 w0 = *reinterpret_cast<const float4*>(wrow + kq), w1 = *reinterpret_cast<const float4*>(wrow + kq + 4);
-        for (int k0 = 0; k0 < C; k0 += BK) {
-            // this thread's 8 consecutive k of the embedding row: 4 (sin, cos) pairs at frequencies (k0+kq)/2 ..
-            float sn[4], cs[4];
-            const int f0 = (k0 + kq) >> 1;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) { const float om = val * divs[f0 + i]; sn[i] = sinf(om); cs[i] = cosf(om); }
-            __syncthreads();
-            *aw0 = make_float4(sn[0], sn[1], sn[2], sn[3]);   // even k: sin
-            *aw1 = make_float4(cs[0], cs[1], cs[2], cs[3]);   // odd k: cos
-            *bw0 = make_float4(w0.x, w0.z, w1.x, w1.z); *bw1 = make_float4(w0.y, w0.w, w1.y, w1.w);
-            __syncthreads();
-            if (k0 + BK < C) { w0 = *reinterpret_cast<const float4*>(wrow + k0 + BK + kq); w1 = *reinterpret_cast<const float4*>(wrow + k0 + BK + kq + 4); }
-            float4 af[4], bf[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) { af[i] = ar[i]; bf[i] = br[i]; }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[i].x, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[i].y, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[i].z, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[i].w, acc, 0, 0, 0);
-            }
-        }
-        if (pass == 0) res = acc;
-        else if (pass == 1) amax = acc;
-        else {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) amax[i] = fmaxf(amax[i], acc[i]);
-        }
-    }
-    const int col = n0 + wn * 32 + (lane & 31);
-    if (col < C) {
-        const float bdv = bd[col], bav = ba[col];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const long row = m0 + wm * 32 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
-            // (acc_d + bd) + (max_k acc_k + ba): the association of the unfused path (bias in each GEMM epilogue,
-            // then max, then add); max_k(acc_k + ba) == max_k(acc_k) + ba exactly (rounding is monotone)
-            if (row < rows) out[(size_t)row * C + col] = (res[i] + bdv) + (amax[i] + bav);
-        }
-    }
-}
-
 }  // namespace
 
 extern "C" int roitr_gemm(const RoitrGemm* g, hipStream_t stream)
@@ -282,18 +195,3 @@ extern "C" int roitr_gemm(const RoitrGemm* g, hipStream_t stream)
     return ROITR_OK;
 }
 
-
-// d_idx (rows), a_idx (rows, angle_k), div_term (C/2), proj_d / proj_a weights (C,C) + biases, out (rows, C)
-extern "C" int roitr_geo_embed(long rows, int C, int angle_k, const float* d_idx, const float* a_idx, const float* div_term,
-                               const float* Wd, const float* bd, const float* Wa, const float* ba, float* out, hipStream_t stream)
-{
-    if (rows <= 0) return ROITR_OK;
-    if (C % BK || C > 1024 || angle_k < 1) return ROITR_ERR_UNSUPPORTED;
-    const long mt = (rows + BM - 1) / BM;
-    if (mt > 0x7fffffffL) return ROITR_ERR_UNSUPPORTED;
-    roitr_prof_begin(ROITR_PROF_GEMM, 2.0 * rows * (1.0 + angle_k) * (double)C * C, stream);
-    geo_embed_kernel<<<dim3(div_up(C, BN), (unsigned)mt), 256, 0, stream>>>(rows, C, angle_k, d_idx, a_idx, div_term, Wd, bd, Wa, ba, out);
-    roitr_prof_end(ROITR_PROF_GEMM, stream);
-    ROITR_LAUNCH_CHECK();
-    return ROITR_OK;
-}

@@ -1,0 +1,183 @@
+// Fused GeometricStructureEmbedding.forward (reference model/transformer/positional_encoding.py:139-154):
+//
+//     E[r, :] = proj_d(sinusoid(d_idx[r])) + max_k proj_a(sinusoid(a_idx[r, k]))          r = (cloud, i, j) pair row
+//
+// as ONE kernel.  The sinusoidal embedding (l.38-62: [sin(v w_0), cos(v w_0), sin(v w_1), ...]) is generated straight
+// into the MFMA A-operand LDS image by the staging threads -- it never exists in HBM -- and the four projections of a
+// 64-row tile (three angles, then the distance) run back to back on the same accumulator registers, with the max / add
+// folded into the epilogue.  Replaces 2 sinusoid launches + 2 GEMMs + 1 combine launch and 7 (rows x C) fp32
+// intermediates of the unfused sequence.
+//
+// Tile: 64 rows x (128 NJ) columns, 4 waves side by side along N, each 64 x (32 NJ) = 2 x NJ accumulators of
+// v_mfma_f32_32x32x2_f32 (exact fp32 fma chains in k order, like gemm_kernel).  NJ = 1 is the default (occupancy beats
+// the halved sin/cos work of NJ = 2, see the launcher).  The sin/cos of the NEXT k-slab are evaluated in
+// the same basic block as the current slab's MFMAs (branch-free Cody-Waite + minimax polynomials), so the VALU work
+// hides under the matrix pipe.
+#include "common.h"
+#include "prof.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int BM = 64, BK = 32, LDR = 20;  // same [kh][row][kk] LDS image as gemm.hip
+
+// sin and cos of x, branch-free.  Three-term Cody-Waite reduction by pi/2 (exact products through fma; good to
+// |x| ~ 1e5, far beyond d/sigma_d or angle/sigma_a of any scene) and the classic single-precision minimax polynomials
+// on [-pi/4, pi/4]; within ~1 ulp of libm's sinf / cosf.
+__device__ __forceinline__ void sincos_cw(float x, float& sn, float& cs)
+{
+    const float k = rintf(x * 0.63661977236758134f);
+    float r = fmaf(-k, 1.57079637050628662109375f, x);
+    r = fmaf(-k, -4.37113900018624283e-8f, r);
+    r = fmaf(-k, -1.71512449944201e-15f, r);
+    const float z = r * r;
+    float ps = fmaf(fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f);
+    ps = fmaf(ps * z, r, r);
+    float pc = fmaf(fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f);
+    pc = fmaf(pc * z, z, fmaf(-0.5f, z, 1.0f));
+    const int q = (int)k;
+    const float s1 = (q & 1) ? pc : ps, c1 = (q & 1) ? ps : pc;
+    sn = (q & 2) ? -s1 : s1;
+    cs = ((q + 1) & 2) ? -c1 : c1;
+}
+
+template <int NJ>
+__global__ __launch_bounds__(256) void geo_embed_kernel(long rows, int C, int angle_k, const float* __restrict__ d_idx,
+                                                        const float* __restrict__ a_idx, const float* __restrict__ div_term,
+                                                        const float* __restrict__ Wd, const float* __restrict__ bd,
+                                                        const float* __restrict__ Wa, const float* __restrict__ ba, float* __restrict__ out)
+{
+    constexpr int BNW = 128 * NJ;     // block tile width
+    constexpr int NB = 2 * NJ;        // weight rows staged per thread
+    __shared__ __attribute__((aligned(16))) float As[2 * BM * LDR];
+    __shared__ __attribute__((aligned(16))) float Bs[2 * BNW * LDR];
+    __shared__ float divs[512];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long m0 = (long)blockIdx.y * BM;
+    const int n0 = blockIdx.x * BNW;
+    const int r = tid >> 2, kq = (tid & 3) * 8;
+    for (int i = tid; i < C / 2; i += 256) divs[i] = div_term[i];
+    const long arow = m0 + r;
+    const bool arow_ok = arow < rows;
+    const int kh = lane >> 5, ml = lane & 31;
+    const float4* ar = reinterpret_cast<const float4*>(As + (kh * BM + ml) * LDR);
+    const float4* br = reinterpret_cast<const float4*>(Bs + (kh * BNW + wave * 32 * NJ + ml) * LDR);
+    float4* aw0 = reinterpret_cast<float4*>(As + (0 * BM + r) * LDR + (kq >> 1));
+    float4* aw1 = reinterpret_cast<float4*>(As + (1 * BM + r) * LDR + (kq >> 1));
+    float4* bw0 = reinterpret_cast<float4*>(Bs + (0 * BNW + r) * LDR + (kq >> 1));
+    float4* bw1 = reinterpret_cast<float4*>(Bs + (1 * BNW + r) * LDR + (kq >> 1));
+    f32x16 amax[2][NJ], acc[2][NJ];
+    __syncthreads();
+    // passes 0..angle_k-1: the angle embeddings (running max); last pass: the distance embedding
+    for (int pass = 0; pass <= angle_k; ++pass) {
+        const bool dist = pass == angle_k;
+        const float* wbase = (dist ? Wd : Wa) + (size_t)(n0 + r) * C + kq;
+        float val = 0.f;
+        if (arow_ok) val = dist ? d_idx[arow] : a_idx[arow * angle_k + pass];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+        float4 w0[NB], w1[NB];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            w0[b] = *reinterpret_cast<const float4*>(wbase + (size_t)b * 64 * C);
+            w1[b] = *reinterpret_cast<const float4*>(wbase + (size_t)b * 64 * C + 4);
+        }
+        float sn[4], cs[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) sincos_cw(val * divs[(kq >> 1) + i], sn[i], cs[i]);
+        for (int k0 = 0; k0 < C; k0 += BK) {
+            __syncthreads();
+            *aw0 = make_float4(sn[0], sn[1], sn[2], sn[3]);   // even k: sin
+            *aw1 = make_float4(cs[0], cs[1], cs[2], cs[3]);   // odd k: cos
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                bw0[b * 64 * LDR / 4] = make_float4(w0[b].x, w0[b].z, w1[b].x, w1[b].z);
+                bw1[b * 64 * LDR / 4] = make_float4(w0[b].y, w0[b].w, w1[b].y, w1[b].w);
+            }
+            __syncthreads();
+            const bool more = k0 + BK < C;
+            if (more) {
+#pragma unroll
+                for (int b = 0; b < NB; ++b) {
+                    w0[b] = *reinterpret_cast<const float4*>(wbase + (size_t)b * 64 * C + k0 + BK);
+                    w1[b] = *reinterpret_cast<const float4*>(wbase + (size_t)b * 64 * C + k0 + BK + 4);
+                }
+            }
+            float4 af[2][4], bf[NJ][4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) af[i][q] = ar[i * 32 * LDR / 4 + q];
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) bf[j][q] = br[j * 32 * LDR / 4 + q];
+            }
+            // next slab's embedding values: independent VALU work the scheduler can sink between the MFMAs
+            const int f0 = ((more ? k0 + BK : 0) + kq) >> 1;
+            float om[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) om[i] = val * divs[f0 + i];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][q].x, bf[j][q].x, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][q].y, bf[j][q].y, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][q].z, bf[j][q].z, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][q].w, bf[j][q].w, acc[i][j], 0, 0, 0);
+                    }
+                sincos_cw(om[q], sn[q], cs[q]);
+            }
+        }
+        if (!dist) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) amax[i][j][e] = pass == 0 ? acc[i][j][e] : fmaxf(amax[i][j][e], acc[i][j][e]);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int col = n0 + wave * 32 * NJ + j * 32 + (lane & 31);
+        const float bdv = bd[col], bav = ba[col];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const long row = m0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                // (acc_d + bd) + (max_k acc_k + ba): the association of the unfused path (bias in each projection, then
+                // max, then add); max_k(acc_k + ba) == max_k(acc_k) + ba exactly because rounding is monotone
+                if (row < rows) out[(size_t)row * C + col] = (acc[i][j][e] + bdv) + (amax[i][j][e] + bav);
+            }
+    }
+}
+
+}  // namespace
+
+// d_idx (rows), a_idx (rows, angle_k), div_term (C/2), proj_d / proj_a weights (C,C) + biases, out (rows, C)
+extern "C" int roitr_geo_embed(long rows, int C, int angle_k, const float* d_idx, const float* a_idx, const float* div_term,
+                               const float* Wd, const float* bd, const float* Wa, const float* ba, float* out, hipStream_t stream)
+{
+    if (rows <= 0) return ROITR_OK;
+    if (C % 128 || C > 1024 || angle_k < 1) return ROITR_ERR_UNSUPPORTED;
+    const long mt = (rows + BM - 1) / BM;
+    if (mt > 0x7fffffffL) return ROITR_ERR_UNSUPPORTED;
+    static const int nj_env = [] { const char* e = getenv("ROITR_GEO_NJ"); return e ? atoi(e) : 0; }();
+    // measured (B=32, N=5000, C=256): NJ=1 1.90 ms (156 VGPRs, 3 blocks/CU), NJ=2 2.27 ms (284 VGPRs, 1 block/CU)
+    const int nj = (C % 256 == 0 && nj_env == 2) ? 2 : 1;
+    roitr_prof_begin(ROITR_PROF_GEO_EMBED, 2.0 * rows * (1.0 + angle_k) * (double)C * C, stream);
+    if (nj == 2)
+        geo_embed_kernel<2><<<dim3(C / 256, (unsigned)mt), 256, 0, stream>>>(rows, C, angle_k, d_idx, a_idx, div_term, Wd, bd, Wa, ba, out);
+    else
+        geo_embed_kernel<1><<<dim3(C / 128, (unsigned)mt), 256, 0, stream>>>(rows, C, angle_k, d_idx, a_idx, div_term, Wd, bd, Wa, ba, out);
+    roitr_prof_end(ROITR_PROF_GEO_EMBED, stream);
+    ROITR_LAUNCH_CHECK();
+    return ROITR_OK;
+}

@@ -18,7 +18,8 @@ enum {
     ROITR_PROF_OT = 10,        // ot_kernel
     ROITR_PROF_LOCAL_ATTN = 11,// local_attn_kernel
     ROITR_PROF_GEMM = 12,      // gemm_kernel: the "bytes" field carries FLOPs (2*M*N*K*batch)
-    ROITR_PROF_MHA = 13        // mha_kernel
+    ROITR_PROF_MHA = 13,       // mha_kernel
+    ROITR_PROF_GEO_EMBED = 14  // geo_embed_kernel: "bytes" carries FLOPs
 };
 
 void roitr_prof_begin(int cls, double bytes, hipStream_t st);
