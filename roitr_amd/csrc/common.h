@@ -39,18 +39,32 @@ __device__ __forceinline__ float sqdist3(float ax, float ay, float az, float bx,
     return __fmaf_rn(dz, dz, __fmaf_rn(dy, dy, __fmul_rn(dx, dx)));
 }
 
+// Wave-wide reductions on the DPP cross-lane path (no LDS traffic, unlike ds_bpermute-backed __shfl_xor for the 16/32
+// strides): row_shr 1/2/4/8 build the 16-lane row result in lane 15 of each row, row_bcast:15 / row_bcast:31 fold the
+// four rows, lane 63 holds the wave result and v_readlane broadcasts it.  Lanes without a source read `old`
+// (bound_ctrl = 0): the identity for the sum, the lane's own value for the idempotent max.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_add_f32(float v)
+{
+    return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_max_f32(float v)
+{
+    const int i = __float_as_int(v);
+    return fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(i, i, CTRL, ROW_MASK, 0xf, false)));
+}
 __device__ __forceinline__ float wave_sum(float v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v = dpp_add_f32<0x111, 0xf>(v); v = dpp_add_f32<0x112, 0xf>(v); v = dpp_add_f32<0x114, 0xf>(v); v = dpp_add_f32<0x118, 0xf>(v);
+    v = dpp_add_f32<0x142, 0xa>(v); v = dpp_add_f32<0x143, 0xc>(v);
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
-
 __device__ __forceinline__ float wave_max(float v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
+    v = dpp_max_f32<0x111, 0xf>(v); v = dpp_max_f32<0x112, 0xf>(v); v = dpp_max_f32<0x114, 0xf>(v); v = dpp_max_f32<0x118, 0xf>(v);
+    v = dpp_max_f32<0x142, 0xa>(v); v = dpp_max_f32<0x143, 0xc>(v);
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
 __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v)

@@ -18,6 +18,10 @@
 // padded patches are built, RIGA_v2.py:129-142) and an elementwise addend on A (x + pos of the
 // cross-attention, geoattention.py:44-45) are fused into the staging loads.
 #include "common.h"
+#include <cstdio>
+#include <cstdlib>
+#include <map>
+#include <string>
 #include "prof.h"
 #include "roitr_engine.h"
 
@@ -176,6 +180,25 @@ __global__ __launch_bounds__(256) void gemm_kernel(RoitrGemm g)
 
 }  // namespace
 
+namespace {
+struct ShapeStat { double ms = 0; long n = 0; };
+struct ShapeLog {
+    std::map<std::string, ShapeStat> m;
+    ~ShapeLog() {
+        for (auto& kv : m) fprintf(stderr, "GEMMSHAPE %s launches %ld ms %.4f\n", kv.first.c_str(), kv.second.n, kv.second.ms);
+    }
+};
+void shape_log(const RoitrGemm* g, bool fast, float ms)
+{
+    static ShapeLog log;
+    char key[160];
+    snprintf(key, sizeof key, "M %d N %d K %d batch %d gather %d a2 %d relu %d seg %d fast %d", g->M, g->N, g->K, g->batch, g->a_idx != nullptr,
+             g->A2 != nullptr, g->relu, g->seg_off != nullptr, (int)fast);
+    auto& st = log.m[key];
+    st.ms += ms; st.n += 1;
+}
+}  // namespace
+
 extern "C" int roitr_gemm(const RoitrGemm* g, hipStream_t stream)
 {
     if (g->M <= 0 || g->N <= 0 || g->batch <= 0) return ROITR_OK;
@@ -188,8 +211,16 @@ extern "C" int roitr_gemm(const RoitrGemm* g, hipStream_t stream)
     // Measured and dropped (A/B on the 32-pair bench): a 128x128 / 128x64 multi-accumulator tile (7.6 vs 7.4 ms of GEMM
     // per forward) and two K-slabs per barrier pair (7.9 vs 7.5 ms): these launches are bounded by HBM writes at
     // level 1 and by short K, not by the LDS->MFMA feed or the prefetch round trip.
+    static const bool shapes = getenv("ROITR_GEMM_SHAPES") != nullptr;  // debug: per-shape timing table at exit (synchronous)
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (shapes) { hipEventCreate(&e0); hipEventCreate(&e1); hipEventRecord(e0, stream); }
     if (fast) gemm_kernel<true><<<grid, 256, 0, stream>>>(*g);
     else gemm_kernel<false><<<grid, 256, 0, stream>>>(*g);
+    if (shapes) {
+        hipEventRecord(e1, stream); hipEventSynchronize(e1);
+        float ms = 0; hipEventElapsedTime(&ms, e0, e1); hipEventDestroy(e0); hipEventDestroy(e1);
+        shape_log(g, fast, ms);
+    }
     roitr_prof_end(ROITR_PROF_GEMM, stream);
     ROITR_LAUNCH_CHECK();
     return ROITR_OK;

@@ -466,40 +466,62 @@ __global__ __launch_bounds__(320) void ot_kernel(RoitrOT a)
 
 // ------------------------------------------------------------------ FineMatching (modules.py:216-324)
 // one block per patch: mutual top-k on exp(score) (dustbin dropped, RIGA_v2.py:159-160), threshold, masks
+// One wave owns a row (lane = column) and then a column (lane = row): the k best are peeled off with k wave maxima
+// (value descending, lower index first among equals -- the rank order the element-wise count would give), the winners
+// recorded as one 64-bit mask per row / column; the flag of (i, j) is then two bit tests.
+__device__ __forceinline__ unsigned long long topk_mask(float v, int k, float conf)
+{
+    const int lane = threadIdx.x & 63;
+    bool sel = false;
+    for (int t = 0; t < k; ++t) {
+        const float cand = sel ? -1.f : v;   // scores are exp(.) >= 0
+        const float m = wave_max(cand);
+        const unsigned long long eq = __ballot(cand == m);
+        if (m >= 0.f && lane == __ffsll((long long)eq) - 1) sel = true;
+    }
+    return __ballot(sel && v > conf);
+}
+
 __global__ __launch_bounds__(256) void fine_flag_kernel(RoitrFine a)
 {
     __shared__ float E[64][65];
+    __shared__ unsigned long long rowm[64], colm[64];
     __shared__ int cnt_s[4];
     const int patch = blockIdx.x;
     const int pair = patch / a.num_corr, p = patch % a.num_corr;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int L = a.limit;
+    const int L = a.limit;   // == 64 (checked by the launcher)
     unsigned char* fl = a.flags + (size_t)patch * L * L;
+    uint4* fl16 = reinterpret_cast<uint4*>(fl) + tid;   // thread -> row tid/4, 16 columns from (tid%4)*16
     if (p >= a.n_corr[pair]) {
-        for (int e = tid; e < L * L; e += 256) fl[e] = 0;
+        *fl16 = make_uint4(0, 0, 0, 0);
         if (tid == 0) a.counts[patch] = 0;
         return;
     }
     const float* sc = a.ot + (size_t)patch * (L + 1) * (L + 1);
-    for (int e = tid; e < L * L; e += 256) { const int i = e / L, j = e % L; E[i][j] = expf(sc[i * (L + 1) + j]); }
+    for (int e = tid; e < L * L; e += 256) { const int i = e >> 6, j = e & 63; E[i][j] = expf(sc[i * (L + 1) + j]); }
     __syncthreads();
-    const int* rm = a.row_masks + (size_t)patch * L;
+    for (int r = wave; r < 64; r += 4) {
+        const unsigned long long mr = topk_mask(E[r][lane], a.k, a.conf);
+        const unsigned long long mc = topk_mask(E[lane][r], a.k, a.conf);
+        if (lane == 0) { rowm[r] = mr; colm[r] = mc; }
+    }
+    __syncthreads();
+    const int i = tid >> 2, j0 = (tid & 3) * 16;
     const int* cm = a.col_masks + (size_t)patch * L;
+    const bool row_ok = a.row_masks[(size_t)patch * L + i] != 0;
+    const unsigned long long rmask = rowm[i];
+    unsigned w[4] = {0, 0, 0, 0};
     int local = 0;
-    for (int e = tid; e < L * L; e += 256) {
-        const int i = e / L, j = e % L;
-        const float v = E[i][j];
-        int rr = 0, rc = 0;  // how many in my row / column beat me (value desc, index asc)
-        for (int t = 0; t < L; ++t) {
-            const float x = E[i][t]; rr += (x > v || (x == v && t < j)) ? 1 : 0;
-            const float y = E[t][j]; rc += (y > v || (y == v && t < i)) ? 1 : 0;
-        }
-        const bool rtop = rr < a.k && v > a.conf, ctop = rc < a.k && v > a.conf;
-        bool f = a.mutual ? (rtop && ctop) : (rtop || ctop);
-        f = f && rm[i] && cm[j];
-        fl[e] = f ? 1 : 0;
+#pragma unroll
+    for (int jj = 0; jj < 16; ++jj) {
+        const int j = j0 + jj;
+        const bool rt = (rmask >> j) & 1, ct = (colm[j] >> i) & 1;
+        const bool f = (a.mutual ? (rt && ct) : (rt || ct)) && row_ok && cm[j] != 0;
+        w[jj >> 2] |= (f ? 1u : 0u) << (8 * (jj & 3));
         local += f ? 1 : 0;
     }
+    *fl16 = make_uint4(w[0], w[1], w[2], w[3]);
     local = (int)wave_sum((float)local);
     if (lane == 0) cnt_s[wave] = local;
     __syncthreads();
