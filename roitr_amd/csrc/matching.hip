@@ -4,6 +4,8 @@
 //
 // All kernels are batched over `pairs`: clouds are laid out [src_0..src_{B-1}, tgt_0..tgt_{B-1}].
 #include "common.h"
+#include <cstdio>
+#include <cstdlib>
 #include "prof.h"
 #include "roitr_engine.h"
 
@@ -374,94 +376,102 @@ __global__ void patch_gather_kernel(RoitrPatch a)
 }
 
 // ------------------------------------------------------------------ LearnableLogOptimalTransport (modules.py:10-72)
-// One block (320 threads) per patch; rows/cols = limit+1 = 65.  The log-domain Sinkhorn of the reference
+// One WAVE per patch; rows/cols = limit+1 = 65 (64 points + dustbin).  The log-domain Sinkhorn of the reference
 //   u = log_mu - logsumexp_j(S + v),  v = log_nu - logsumexp_i(S + u)      (100 iterations)
 // is run in the exponential domain with per-row max shifts: K'_ij = exp(S_ij - m_i), b = e^v,
-// a~_i = mu_i / (K' b)_i (= e^{u_i + m_i}), b_j = nu_j / (K'^T a~)_j -- the same iteration, no exp/log inside
-// the loop.  Each thread keeps its 17-element strip of a row AND of a column of K' in registers; only the
-// two 65-vectors go through LDS.  Masked rows/cols carry mu = 0 / K' = 0 exactly (the reference's -1e6
-// entries underflow to 0 in its logsumexp as well).
-constexpr int OTN = 65, OTQ = 4, OTE = 17;
-__global__ __launch_bounds__(320) void ot_kernel(RoitrOT a)
+// a~_i = mu_i / (K' b)_i (= e^{u_i + m_i}), b_j = nu_j / (K'^T a~)_j -- the same iteration, no exp/log inside the loop.
+// Lane l keeps row l AND column l of the 64x64 block of K' in registers (128 VGPRs); the dustbin row/column are one
+// value per lane.  An iteration is two 64-term register dot products per lane against a vector broadcast out of LDS
+// (ds_read_b128, all lanes the same address) plus two DPP wave sums for the dustbin: no block barrier, no shuffles.
+// Masked rows/cols carry mu = 0 / K' = 0 exactly (the reference's -1e6 entries underflow to 0 in its logsumexp too).
+// The loop stops early only when b reproduced itself bit for bit (then every later iterate is identical).
+constexpr int OTN = 65;
+__global__ __launch_bounds__(64) void ot_kernel(RoitrOT a, unsigned long long* stats)
 {
-    __shared__ float S[OTN][OTN + 1];
-    __shared__ float av[OTN + 3], bv[OTN + 3], mrow[OTN + 3];
-    __shared__ int rmask[OTN], cmask[OTN];
+    __shared__ float T[64][65];
+    __shared__ __attribute__((aligned(16))) float av[64], bv[64];
     const int patch = blockIdx.x;
     const int pair = patch / a.num_corr, p = patch % a.num_corr;
-    const int tid = threadIdx.x;
-    const int L = a.limit;  // 64
-    float* out = a.out + (size_t)patch * OTN * OTN;
+    const int lane = threadIdx.x;
     if (p >= a.n_corr[pair]) return;
+    float* out = a.out + (size_t)patch * OTN * OTN;
     const float alpha = *a.alpha;
-    const float* sc = a.scores + (size_t)patch * L * L;
-    const int* rm = a.row_masks + (size_t)patch * L;
-    const int* cm = a.col_masks + (size_t)patch * L;
-    for (int i = tid; i < OTN; i += 320) { rmask[i] = i < L ? rm[i] : 1; cmask[i] = i < L ? cm[i] : 1; }
-    __syncthreads();
-    for (int e = tid; e < OTN * OTN; e += 320) {
-        const int i = e / OTN, j = e % OTN;
-        float v = (i < L && j < L) ? sc[i * L + j] : alpha;
-        if (!rmask[i] || !cmask[j]) v = -1e6f;
-        S[i][j] = v;
-    }
-    int nvr = 0, nvc = 0;
-    for (int i = 0; i < L; ++i) { nvr += rmask[i] ? 1 : 0; nvc += cmask[i] ? 1 : 0; }
+    const float* sc = a.scores + (size_t)patch * 64 * 64;
+    const bool rml = a.row_masks[(size_t)patch * 64 + lane] != 0, cml = a.col_masks[(size_t)patch * 64 + lane] != 0;
+    const unsigned long long rbits = __ballot(rml), cbits = __ballot(cml);
+    const int nvr = __popcll(rbits), nvc = __popcll(cbits);
     const float norm = -logf((float)nvr + (float)nvc);
+    // column view (coalesced): lane = column l
+#pragma unroll 8
+    for (int i = 0; i < 64; ++i) T[i][lane] = sc[i * 64 + lane];
     __syncthreads();
-    const int i = tid >> 2, q = tid & 3;
-    const bool act = tid < OTN * OTQ;
-    // row maxima
-    if (act) {
-        float m = -INFINITY;
-        for (int e = 0; e < OTE; ++e) { const int j = q * OTE + e; if (j < OTN) m = fmaxf(m, S[i][j]); }
-        m = fmaxf(m, __shfl_xor(m, 1, 64)); m = fmaxf(m, __shfl_xor(m, 2, 64));
-        if (q == 0) mrow[i] = m;
-    }
-    __syncthreads();
-    float kr[OTE], kc[OTE];  // my strip of row i of K', my strip of column i of K'
-    float mu = 0.f, nu = 0.f;
-    if (act) {
+    // row view: lane = row l.  m_l = row max over the 65 entries (masked entries are -1e6, the dustbin is alpha)
+    float KR[64], KC[64];
+    float m = rml ? alpha : -1e6f;
 #pragma unroll
-        for (int e = 0; e < OTE; ++e) {
-            const int j = q * OTE + e;
-            kr[e] = (j < OTN && rmask[i] && cmask[j]) ? expf(S[i][j] - mrow[i]) : 0.f;
-            kc[e] = (j < OTN && rmask[j] && cmask[i]) ? expf(S[j][i] - mrow[j]) : 0.f;  // column i, row j
-        }
-        // mu_i = exp(log_mu_i), nu likewise (modules.py:55-63)
-        mu = rmask[i] ? (i < L ? expf(norm) : expf(logf((float)nvc) + norm)) : 0.f;
-        nu = cmask[i] ? (i < L ? expf(norm) : expf(logf((float)nvr) + norm)) : 0.f;
-        if (q == 0) bv[i] = cmask[i] ? 1.0f : 0.f;  // v = 0
+    for (int j = 0; j < 64; ++j) {
+        const float v = (rml && ((cbits >> j) & 1)) ? T[lane][j] : -1e6f;
+        KR[j] = v;
+        m = fmaxf(m, v);
     }
+#pragma unroll
+    for (int j = 0; j < 64; ++j) {
+        KR[j] = (rml && ((cbits >> j) & 1)) ? expf(KR[j] - m) : 0.f;
+        T[lane][j] = KR[j];
+    }
+    const float krd = rml ? expf(alpha - m) : 0.f;   // K'[l][64]
+    const float kdr = cml ? 1.0f : 0.f;               // K'[64][l] = exp(alpha - m_64), m_64 = alpha
+    const float kdd = 1.0f;                           // K'[64][64]
     __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 64; ++i) KC[i] = T[i][lane];
+    // mu_i = exp(log_mu_i), nu likewise (modules.py:55-63)
+    const float mu = rml ? expf(norm) : 0.f, nu = cml ? expf(norm) : 0.f;
+    const float mu64 = expf(logf((float)nvc) + norm), nu64 = expf(logf((float)nvr) + norm);
+    float al = 0.f, a64 = 0.f, bl = cml ? 1.0f : 0.f, b64 = 1.0f;   // v = 0
+    bv[lane] = bl;
+    const float4* av4 = reinterpret_cast<const float4*>(av);
+    const float4* bv4 = reinterpret_cast<const float4*>(bv);
     for (int it = 0; it < a.num_iter; ++it) {
-        if (act) {
-            float r = 0.f;
-#pragma unroll
-            for (int e = 0; e < OTE; ++e) { const int j = q * OTE + e; r += kr[e] * bv[j < OTN ? j : 0]; }
-            r += __shfl_xor(r, 1, 64); r += __shfl_xor(r, 2, 64);
-            if (q == 0) av[i] = rmask[i] ? mu / r : 0.f;
-        }
         __syncthreads();
-        if (act) {
-            float cs = 0.f;
+        float r0 = krd * b64, r1 = 0.f, r2 = 0.f, r3 = 0.f;
 #pragma unroll
-            for (int e = 0; e < OTE; ++e) { const int j = q * OTE + e; cs += kc[e] * av[j < OTN ? j : 0]; }
-            cs += __shfl_xor(cs, 1, 64); cs += __shfl_xor(cs, 2, 64);
-            if (q == 0) bv[i] = cmask[i] ? nu / cs : 0.f;
+        for (int q = 0; q < 16; ++q) {
+            const float4 t = bv4[q];
+            r0 = fmaf(KR[4 * q], t.x, r0); r1 = fmaf(KR[4 * q + 1], t.y, r1); r2 = fmaf(KR[4 * q + 2], t.z, r2); r3 = fmaf(KR[4 * q + 3], t.w, r3);
         }
+        al = rml ? mu / ((r0 + r1) + (r2 + r3)) : 0.f;
+        a64 = mu64 / (wave_sum(kdr * bl) + kdd * b64);
+        av[lane] = al;
         __syncthreads();
+        float c0 = kdr * a64, c1 = 0.f, c2 = 0.f, c3 = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const float4 t = av4[q];
+            c0 = fmaf(KC[4 * q], t.x, c0); c1 = fmaf(KC[4 * q + 1], t.y, c1); c2 = fmaf(KC[4 * q + 2], t.z, c2); c3 = fmaf(KC[4 * q + 3], t.w, c3);
+        }
+        const float bn = cml ? nu / ((c0 + c1) + (c2 + c3)) : 0.f;
+        const float b64n = nu64 / (wave_sum(krd * al) + kdd * a64);
+        const bool same = __ballot(__float_as_int(bn) != __float_as_int(bl)) == 0 && __float_as_int(b64n) == __float_as_int(b64);
+        bl = bn; b64 = b64n;
+        if (same) { if (stats && lane == 0) atomicAdd(stats + 1, (unsigned long long)(a.num_iter - 1 - it)); break; }
+        bv[lane] = bl;
     }
+    if (stats && lane == 0) atomicAdd(stats, 1ull);
     // outputs = S + u + v - norm  with u_i = log(a~_i) - m_i, v_j = log(b_j)  (modules.py:27,66-67)
-    if (act && q == 0) {
-        av[i] = rmask[i] ? logf(av[i]) - mrow[i] : 0.f;
-        bv[i] = cmask[i] ? logf(bv[i]) : 0.f;
-    }
     __syncthreads();
-    for (int e = tid; e < OTN * OTN; e += 320) {
-        const int r = e / OTN, c = e % OTN;
-        out[e] = S[r][c] + av[r] + bv[c] - norm;
+    const float ul = rml ? logf(al) - m : 0.f, vl = cml ? logf(bl) : 0.f;
+    const float u64 = logf(a64) - alpha, v64 = logf(b64);
+    av[lane] = ul;
+    __syncthreads();
+#pragma unroll 8
+    for (int i = 0; i < 64; ++i) {
+        const float sv = (cml && ((rbits >> i) & 1)) ? sc[i * 64 + lane] : -1e6f;
+        out[i * OTN + lane] = sv + av[i] + vl - norm;
     }
+    out[64 * OTN + lane] = (cml ? alpha : -1e6f) + u64 + vl - norm;
+    out[lane * OTN + 64] = (rml ? alpha : -1e6f) + ul + v64 - norm;
+    if (lane == 0) out[64 * OTN + 64] = alpha + u64 + v64 - norm;
 }
 
 // ------------------------------------------------------------------ FineMatching (modules.py:216-324)
@@ -649,7 +659,14 @@ extern "C" int roitr_optimal_transport(const RoitrOT* a, hipStream_t stream)
     if (a->pairs <= 0) return ROITR_OK;
     if (a->limit != 64) return ROITR_ERR_UNSUPPORTED;
     roitr_prof_begin(ROITR_PROF_OT, (double)a->pairs * a->num_corr * (64.0 * 64 + 65.0 * 65) * 4.0, stream);
-    ot_kernel<<<a->pairs * a->num_corr, 320, 0, stream>>>(*a);
+    // debug (ROITR_OT_STATS=1): live patches and Sinkhorn iterations skipped by the exact fixed-point exit, printed at exit
+    struct Stats {
+        unsigned long long* d = nullptr;
+        Stats() { if (getenv("ROITR_OT_STATS")) { hipMalloc(&d, 16); hipMemset(d, 0, 16); } }
+        ~Stats() { if (d) { unsigned long long h[2]; hipMemcpy(h, d, 16, hipMemcpyDeviceToHost); fprintf(stderr, "OTSTATS live_patches %llu skipped_iterations %llu\n", h[0], h[1]); } }
+    };
+    static Stats stats;
+    ot_kernel<<<a->pairs * a->num_corr, 64, 0, stream>>>(*a, stats.d);
     roitr_prof_end(ROITR_PROF_OT, stream);
     ROITR_LAUNCH_CHECK();
     return ROITR_OK;
