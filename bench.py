@@ -127,6 +127,7 @@ def main():
     }
     if rank == 0:
         out["roofline"] = roofline(prof, B, N)
+        attach_traffic(out["roofline"], B)
         out["kernel_ms_per_step"] = {k: round(v["ms"] / max(args.steps, 1), 4) for k, v in prof.items()}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(N, args.cpu_baseline_seconds)
@@ -157,6 +158,23 @@ def roofline(prof, B, N):
     return {"bound": "hbm", "kernel": name, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None, "avg_launch_ms": round(avg_ms, 5),
             "algorithmic_bytes_per_launch": int(per_launch), "launches_timed": int(p["launches"])}
+
+
+def attach_traffic(roof, B):
+    """roofline.traffic: HBM bytes per launch of the dominant kernel from the PMC passes (FETCH_SIZE / WRITE_SIZE collected
+    in their own rocprofv3 runs of this same command by scripts/collect_profiles.sh, gfx950 corrections applied in
+    scripts/pmc_summary.py); only attached when the committed summary was taken at the same pairs-per-step."""
+    if not roof:
+        return
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        pmc = json.load(open(path))
+    except Exception:
+        return
+    k = pmc.get("kernels", {}).get(roof.get("kernel"))
+    if k and pmc.get("pairs_per_step") == B:
+        roof["traffic"] = k["hbm_bytes_per_launch"]
+        roof["traffic_source"] = "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
 
 
 def cpu_baseline(N, budget_s):

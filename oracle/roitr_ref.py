@@ -407,19 +407,25 @@ def closed_form_state(factor=1):
     return sd
 
 
-def timed_baseline(n_points, budget_s=20.0):
-    """bench.py cpu_baseline ('port'): forward of ONE pair of the bench workload on this host's cores.
+def timed_baseline(n_points, budget_s=20.0, max_pairs=16):
+    """bench.py cpu_baseline ('port'): full forwards of pairs of the bench workload on this host's cores.
 
     FPS/kNN run in the C restatement (kNN split over all cores with threads; FPS is inherently serial per
-    cloud), the dense stages in numpy (BLAS threads as configured).  The bounded sample is a single pair:
-    the full forward takes ~10-30 s of CPU time at N=5000."""
+    cloud), the dense stages in numpy (BLAS threads as configured).  The bounded sample: distinct pairs are run
+    one after the other until `budget_s` seconds of wall time are used (at least one pair, at most `max_pairs`)."""
     from roitr_amd.synthetic import make_pair
     cores = len(os.sched_getaffinity(0))
     sd = closed_form_state()
-    pair = make_pair(n_points, config=2, pair_index=0)
-    t0 = time.perf_counter()
-    out = forward(sd, pair, threads=cores)
-    dt = time.perf_counter() - t0
-    return {"value": round(1.0 / dt, 5), "unit": "pairs/s", "cores": cores, "kind": "port",
-            "sample": f"1 pair, N={n_points} pts/cloud, full forward, oracle/roitr_ref.py (numpy fp32 + C FPS/kNN), "
-                      f"{dt:.2f} s wall, {int(out['corr_scores'].shape[0])} correspondences"}
+    pairs = 0
+    ncorr = 0
+    dt = 0.0
+    while pairs < max_pairs and (pairs == 0 or dt < budget_s):
+        pair = make_pair(n_points, config=2, pair_index=pairs)
+        t0 = time.perf_counter()
+        out = forward(sd, pair, threads=cores)
+        dt += time.perf_counter() - t0
+        ncorr += int(out["corr_scores"].shape[0])
+        pairs += 1
+    return {"value": round(pairs / dt, 5), "unit": "pairs/s", "cores": cores, "kind": "port",
+            "sample": f"{pairs} pair(s), N={n_points} pts/cloud, full forward each, oracle/roitr_ref.py (numpy fp32 + C FPS/kNN), "
+                      f"{dt:.2f} s wall, {ncorr} correspondences"}

@@ -39,6 +39,17 @@ __device__ __forceinline__ float sqdist3(float ax, float ay, float az, float bx,
     return __fmaf_rn(dz, dz, __fmaf_rn(dy, dy, __fmul_rn(dx, dx)));
 }
 
+// XCD-aware block id.  The dispatcher places block b on XCD b % 8 (MI355X_MICROARCH.md, workgroup dispatch), each XCD
+// with a private 4 MiB L2: consecutive blocks that share gathered rows would each fetch them into a different L2.
+// This remap hands every XCD one contiguous eighth of the logical block range.  Launch xcd_grid(n) blocks and skip
+// logical ids >= n (padding of the rounded-up grid).
+__host__ __device__ __forceinline__ int xcd_grid(int n) { return ((n + 7) >> 3) << 3; }
+__device__ __forceinline__ int xcd_block_id(int n)
+{
+    const int b = blockIdx.x;
+    return (b & 7) * ((n + 7) >> 3) + (b >> 3);
+}
+
 // Wave-wide reductions on the DPP cross-lane path (no LDS traffic, unlike ds_bpermute-backed __shfl_xor for the 16/32
 // strides): row_shr 1/2/4/8 build the 16-lane row result in lane 15 of each row, row_bcast:15 / row_bcast:31 fold the
 // four rows, lane 63 holds the wave result and v_readlane broadcasts it.  Lanes without a source read `old`

@@ -11,106 +11,134 @@
 // (the dominant dense cost of the encoder); here it is 5 extra GEMM columns
 // per head (qp, produced together with q) and 5 FMAs per output channel.
 //
-// One wave per node.  Phase 1: lane = (head, neighbour) computes its score with 16-byte loads of the
-// gathered key row slice, softmax over the neighbour axis is a butterfly inside the head's lane
-// group.  Phase 2: lane = channel; the value rows are read fully coalesced.  Gathered k/v rows are
-// never materialised (the reference builds (M,K,H) copies with fancy indexing, attention.py:174-175).
+// One wave per node, 4 heads = the 4 DPP rows of the wave: lane l owns the HV = H/64 consecutive channels
+// l*HV .. l*HV+HV-1, which all belong to head l/16.  Every gathered key / value row is read once, fully coalesced
+// (HV floats per lane, scalar row base + lane offset: no per-lane address arithmetic); the per-head dot product is a
+// per-lane partial + a 4-step DPP butterfly inside the 16-lane row; the PPF term rides in the same reduction (lanes
+// 0..4 of each row add qp[h][t] * ppf[k][t] resp. the q_h . bpe_h constant); softmax is evaluated once per (head,
+// neighbour) by lane t = neighbour of the head's row; the probabilities and the 4 pbar numbers per head cross lanes
+// through a 320-byte LDS slot per wave.  No block barrier, no shuffles through LDS, gathered k/v rows are never
+// materialised (the reference builds (M,K,H) copies with fancy indexing, attention.py:174-175).
 #include "common.h"
 #include "prof.h"
 #include "roitr_engine.h"
 
 namespace {
 
-// K = neighbours per node (8 / 16), HV = H / 64 (channels per lane in phase 2).  Memory round trips per node are the
-// critical path (72 % of wave time was s_waitcnt in the first version), so everything that only depends on the node
-// id is requested up front (neighbour indices, q row, ppf), and everything that only depends on the neighbour
-// indices -- the key slices AND the value rows -- is requested together: two dependent round trips instead of four.
+template <int CTRL>
+__device__ __forceinline__ float row_dpp_add(float v)
+{
+    return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+// sum over the 16 lanes of a DPP row, result in every lane: quad xor 1, quad xor 2, half mirror, row mirror
+__device__ __forceinline__ float row_allsum(float v)
+{
+    v = row_dpp_add<0xB1>(v);   // quad_perm [1,0,3,2]
+    v = row_dpp_add<0x4E>(v);   // quad_perm [2,3,0,1]
+    v = row_dpp_add<0x141>(v);  // row_half_mirror
+    v = row_dpp_add<0x140>(v);  // row_mirror
+    return v;
+}
+
+template <int HV> struct VecLoad;
+template <> struct VecLoad<1> { static __device__ __forceinline__ void ld(const float* p, float* d) { d[0] = *p; }
+                                static __device__ __forceinline__ void st(float* p, const float* d) { *p = d[0]; } };
+template <> struct VecLoad<2> { static __device__ __forceinline__ void ld(const float* p, float* d) { const float2 t = *reinterpret_cast<const float2*>(p); d[0] = t.x; d[1] = t.y; }
+                                static __device__ __forceinline__ void st(float* p, const float* d) { *reinterpret_cast<float2*>(p) = make_float2(d[0], d[1]); } };
+template <> struct VecLoad<4> { static __device__ __forceinline__ void ld(const float* p, float* d) { const float4 t = *reinterpret_cast<const float4*>(p); d[0] = t.x; d[1] = t.y; d[2] = t.z; d[3] = t.w; }
+                                static __device__ __forceinline__ void st(float* p, const float* d) { *reinterpret_cast<float4*>(p) = make_float4(d[0], d[1], d[2], d[3]); } };
+template <> struct VecLoad<8> { static __device__ __forceinline__ void ld(const float* p, float* d) { VecLoad<4>::ld(p, d); VecLoad<4>::ld(p + 4, d + 4); }
+                                static __device__ __forceinline__ void st(float* p, const float* d) { VecLoad<4>::st(p, d); VecLoad<4>::st(p + 4, d + 4); } };
+
+__device__ __forceinline__ void lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+// K = neighbours per node (8 / 16), HV = H / 64 (channels per lane); heads == 4.
 template <int K, int HV>
 __global__ __launch_bounds__(256) void local_attn_kernel(RoitrLocalAttn a)
 {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
+    __shared__ __attribute__((aligned(16))) float xch[4][80];   // per wave: probs [head][16] | pbar [head][4]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    // nodes are visited in the grid's cell order when one is given: consecutive waves then gather overlapping
-    // neighbour sets, so a k/v row is re-used from L2 instead of being fetched once per referencing node
-    const int slot = blockIdx.x * 4 + wave;
-    const bool valid = slot < a.M;  // whole-wave predicate (no early exit: block barriers below)
-    const int node = (a.node_order && valid) ? __float_as_int(reinterpret_cast<const float4*>(a.node_order)[slot].w) : (valid ? slot : 0);
+    // nodes are visited in the grid's cell order when one is given, and every XCD gets a contiguous eighth of that
+    // order: the k/v rows a node gathers are then re-used out of its XCD's L2 by the spatially adjacent nodes
+    const int slot = xcd_block_id((a.M + 3) >> 2) * 4 + wave;
+    if (slot >= a.M) return;
+    int node = slot;
+    if (a.node_order) node = __float_as_int(reinterpret_cast<const float4*>(a.node_order)[slot].w);
+    node = __builtin_amdgcn_readfirstlane(node);
     constexpr int H = 64 * HV;
-    const int NH = a.heads, c = H / NH;
-    float* qs = smem + (size_t)wave * (H + 5 * NH + 64 + 4 * NH + 64);  // q row | qp | probs | pbar | ppf
-    float* qp = qs + H;
-    float* pr = qp + 5 * NH;
-    float* pb = pr + 64;
-    float* pf = pb + 4 * NH;
+    const int h = lane >> 4, t = lane & 15;
+    float* probs = xch[wave];
+    float* pbar = xch[wave] + 64;
 
     // ---- round trip 1: everything addressed by the node id
-    const int h = lane / K, k = lane % K;
-    const bool act = valid && lane < NH * K;
-    const int g = a.group_idx[(size_t)node * K + k];
+    const int g = a.group_idx[(size_t)node * K + (lane < K ? lane : 0)];
     const float* qrow = a.q + (size_t)node * a.ldq;
-    for (int i = lane; i < H + 5 * NH; i += 64) qs[i] = qrow[i];
-    if (lane < K) {
-        const float4 f = reinterpret_cast<const float4*>(a.ppf)[(size_t)node * K + lane];
-        pf[lane * 4 + 0] = f.x; pf[lane * 4 + 1] = f.y; pf[lane * 4 + 2] = f.z; pf[lane * 4 + 3] = f.w;
-    }
-    // ---- round trip 2: value rows (lane = channel) and key slices (lane = head, neighbour), all in flight together
-    float vr[K][HV];
+    float qv[HV];
+    VecLoad<HV>::ld(qrow + lane * HV, qv);
+    float ec = t < 5 ? qrow[H + h * 5 + t] : 0.f;   // qp[h][0..3] (PPF coefficients), qp[h][4] (q_h . bpe_h)
+    float pv[K];
+    const float* pf = a.ppf + (size_t)node * K * 4 + (t < 4 ? t : 0);
+#pragma unroll
+    for (int kk = 0; kk < K; ++kk) pv[kk] = pf[kk * 4];
+    // ---- round trip 2: key and value rows of the K neighbours, all in flight together
+    float kr[K][HV], vr[K][HV];
 #pragma unroll
     for (int kk = 0; kk < K; ++kk) {
-        const int gk = __builtin_amdgcn_readlane(g, kk);  // lane kk (head 0) holds neighbour kk
-        const float* vrow = a.v + (size_t)gk * a.ldv + lane;
-#pragma unroll
-        for (int i = 0; i < HV; ++i) vr[kk][i] = vrow[64 * i];
+        const int gk = __builtin_amdgcn_readlane(g, kk);
+        VecLoad<HV>::ld(a.k + (size_t)gk * a.ldk + lane * HV, kr[kk]);
     }
-    const float* krow = a.k + (size_t)g * a.ldk + (act ? h : 0) * c;
-    __syncthreads();
-    float score = -INFINITY;
-    if (act) {
-        const float* qh = qs + h * c;
-        float dot = 0.f;
-        for (int i = 0; i < c; i += 4) {
-            const float4 kv = *reinterpret_cast<const float4*>(krow + i);
-            const float4 qv = *reinterpret_cast<const float4*>(qh + i);
-            dot += kv.x * qv.x; dot += kv.y * qv.y; dot += kv.z * qv.z; dot += kv.w * qv.w;
-        }
-        const float* qph = qp + h * 5;
-        const float sp = qph[0] * pf[k * 4] + qph[1] * pf[k * 4 + 1] + qph[2] * pf[k * 4 + 2] + qph[3] * pf[k * 4 + 3] + qph[4];
-        score = (dot + sp) * a.scale;
-    }
-    // softmax over k inside each K-lane group
-    float mx = score;
 #pragma unroll
-    for (int o = 1; o < K; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
-    const float e = act ? expf(score - mx) : 0.f;  // accurate exp: the reference softmax is libm-exact
-    float sum = e;
-#pragma unroll
-    for (int o = 1; o < K; o <<= 1) sum += __shfl_xor(sum, o, 64);
-    const float p = act ? e / sum : 0.f;
-    // pbar[h][j] = sum_k p * ppf[k][j]
-    float b0 = p * pf[k * 4 + 0], b1 = p * pf[k * 4 + 1], b2 = p * pf[k * 4 + 2], b3 = p * pf[k * 4 + 3];
-#pragma unroll
-    for (int o = 1; o < K; o <<= 1) {
-        b0 += __shfl_xor(b0, o, 64); b1 += __shfl_xor(b1, o, 64); b2 += __shfl_xor(b2, o, 64); b3 += __shfl_xor(b3, o, 64);
+    for (int kk = 0; kk < K; ++kk) {
+        const int gk = __builtin_amdgcn_readlane(g, kk);
+        VecLoad<HV>::ld(a.v + (size_t)gk * a.ldv + lane * HV, vr[kk]);
     }
-    if (act) {
-        pr[lane] = p;
-        if (k == 0) { pb[h * 4 + 0] = b0; pb[h * 4 + 1] = b1; pb[h * 4 + 2] = b2; pb[h * 4 + 3] = b3; }
-    }
-    __syncthreads();
-    if (!valid) return;
+#pragma unroll
+    for (int i = 0; i < HV; ++i) qv[i] *= a.scale;
+    ec *= a.scale;
+#pragma unroll
+    for (int kk = 0; kk < K; ++kk) pv[kk] = t < 4 ? pv[kk] : (t == 4 ? 1.0f : 0.f);
 
-    // ---- phase 2: lane = channel, value rows already in registers
+    // ---- scores: s(h, kk) = scale * (q_h . k_h[kk] + qp_h . [ppf_kk, 1]); lane t of row h keeps s(h, t)
+    float mine = 0.f, mx = -INFINITY;
+#pragma unroll
+    for (int kk = 0; kk < K; ++kk) {
+        float d = ec * pv[kk];
+#pragma unroll
+        for (int i = 0; i < HV; ++i) d = fmaf(qv[i], kr[kk][i], d);
+        d = row_allsum(d);
+        mine = t == kk ? d : mine;
+        mx = fmaxf(mx, d);
+    }
+    const float e = t < K ? expf(mine - mx) : 0.f;   // accurate exp: the reference softmax is libm-exact
+    const float p = e / row_allsum(e);
+    probs[lane] = p;   // [h][t]
+    lds_fence();
+    float pk[K];
+#pragma unroll
+    for (int q4 = 0; q4 < K / 4; ++q4) {
+        const float4 v4 = reinterpret_cast<const float4*>(probs + h * 16)[q4];
+        pk[4 * q4] = v4.x; pk[4 * q4 + 1] = v4.y; pk[4 * q4 + 2] = v4.z; pk[4 * q4 + 3] = v4.w;
+    }
+    // pbar[h][j] = sum_k p(h,k) ppf[k][j]   (lanes t < 4 of every row)
+    float pb = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < K; ++kk) pb = fmaf(pk[kk], pv[kk], pb);
+    if (t < 4) pbar[h * 4 + t] = pb;
+    lds_fence();
+    const float4 pb4 = reinterpret_cast<const float4*>(pbar)[h];
+
+    // ---- output: sum_k p v  +  Wvpe pbar + bvpe
+    float o[HV], bias[HV];
+    VecLoad<HV>::ld(a.bvpe + lane * HV, bias);
 #pragma unroll
     for (int i = 0; i < HV; ++i) {
-        const int ch = lane + 64 * i;
-        const int hh = ch / c;
         float acc = 0.f;
 #pragma unroll
-        for (int kk = 0; kk < K; ++kk) acc += pr[hh * K + kk] * vr[kk][i];
-        const float4 w = reinterpret_cast<const float4*>(a.wvpe)[ch];
-        acc += w.x * pb[hh * 4] + w.y * pb[hh * 4 + 1] + w.z * pb[hh * 4 + 2] + w.w * pb[hh * 4 + 3] + a.bvpe[ch];
-        a.out[(size_t)node * a.ldo + ch] = acc;
+        for (int kk = 0; kk < K; ++kk) acc = fmaf(pk[kk], vr[kk][i], acc);
+        const float4 w = reinterpret_cast<const float4*>(a.wvpe)[lane * HV + i];
+        o[i] = acc + (w.x * pb4.x + w.y * pb4.y + w.z * pb4.z + w.w * pb4.w + bias[i]);
     }
+    VecLoad<HV>::st(a.out + (size_t)node * a.ldo + lane * HV, o);
 }
 
 // Pfold (5*NH x H): row h*5+j holds Wpe[h*c + cc][j] (j<4) / bpe[h*c+cc] (j=4) at column h*c+cc, else 0.
@@ -131,16 +159,14 @@ __global__ void build_pfold_kernel(int H, int NH, const float* __restrict__ wpe,
 extern "C" int roitr_local_attention(const RoitrLocalAttn* a, hipStream_t stream)
 {
     if (a->M <= 0) return ROITR_OK;
-    const int c = a->H / a->heads;
-    if (a->heads * a->K > 64 || (a->K & (a->K - 1)) || a->H % a->heads || c % 4 || (a->ldk % 4) || a->K < 1) return ROITR_ERR_UNSUPPORTED;
-    const size_t per_wave = (size_t)a->H + 5 * a->heads + 64 + 4 * a->heads + 64;
-    const size_t lds = per_wave * 4 * sizeof(float);
-    if (per_wave % 4) return ROITR_ERR_UNSUPPORTED;  // keeps every wave's q row 16-byte aligned
+    const int hv = a->H / 64;
+    // heads = the 4 DPP rows of a wave; float4 row accesses need 16-byte aligned rows
+    if (a->heads != 4 || a->H % 64 || (a->K != 8 && a->K != 16) || (hv != 1 && hv != 2 && hv != 4 && hv != 8)) return ROITR_ERR_UNSUPPORTED;
+    if (hv > 1 && ((a->ldq | a->ldk | a->ldv | a->ldo) % (hv > 4 ? 4 : hv) || ((uintptr_t)a->q | (uintptr_t)a->k | (uintptr_t)a->v | (uintptr_t)a->out) % 16))
+        return ROITR_ERR_UNSUPPORTED;
     // algorithmic bytes: q row + K gathered k and v rows + ppf + idx in, one row out
     roitr_prof_begin(ROITR_PROF_LOCAL_ATTN, (double)a->M * ((a->H + 20.0) * 4 + a->K * (2.0 * a->H * 4 + 20.0) + a->H * 4.0), stream);
-    const int hv = a->H / 64;
-    if (a->H % 64 || (a->K != 8 && a->K != 16) || (hv != 1 && hv != 2 && hv != 4 && hv != 8)) return ROITR_ERR_UNSUPPORTED;
-#define LA_CASE(KK, HH) local_attn_kernel<KK, HH><<<div_up(a->M, 4), 256, lds, stream>>>(*a)
+#define LA_CASE(KK, HH) local_attn_kernel<KK, HH><<<xcd_grid(div_up(a->M, 4)), 256, 0, stream>>>(*a)
     if (a->K == 8) { if (hv == 1) LA_CASE(8, 1); else if (hv == 2) LA_CASE(8, 2); else if (hv == 4) LA_CASE(8, 4); else LA_CASE(8, 8); }
     else { if (hv == 1) LA_CASE(16, 1); else if (hv == 2) LA_CASE(16, 2); else if (hv == 4) LA_CASE(16, 4); else LA_CASE(16, 8); }
 #undef LA_CASE
