@@ -39,6 +39,22 @@ __device__ __forceinline__ float sqdist3(float ax, float ay, float az, float bx,
     return __fmaf_rn(dz, dz, __fmaf_rn(dy, dy, __fmul_rn(dx, dx)));
 }
 
+// Sum over the 16 lanes of a DPP row (result in every lane of the row).
+template <int CTRL>
+__device__ __forceinline__ float row_dpp_add(float v)
+{
+    return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+// sum over the 16 lanes of a DPP row, result in every lane: quad xor 1, quad xor 2, half mirror, row mirror
+__device__ __forceinline__ float row_allsum(float v)
+{
+    v = row_dpp_add<0xB1>(v);   // quad_perm [1,0,3,2]
+    v = row_dpp_add<0x4E>(v);   // quad_perm [2,3,0,1]
+    v = row_dpp_add<0x141>(v);  // row_half_mirror
+    v = row_dpp_add<0x140>(v);  // row_mirror
+    return v;
+}
+
 // XCD-aware block id.  The dispatcher places block b on XCD b % 8 (MI355X_MICROARCH.md, workgroup dispatch), each XCD
 // with a private 4 MiB L2: consecutive blocks that share gathered rows would each fetch them into a different L2.
 // This remap hands every XCD one contiguous eighth of the logical block range.  Launch xcd_grid(n) blocks and skip

@@ -14,6 +14,7 @@
 //     proj_p(E) / proj_vp(E) of geoattention.py:104-105 (n^2 C^2 MACs each, 3.3 GFLOP per self layer at
 //     n = 78) are never formed; what remains on E is two streaming passes (n^2 C MACs each).
 #include "common.h"
+#include <cstdlib>
 #include "prof.h"
 #include "roitr_engine.h"
 
@@ -216,6 +217,112 @@ __global__ __launch_bounds__(256) void mha_kernel(RoitrMha a)
     }
 }
 
+
+// ------------------------------------------------------------------ self attention with the folded RPE branch, C = 256, 4 heads
+// One block per query row i, same math as mha_kernel.  The (n, C) slab E[i, :, :] -- the only HBM-sized operand, n*C*4
+// = 80 KB at n = 78 -- is read from memory exactly ONCE, fully coalesced (wave w owns keys j = w, w+4, ...; a lane holds
+// the float4 of channels 4*lane.. of each of its rows), and stays in registers for both uses: the score pass
+// (q~_h . E_ij, wave reductions on the DPP path) and the value pass (ebar_h = sum_j a'_hj E_ij, register FMAs; the four
+// waves' partial sums meet in LDS).  Channels 4*lane..4*lane+3 belong to head lane/16 = the lane's DPP row, so q_h . k_j
+// is a row reduction.  mha_kernel streams E twice with one 1 KB row per LANE (uncoalesced, L1-thrashing): 1.9 ms per
+// launch at 128 pairs against 0.3-0.4 ms for one pass over E at HBM speed.
+__device__ __forceinline__ float dot4(const float4 a, const float4 b) { return fmaf(a.w, b.w, fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x))); }
+
+template <int R>   // R = key rows per wave kept in registers: n <= 4 R
+__global__ __launch_bounds__(256) void mha_geo_kernel(RoitrMha a)
+{
+    constexpr int C = 256, NH = 4, NKP = 4 * R;
+    __shared__ __attribute__((aligned(16))) float sc[NH][NKP];    // scores -> probabilities [head][key]
+    __shared__ __attribute__((aligned(16))) float sc2t[NKP * 4];   // diagonal-masked probabilities [key][head]
+    __shared__ __attribute__((aligned(16))) float red[4][NH * C];  // per-wave ebar partials
+    const int row = a.q_row0 + blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hl = lane >> 4;
+    const int cl = a.cloud_of_row[row];
+    const int ks = cl == 0 ? 0 : a.offset[cl - 1], nk = a.offset[cl] - ks;
+    const int qi = row - ks;
+    const float* Erow = a.E + a.eoff[cl] * C + (size_t)qi * nk * C;
+    float4 e[R];
+#pragma unroll
+    for (int rr = 0; rr < R; ++rr) {
+        const int j = wave + 4 * rr;
+        e[rr] = j < nk ? reinterpret_cast<const float4*>(Erow + (size_t)j * C)[lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const float4 qv = reinterpret_cast<const float4*>(a.q + (size_t)row * a.ldq)[lane];
+    float4 qt4[NH];
+#pragma unroll
+    for (int h = 0; h < NH; ++h) qt4[h] = reinterpret_cast<const float4*>(a.qt + ((size_t)row * NH + h) * C)[lane];
+    const float qb = row_allsum(dot4(qv, reinterpret_cast<const float4*>(a.bp)[lane]));   // q_h . bp_h, h = this lane's row
+    // ---- scores
+#pragma unroll
+    for (int rr = 0; rr < R; ++rr) {
+        const int j = wave + 4 * rr;
+        const int jc = j < nk ? j : nk - 1;
+        const float4 kv = reinterpret_cast<const float4*>(a.k + (size_t)(ks + jc) * a.ldk)[lane];
+        const float s1 = row_allsum(dot4(qv, kv));
+        const float se0 = wave_sum(dot4(qt4[0], e[rr])), se1 = wave_sum(dot4(qt4[1], e[rr]));
+        const float se2 = wave_sum(dot4(qt4[2], e[rr])), se3 = wave_sum(dot4(qt4[3], e[rr]));
+        const float se = hl == 0 ? se0 : (hl == 1 ? se1 : (hl == 2 ? se2 : se3));
+        if (j < nk && (lane & 15) == 0) sc[hl][j] = (s1 + (se + qb)) * a.scale;
+    }
+    __syncthreads();
+    // ---- softmax and the diagonal-masked softmax (geoattention.py:117-134) over the keys: wave = head
+    {
+        const int h = wave;
+        float mx = -INFINITY, mx2 = -INFINITY;
+        for (int j = lane; j < nk; j += 64) {
+            const float v = sc[h][j];
+            mx = fmaxf(mx, v);
+            if (j != qi) mx2 = fmaxf(mx2, v);
+        }
+        mx = wave_max(mx); mx2 = wave_max(mx2);
+        float sm = 0.f, sm2 = 0.f;
+        float e1[(NKP + 63) / 64], e2[(NKP + 63) / 64];
+#pragma unroll
+        for (int u = 0; u < (NKP + 63) / 64; ++u) {
+            const int j = lane + 64 * u;
+            const float v = j < nk ? sc[h][j] : 0.f;
+            e1[u] = j < nk ? expf(v - mx) : 0.f;
+            e2[u] = (j < nk && j != qi) ? expf(v - mx2) : 0.f;
+            sm += e1[u]; sm2 += e2[u];
+        }
+        sm = wave_sum(sm); sm2 = wave_sum(sm2);
+#pragma unroll
+        for (int u = 0; u < (NKP + 63) / 64; ++u) {
+            const int j = lane + 64 * u;
+            if (j < nk) { sc[h][j] = e1[u] / sm; sc2t[j * 4 + h] = e2[u] / sm2; }
+        }
+    }
+    __syncthreads();
+    // ---- hidden[ch] = sum_j p[head(ch)][j] v[j][ch]: thread = channel
+    {
+        const int h = tid >> 6;
+        const float* vp = a.v + (size_t)ks * a.ldv + tid;
+        float acc = 0.f;
+        for (int j = 0; j < nk; ++j) acc = fmaf(sc[h][j], vp[(size_t)j * a.ldv], acc);
+        a.out[(size_t)row * a.ldo + tid] = acc;
+    }
+    // ---- ebar[h][:] = sum_j p2[h][j] E[i][j][:]: this wave's rows out of registers, then the 4 waves through LDS
+    float4 acc[NH];
+#pragma unroll
+    for (int h = 0; h < NH; ++h) acc[h] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int rr = 0; rr < R; ++rr) {
+        const int j = wave + 4 * rr;
+        const float4 p2 = reinterpret_cast<const float4*>(sc2t)[j < nk ? j : 0];
+        const float w0 = j < nk ? p2.x : 0.f, w1 = j < nk ? p2.y : 0.f, w2 = j < nk ? p2.z : 0.f, w3 = j < nk ? p2.w : 0.f;
+        acc[0].x = fmaf(w0, e[rr].x, acc[0].x); acc[0].y = fmaf(w0, e[rr].y, acc[0].y); acc[0].z = fmaf(w0, e[rr].z, acc[0].z); acc[0].w = fmaf(w0, e[rr].w, acc[0].w);
+        acc[1].x = fmaf(w1, e[rr].x, acc[1].x); acc[1].y = fmaf(w1, e[rr].y, acc[1].y); acc[1].z = fmaf(w1, e[rr].z, acc[1].z); acc[1].w = fmaf(w1, e[rr].w, acc[1].w);
+        acc[2].x = fmaf(w2, e[rr].x, acc[2].x); acc[2].y = fmaf(w2, e[rr].y, acc[2].y); acc[2].z = fmaf(w2, e[rr].z, acc[2].z); acc[2].w = fmaf(w2, e[rr].w, acc[2].w);
+        acc[3].x = fmaf(w3, e[rr].x, acc[3].x); acc[3].y = fmaf(w3, e[rr].y, acc[3].y); acc[3].z = fmaf(w3, e[rr].z, acc[3].z); acc[3].w = fmaf(w3, e[rr].w, acc[3].w);
+    }
+#pragma unroll
+    for (int h = 0; h < NH; ++h) reinterpret_cast<float4*>(red[wave])[h * 64 + lane] = acc[h];
+    __syncthreads();
+#pragma unroll
+    for (int h = 0; h < NH; ++h)
+        a.ebar[((size_t)row * NH + h) * C + tid] = (red[0][h * C + tid] + red[1][h * C + tid]) + (red[2][h * C + tid] + red[3][h * C + tid]);
+}
+
 }  // namespace
 
 extern "C" int roitr_geo_indices(int rows, const float* pts, const int* offset, const int* cloud_of_row, const long* eoff,
@@ -239,6 +346,12 @@ extern "C" int roitr_mha(const RoitrMha* a, hipStream_t stream)
     static const hipError_t attr_ = hipFuncSetAttribute((const void*)mha_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     (void)attr_;
     roitr_prof_begin(ROITR_PROF_MHA, 0.0, stream);
+    // self attention over E at the model's width: the single-pass register-resident kernel (nk_max bounds every cloud)
+    const bool geo = a->E && !a->partner && a->C == 256 && a->heads == 4 && a->ldq % 4 == 0 && a->ldk % 4 == 0 && a->nk_max <= 128 &&
+                     getenv("ROITR_MHA_GENERIC") == nullptr;
+    if (geo && a->nk_max <= 80) mha_geo_kernel<20><<<a->q_rows, 256, 0, stream>>>(*a);
+    else if (geo) mha_geo_kernel<32><<<a->q_rows, 256, 0, stream>>>(*a);
+    else
     mha_kernel<<<a->q_rows, 256, floats * sizeof(float), stream>>>(*a);
     roitr_prof_end(ROITR_PROF_MHA, stream);
     ROITR_LAUNCH_CHECK();

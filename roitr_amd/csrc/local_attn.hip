@@ -25,21 +25,6 @@
 
 namespace {
 
-template <int CTRL>
-__device__ __forceinline__ float row_dpp_add(float v)
-{
-    return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
-}
-// sum over the 16 lanes of a DPP row, result in every lane: quad xor 1, quad xor 2, half mirror, row mirror
-__device__ __forceinline__ float row_allsum(float v)
-{
-    v = row_dpp_add<0xB1>(v);   // quad_perm [1,0,3,2]
-    v = row_dpp_add<0x4E>(v);   // quad_perm [2,3,0,1]
-    v = row_dpp_add<0x141>(v);  // row_half_mirror
-    v = row_dpp_add<0x140>(v);  // row_mirror
-    return v;
-}
-
 template <int HV> struct VecLoad;
 template <> struct VecLoad<1> { static __device__ __forceinline__ void ld(const float* p, float* d) { d[0] = *p; }
                                 static __device__ __forceinline__ void st(float* p, const float* d) { *p = d[0]; } };
