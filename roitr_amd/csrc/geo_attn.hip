@@ -229,7 +229,7 @@ __global__ __launch_bounds__(256) void mha_kernel(RoitrMha a)
 __device__ __forceinline__ float dot4(const float4 a, const float4 b) { return fmaf(a.w, b.w, fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x))); }
 
 template <int R>   // R = key rows per wave kept in registers: n <= 4 R
-__global__ __launch_bounds__(256) void mha_geo_kernel(RoitrMha a)
+__global__ __launch_bounds__(256, R <= 20 ? 3 : 2) void mha_geo_kernel(RoitrMha a)
 {
     constexpr int C = 256, NH = 4, NKP = 4 * R;
     __shared__ __attribute__((aligned(16))) float sc[NH][NKP];    // scores -> probabilities [head][key]
@@ -252,17 +252,32 @@ __global__ __launch_bounds__(256) void mha_geo_kernel(RoitrMha a)
 #pragma unroll
     for (int h = 0; h < NH; ++h) qt4[h] = reinterpret_cast<const float4*>(a.qt + ((size_t)row * NH + h) * C)[lane];
     const float qb = row_allsum(dot4(qv, reinterpret_cast<const float4*>(a.bp)[lane]));   // q_h . bp_h, h = this lane's row
-    // ---- scores
+    // ---- scores, part 1 (while the E rows are in flight): q_h . k_j from L2-resident key rows, 5 rows per batch
+#pragma unroll
+    for (int r0 = 0; r0 < R; r0 += 5) {
+        float4 kv[5];
+#pragma unroll
+        for (int u = 0; u < 5; ++u) {
+            const int j = wave + 4 * (r0 + u);
+            kv[u] = reinterpret_cast<const float4*>(a.k + (size_t)(ks + (j < nk ? j : nk - 1)) * a.ldk)[lane];
+        }
+#pragma unroll
+        for (int u = 0; u < 5; ++u) {
+            if (r0 + u < R) {
+                const int j = wave + 4 * (r0 + u);
+                const float s1 = row_allsum(dot4(qv, kv[u]));
+                if (j < nk && (lane & 15) == 0) sc[hl][j] = s1;
+            }
+        }
+    }
+    // ---- scores, part 2: + q~_h . E_ij + q_h . bp_h  (same lane re-reads its own LDS word: no barrier needed)
 #pragma unroll
     for (int rr = 0; rr < R; ++rr) {
         const int j = wave + 4 * rr;
-        const int jc = j < nk ? j : nk - 1;
-        const float4 kv = reinterpret_cast<const float4*>(a.k + (size_t)(ks + jc) * a.ldk)[lane];
-        const float s1 = row_allsum(dot4(qv, kv));
         const float se0 = wave_sum(dot4(qt4[0], e[rr])), se1 = wave_sum(dot4(qt4[1], e[rr]));
         const float se2 = wave_sum(dot4(qt4[2], e[rr])), se3 = wave_sum(dot4(qt4[3], e[rr]));
         const float se = hl == 0 ? se0 : (hl == 1 ? se1 : (hl == 2 ? se2 : se3));
-        if (j < nk && (lane & 15) == 0) sc[hl][j] = (s1 + (se + qb)) * a.scale;
+        if (j < nk && (lane & 15) == 0) sc[hl][j] = (sc[hl][j] + (se + qb)) * a.scale;
     }
     __syncthreads();
     // ---- softmax and the diagonal-masked softmax (geoattention.py:117-134) over the keys: wave = head
@@ -298,7 +313,15 @@ __global__ __launch_bounds__(256) void mha_geo_kernel(RoitrMha a)
         const int h = tid >> 6;
         const float* vp = a.v + (size_t)ks * a.ldv + tid;
         float acc = 0.f;
-        for (int j = 0; j < nk; ++j) acc = fmaf(sc[h][j], vp[(size_t)j * a.ldv], acc);
+        int j = 0;
+        for (; j + 8 <= nk; j += 8) {   // 8 independent loads in flight
+            float vv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) vv[u] = vp[(size_t)(j + u) * a.ldv];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc = fmaf(sc[h][j + u], vv[u], acc);
+        }
+        for (; j < nk; ++j) acc = fmaf(sc[h][j], vp[(size_t)j * a.ldv], acc);
         a.out[(size_t)row * a.ldo + tid] = acc;
     }
     // ---- ebar[h][:] = sum_j p2[h][j] E[i][j][:]: this wave's rows out of registers, then the 4 waves through LDS
