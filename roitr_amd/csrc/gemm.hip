@@ -59,11 +59,17 @@ constexpr int ZERO_ROW_LEN = 2048;
 __device__ __attribute__((aligned(16))) float g_zero_row[ZERO_ROW_LEN];
 
 template <bool FAST>
-__global__ __launch_bounds__(256) void gemm_kernel(RoitrGemm g)
+__global__ __launch_bounds__(256) void gemm_kernel(RoitrGemm g, int nx, int ny, int T)
 {
     __shared__ __attribute__((aligned(16))) float As[2 * BM * LDR];
     __shared__ __attribute__((aligned(16))) float Bs[2 * BN * LDR];
-    const int bz = blockIdx.z;
+    // 1-D XCD-aware tile grid: XCD x = blockIdx % 8 gets the contiguous tile range [x T/8, (x+1) T/8), N tiles of one
+    // row block adjacent, so the A rows of a row block are fetched into ONE L2 instead of nx different ones
+    const int tile = xcd_block_id(T);
+    if (tile >= T) return;
+    const int bz = tile / (nx * ny);
+    const int rem = tile - bz * nx * ny;
+    const int by_ = rem / nx, bx_ = rem - by_ * nx;
     const float* A = g.A + (size_t)bz * g.sA;
     const float* A2 = g.A2 ? g.A2 + (size_t)bz * g.sA : nullptr;
     const float* W = g.W + (size_t)bz * g.sW;
@@ -74,7 +80,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(RoitrGemm g)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int m0 = by_ * BM, n0 = bx_ * BN;
     const int r = tid >> 2, kq = (tid & 3) * 8;
     if (g.seg_off) {  // ragged batch: this batch's row segments of A and W
         const int ia = g.seg_a0 + bz, iw = g.seg_w0 + bz;
@@ -203,19 +209,26 @@ extern "C" int roitr_gemm(const RoitrGemm* g, hipStream_t stream)
 {
     if (g->M <= 0 || g->N <= 0 || g->batch <= 0) return ROITR_OK;
     if (g->K <= 0 || !g->A || !g->W || !g->C) return ROITR_ERR_ARG;
-    dim3 grid(div_up(g->N, BN), div_up(g->M, BM), g->batch);
+    const int nx = div_up(g->N, BN), ny = div_up(g->M, BM);
+    const long Tl = (long)nx * ny * g->batch;
+    if (Tl > 0x7ffffff0L) return ROITR_ERR_UNSUPPORTED;
+    const int T = (int)Tl;
+    const unsigned grid = (unsigned)xcd_grid(T);
     auto al16 = [](const void* p, long stride_floats) { return ((uintptr_t)p & 15) == 0 && (stride_floats % 4) == 0; };
     const bool fast = g->K % BK == 0 && g->K <= ZERO_ROW_LEN && g->lda % 4 == 0 && g->ldw % 4 == 0 && al16(g->A, g->sA) && al16(g->W, g->sW) &&
                       (!g->A2 || al16(g->A2, g->sA));
     roitr_prof_begin(ROITR_PROF_GEMM, 2.0 * g->M * g->N * (double)g->K * g->batch, stream);
-    // Measured and dropped (A/B on the 32-pair bench): a 128x128 / 128x64 multi-accumulator tile (7.6 vs 7.4 ms of GEMM
-    // per forward) and two K-slabs per barrier pair (7.9 vs 7.5 ms): these launches are bounded by HBM writes at
-    // level 1 and by short K, not by the LDS->MFMA feed or the prefetch round trip.
+    // Measured and dropped (A/B on the forward bench): 64x128 / 128x128 multi-accumulator tiles (19.7 / 22.0 vs 16.9 ms of
+    // GEMM per 128-pair forward), two K-slabs per barrier pair (7.9 vs 7.5 ms at 32 pairs), and a persistent-block
+    // variant that opens the next tile (row pointers + first slab in flight) before the store epilogue (18.3-19.8 vs
+    // 16.9 ms): at K = 64..512 the hardware dispatcher overlapping 7 resident 64x64 blocks per CU beats all of them.
+    // The kernel alone reaches 106 TFLOP/s at K = 2048 and 78 at K = 256 (scripts/bench_gemm.py); the no-memory MFMA
+    // ceiling measured on this part is 143-157 TFLOP/s (scripts/micro/mfma_peak.hip).
     static const bool shapes = getenv("ROITR_GEMM_SHAPES") != nullptr;  // debug: per-shape timing table at exit (synchronous)
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (shapes) { hipEventCreate(&e0); hipEventCreate(&e1); hipEventRecord(e0, stream); }
-    if (fast) gemm_kernel<true><<<grid, 256, 0, stream>>>(*g);
-    else gemm_kernel<false><<<grid, 256, 0, stream>>>(*g);
+    if (fast) gemm_kernel<true><<<grid, 256, 0, stream>>>(*g, nx, ny, T);
+    else gemm_kernel<false><<<grid, 256, 0, stream>>>(*g, nx, ny, T);
     if (shapes) {
         hipEventRecord(e1, stream); hipEventSynchronize(e1);
         float ms = 0; hipEventElapsedTime(&ms, e0, e1); hipEventDestroy(e0); hipEventDestroy(e1);
