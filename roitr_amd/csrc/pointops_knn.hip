@@ -586,6 +586,98 @@ __global__ __launch_bounds__(256) void knn_lane_kernel(int m, int nsample, int b
     }
 }
 
+// ---------------------------------------------------------------- lane-per-query, small clouds (no grid)
+// Clouds below the grid threshold (the two coarse levels: 312 and 78 points per cloud at N = 5000) used to go to the
+// wave-per-query brute kernel -- 80 k waves for 80 k queries, 0.29 ms per call.  Here a lane owns a query and keeps its
+// sorted best list in registers (same list code and same tie -> replay rule as knn_lane_kernel); a block stages the
+// cloud(s) its 256 consecutive queries belong to through LDS as float4 (x, y, z, index) and every lane reads the same
+// candidate per step (LDS broadcast).
+template <int L>
+__global__ __launch_bounds__(256) void knn_lane_brute_kernel(int m, int nsample, int b, const float* __restrict__ xyz,
+                                                             const float* __restrict__ new_xyz, const int* __restrict__ offset,
+                                                             const int* __restrict__ new_offset, KnnOut o)
+{
+    constexpr int CH = 1024;
+    __shared__ float4 cand[CH];
+    __shared__ int seg_range[2];
+    const int tid = threadIdx.x;
+    const int q = blockIdx.x * 256 + tid;
+    const bool valid = q < m;
+    int seg = 0;
+    if (valid) {
+        if (b > 0) { int lo = 0, hi = b - 1; while (lo < hi) { const int mid = (lo + hi) >> 1; if (q < new_offset[mid]) hi = mid; else lo = mid + 1; } seg = lo; }
+        else { while (!(q < new_offset[seg])) seg++; }
+    }
+    if (tid == 0) seg_range[0] = seg;
+    if (q == min(m, (int)(blockIdx.x + 1) * 256) - 1) seg_range[1] = seg;
+    __syncthreads();
+    const int s_lo = seg_range[0], s_hi = seg_range[1];
+    float qx = 0.f, qy = 0.f, qz = 0.f;
+    if (valid) { qx = new_xyz[(size_t)q * 3]; qy = new_xyz[(size_t)q * 3 + 1]; qz = new_xyz[(size_t)q * 3 + 2]; }
+    const int my_start = seg == 0 ? 0 : offset[seg - 1];
+    float d[L]; int id[L];
+#pragma unroll
+    for (int j = 0; j < L; ++j) { d[j] = KNN_FILL; id[j] = my_start; }
+    auto offer = [&](float dd, int ci) {
+        if (dd < d[L - 1]) {
+#pragma unroll
+            for (int j = L - 1; j > 0; --j) {
+                const bool sh = d[j - 1] > dd, here = d[j] > dd;
+                d[j] = sh ? d[j - 1] : (here ? dd : d[j]);
+                id[j] = sh ? id[j - 1] : (here ? ci : id[j]);
+            }
+            const bool h0 = d[0] > dd;
+            d[0] = h0 ? dd : d[0]; id[0] = h0 ? ci : id[0];
+        }
+    };
+    for (int s = s_lo; s <= s_hi; ++s) {
+        const int start = s == 0 ? 0 : offset[s - 1], end = offset[s];
+        for (int base = start; base < end; base += CH) {
+            const int cnt = min(CH, end - base);
+            __syncthreads();
+            for (int i = tid; i < cnt; i += 256) {
+                const float* pp = xyz + (size_t)(base + i) * 3;
+                cand[i] = make_float4(pp[0], pp[1], pp[2], __int_as_float(base + i));
+            }
+            __syncthreads();
+            if (valid && seg == s) {
+                for (int i = 0; i < cnt; ++i) {
+                    const float4 c = cand[i];
+                    offer(sqdist3(qx, qy, qz, c.x, c.y, c.z), __float_as_int(c.w));
+                }
+            }
+        }
+    }
+    if (!valid) return;
+    bool tie = false;
+#pragma unroll
+    for (int j = 0; j + 1 < L; ++j) tie |= (j < nsample) && (d[j] == d[j + 1]) && (d[j] < KNN_FILL);
+    if (tie) {
+        const int slot = atomicAdd(o.tie_count, 1);
+        o.tie_list[slot] = q;
+        return;
+    }
+#pragma unroll
+    for (int j = 0; j < L; ++j) {
+        if (j < nsample) {
+            if (o.idx) o.idx[(size_t)q * nsample + j] = id[j];
+            if (o.dist2) o.dist2[(size_t)q * nsample + j] = d[j];
+            if (j >= 1 && o.group_idx) o.group_idx[(size_t)q * (nsample - 1) + j - 1] = id[j];
+        }
+    }
+    if (o.ppf) {  // neighbour indices are read back from the row this lane just wrote
+        const float* qn = o.query_normals + (size_t)q * 3;
+        const float nx = qn[0], ny = qn[1], nz = qn[2];
+        for (int j = 0; j < nsample - 1; ++j) {
+            const int gi = o.group_idx[(size_t)q * (nsample - 1) + j];
+            const float* pp = xyz + (size_t)gi * 3;
+            const float* pn = o.ref_normals + (size_t)gi * 3;
+            reinterpret_cast<float4*>(o.ppf)[(size_t)q * (nsample - 1) + j] =
+                ppf4(qx, qy, qz, nx, ny, nz, pp[0], pp[1], pp[2], pn[0], pn[1], pn[2]);
+        }
+    }
+}
+
 // ---------------------------------------------------------------- exact replay of tied queries
 // knnquery_cuda_kernel.cu:65-108 restated for one wave: the heap lives in LDS, every lane runs the
 // same (uniform) heap code; 64 distances are evaluated per step and only those below the root are
@@ -751,6 +843,7 @@ extern "C" int roitr_knnquery_ex(int b, int n, int m, int nsample, const float* 
         roitr_prof_begin(ROITR_PROF_KNN, bytes, stream);
     }
     static const int lane_min = [] { const char* e = getenv("ROITR_KNN_LANE_MIN"); return e ? atoi(e) : 8192; }();
+    static const bool lane_brute = getenv("ROITR_KNN_NO_LANE_BRUTE") == nullptr;
     const bool lane_ok = use_grid && m >= lane_min && (!ppf || group_idx) && b > 0;
     const int self_sorted = (new_xyz == xyz && new_offset == offset && m == n) ? 1 : 0;
     // non-self queries: walk them in reference-cell order; the order array reuses the tie list's tail
@@ -772,7 +865,13 @@ extern "C" int roitr_knnquery_ex(int b, int n, int m, int nsample, const float* 
         if (nsample + 1 <= 66) LANE_CASE(66); else LANE_CASE(101);
     } else
 #undef LANE_CASE
-    if (use_grid) {
+    if (!use_grid && nsample + 1 <= 34 && (!ppf || group_idx) && lane_brute) {
+#define LB_CASE(LC) knn_lane_brute_kernel<LC><<<div_up(m, 256), 256, 0, stream>>>(m, nsample, b, xyz, new_xyz, offset, new_offset, o)
+        const int need = nsample + 1;
+        if (need <= 2) LB_CASE(2); else if (need <= 4) LB_CASE(4); else if (need <= 10) LB_CASE(10);
+        else if (need <= 18) LB_CASE(18); else LB_CASE(34);
+#undef LB_CASE
+    } else if (use_grid) {
         if (nsample + 1 <= 64)
             knn_grid_kernel<1><<<blocks, 256, 0, stream>>>(m, nsample, xyz, new_xyz, offset, new_offset, v.grids, v.cell_start, v.sorted, o);
         else
