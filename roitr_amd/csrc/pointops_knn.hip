@@ -589,11 +589,11 @@ __global__ __launch_bounds__(256) void knn_lane_kernel(int m, int nsample, int b
 // ---------------------------------------------------------------- lane-per-query, small clouds (no grid)
 // Clouds below the grid threshold (the two coarse levels: 312 and 78 points per cloud at N = 5000) used to go to the
 // wave-per-query brute kernel -- 80 k waves for 80 k queries, 0.29 ms per call.  Here a lane owns a query and keeps its
-// sorted best list in registers (same list code and same tie -> replay rule as knn_lane_kernel); a block stages the
-// cloud(s) its 256 consecutive queries belong to through LDS as float4 (x, y, z, index) and every lane reads the same
+// sorted best list in registers (same list code and same tie -> replay rule as knn_lane_kernel); a block (one wave) stages the
+// cloud(s) its 64 consecutive queries belong to through LDS as float4 (x, y, z, index) and every lane reads the same
 // candidate per step (LDS broadcast).
 template <int L>
-__global__ __launch_bounds__(256) void knn_lane_brute_kernel(int m, int nsample, int b, const float* __restrict__ xyz,
+__global__ __launch_bounds__(64) void knn_lane_brute_kernel(int m, int nsample, int b, const float* __restrict__ xyz,
                                                              const float* __restrict__ new_xyz, const int* __restrict__ offset,
                                                              const int* __restrict__ new_offset, KnnOut o)
 {
@@ -601,7 +601,7 @@ __global__ __launch_bounds__(256) void knn_lane_brute_kernel(int m, int nsample,
     __shared__ float4 cand[CH];
     __shared__ int seg_range[2];
     const int tid = threadIdx.x;
-    const int q = blockIdx.x * 256 + tid;
+    const int q = blockIdx.x * 64 + tid;   // one wave per block: many small blocks interleave their insertion chains
     const bool valid = q < m;
     int seg = 0;
     if (valid) {
@@ -609,7 +609,7 @@ __global__ __launch_bounds__(256) void knn_lane_brute_kernel(int m, int nsample,
         else { while (!(q < new_offset[seg])) seg++; }
     }
     if (tid == 0) seg_range[0] = seg;
-    if (q == min(m, (int)(blockIdx.x + 1) * 256) - 1) seg_range[1] = seg;
+    if (q == min(m, (int)(blockIdx.x + 1) * 64) - 1) seg_range[1] = seg;
     __syncthreads();
     const int s_lo = seg_range[0], s_hi = seg_range[1];
     float qx = 0.f, qy = 0.f, qz = 0.f;
@@ -635,7 +635,7 @@ __global__ __launch_bounds__(256) void knn_lane_brute_kernel(int m, int nsample,
         for (int base = start; base < end; base += CH) {
             const int cnt = min(CH, end - base);
             __syncthreads();
-            for (int i = tid; i < cnt; i += 256) {
+            for (int i = tid; i < cnt; i += 64) {
                 const float* pp = xyz + (size_t)(base + i) * 3;
                 cand[i] = make_float4(pp[0], pp[1], pp[2], __int_as_float(base + i));
             }
@@ -866,7 +866,7 @@ extern "C" int roitr_knnquery_ex(int b, int n, int m, int nsample, const float* 
     } else
 #undef LANE_CASE
     if (!use_grid && nsample + 1 <= 34 && (!ppf || group_idx) && lane_brute) {
-#define LB_CASE(LC) knn_lane_brute_kernel<LC><<<div_up(m, 256), 256, 0, stream>>>(m, nsample, b, xyz, new_xyz, offset, new_offset, o)
+#define LB_CASE(LC) knn_lane_brute_kernel<LC><<<div_up(m, 64), 64, 0, stream>>>(m, nsample, b, xyz, new_xyz, offset, new_offset, o)
         const int need = nsample + 1;
         if (need <= 2) LB_CASE(2); else if (need <= 4) LB_CASE(4); else if (need <= 10) LB_CASE(10);
         else if (need <= 18) LB_CASE(18); else LB_CASE(34);
