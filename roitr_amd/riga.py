@@ -302,6 +302,12 @@ class RIGA_v2(nn.Module):
 
         All B pairs go through the engine in ONE batched pass (clouds laid out src_0..src_{B-1},
         tgt_0..tgt_{B-1}); the only host synchronisation is the final read of the correspondence count."""
+        return self.finish_batch(self.launch_batch(pairs, want_gt))
+
+    def launch_batch(self, pairs, want_gt=True):
+        """Enqueue the batched forward on the current stream and return a handle for finish_batch().  Nothing here waits
+        for the GPU: a caller may launch batch s+1 before finishing batch s, so the device never idles while the host
+        unpacks results (outputs are per-call tensors, the engine's scratch arena is re-used in stream order)."""
         self._ensure_engine()
         dev = pairs[0]["src_pcd"].device
         B = len(pairs)
@@ -347,10 +353,22 @@ class RIGA_v2(nn.Module):
         for k, v in out.items():
             setattr(io, k, L.ptr(v))
         L.check(L.lib().roitr_engine_forward(self._engine, ctypes.byref(io), L.stream_ptr()), "engine_forward")
-        # ---- unpack per pair (host sync happens here, on the counts)
-        # one D2H transfer for all the counts: [first output row of every pair | total | n_corr per pair]
+        # one D2H transfer for all the counts: [first output row of every pair | total | n_corr per pair | gt counts],
+        # queued behind this forward only (an event, not a stream sync, is waited on in finish_batch)
         parts = [out["fine_offsets"].view(B, P)[:, 0], out["n_out"], out["n_corr"]] + ([out["gt_corr_count"]] if have_gt else [])
-        meta = torch.cat(parts).tolist()
+        meta_dev = torch.cat(parts)
+        meta_host = torch.empty(meta_dev.shape, dtype=meta_dev.dtype, pin_memory=True)
+        meta_host.copy_(meta_dev, non_blocking=True)
+        done = torch.cuda.Event()
+        done.record()
+        keep = (geom, pout, nrm, feats, rot, trans, arr, meta_dev)   # inputs stay alive until the forward has run
+        return dict(pairs=pairs, out=out, B=B, P=P, n_all=n_all, n4=n4, have_gt=have_gt, meta_host=meta_host, done=done, keep=keep)
+
+    def finish_batch(self, h):
+        """Wait for the forward of launch_batch() and unpack it per pair (the one host synchronisation of the path)."""
+        pairs, out, B, P, n_all, n4, have_gt = h["pairs"], h["out"], h["B"], h["P"], h["n_all"], h["n4"], h["have_gt"]
+        h["done"].synchronize()
+        meta = h["meta_host"].tolist()
         starts, n_corr, gt_cnt = meta[:B + 1], meta[B + 1:2 * B + 1], meta[2 * B + 1:]
         o_pts = np.cumsum([0] + n_all)
         o_nod = np.cumsum([0] + n4)
