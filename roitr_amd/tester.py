@@ -45,15 +45,23 @@ class Tester:
         device = next(self.model.parameters()).device
         self.model.eval()
         total_corr = 0
+        def load(s):
+            ids = mine[s:s + self.pairs_per_forward]
+            items = [self._to_device(self.dataset[i], device) for i in ids]
+            pairs = [dict(src_pcd=it["src_points"].contiguous(), tgt_pcd=it["tgt_points"].contiguous(),
+                          src_feats=it["src_feats"].contiguous(), tgt_feats=it["tgt_feats"].contiguous(),
+                          src_normals=it["src_normals"].contiguous(), tgt_normals=it["tgt_normals"].contiguous(),
+                          rot=it["rot"], trans=it["trans"], src_raw_pcd=it["raw_src_pcd"].contiguous()) for it in items]
+            return ids, items, pairs, self.model.launch_batch(pairs)
+
         with torch.no_grad():
-            for s in range(0, len(mine), self.pairs_per_forward):
-                ids = mine[s:s + self.pairs_per_forward]
-                items = [self._to_device(self.dataset[i], device) for i in ids]
-                pairs = [dict(src_pcd=it["src_points"].contiguous(), tgt_pcd=it["tgt_points"].contiguous(),
-                              src_feats=it["src_feats"].contiguous(), tgt_feats=it["tgt_feats"].contiguous(),
-                              src_normals=it["src_normals"].contiguous(), tgt_normals=it["tgt_normals"].contiguous(),
-                              rot=it["rot"], trans=it["trans"], src_raw_pcd=it["raw_src_pcd"].contiguous()) for it in items]
-                outs = self.model.forward_batch(pairs)
+            starts = list(range(0, len(mine), self.pairs_per_forward))
+            nxt = load(starts[0]) if starts else None
+            for k in range(len(starts)):
+                ids, items, pairs, handle = nxt
+                # the next batch is loaded and enqueued before this one is unpacked and written to disk
+                nxt = load(starts[k + 1]) if k + 1 < len(starts) else None
+                outs = self.model.finish_batch(handle)
                 for idx, it, p, o in zip(ids, items, pairs, outs):
                     data = dict()  # lib/tester.py:56-69
                     data["src_raw_pcd"] = p["src_raw_pcd"].cpu()
