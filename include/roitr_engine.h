@@ -34,6 +34,11 @@ typedef struct RoitrGemm {
     /* optional ragged batching: batch b multiplies row segment (seg_a0 + b) of A with row segment (seg_w0 + b) of W,
      * segments given by the cumulative int32 `seg_off`; M / N then only bound the grid. */
     const int* seg_off; int seg_a0, seg_w0;
+    /* optional fused LayerNorm epilogue (ln_gamma != NULL; requires N == 64 = one tile per row, batch == 1):
+     *   C[r,:] = [relu]( LayerNorm(acc[r,:] + bias + ln_res[ln_res_idx ? ln_res_idx[r] : r, :]) * gamma + beta + ln_post[r,:] )
+     * i.e. the GEMM followed by roitr_add_layernorm in one launch (ln_res / ln_post rows are 64 floats, dense). */
+    const float* ln_gamma; const float* ln_beta; const float* ln_res; const int* ln_res_idx; const float* ln_post;
+    int ln_relu; float ln_eps;
 } RoitrGemm;
 int roitr_gemm(const RoitrGemm* g, roitr_stream_t stream);
 

@@ -147,6 +147,30 @@ int gemm(hipStream_t st, int M, const float* A, const Lin& l, float* C, bool rel
     return gemm(st, M, l.out, l.in, A, l.in, l.w, l.in, l.b, C, l.out, relu, a_idx, A2);
 }
 
+// nn.Linear followed by (+ residual) LayerNorm (+ post-add) (ReLU): one launch when the layer is 64 wide (the LayerNorm
+// runs in the GEMM epilogue, the (M, 64) intermediate never reaches HBM), the two-launch sequence otherwise.
+// `tmp` (M x l.out) is only touched by the two-launch form.
+int gemm_ln(hipStream_t st, int M, const float* A, const Lin& l, const float* res, const int* res_idx, const float* gamma,
+            const float* beta, const float* post, bool relu, float* tmp, float* out, int lda = 0, const float* W = nullptr, int ldw = 0,
+            const float* bias = nullptr, bool has_bias = true)
+{
+    static const bool fuse = getenv("ROITR_NO_LN_FUSE") == nullptr;
+    const float* w = W ? W : l.w;
+    const float* b = W ? (has_bias ? bias : nullptr) : l.b;
+    const int K = l.in, N = l.out;
+    if (lda == 0) lda = K;
+    if (ldw == 0) ldw = K;
+    if (fuse && N == 64) {
+        RoitrGemm g;
+        memset(&g, 0, sizeof(g));
+        g.M = M; g.N = N; g.K = K; g.A = A; g.lda = lda; g.W = w; g.ldw = ldw; g.bias = b; g.alpha = 1.0f; g.C = out; g.ldc = N; g.batch = 1;
+        g.ln_gamma = gamma; g.ln_beta = beta; g.ln_res = res; g.ln_res_idx = res_idx; g.ln_post = post; g.ln_relu = relu ? 1 : 0; g.ln_eps = 1e-5f;
+        return roitr_gemm(&g, st);
+    }
+    CHK(gemm(st, M, N, K, A, lda, w, ldw, b, tmp, N));
+    return roitr_add_layernorm(M, N, tmp, res, res_idx, gamma, beta, post, relu ? 1 : 0, 1e-5f, out, st);
+}
+
 int d2d(hipStream_t st, void* dst, const void* src, size_t bytes)
 {
     ROITR_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, st));
@@ -239,8 +263,9 @@ struct Dev {  // device-resident descriptors
 };
 
 // LocalPPFTransformer.forward (ppftransformer.py:227-253) on N_in input rows -> M node rows
+// `bn2_res` != nullptr: the caller is RIPointTransformerBlock and wants out = relu(bn2(out_proj(..)) + bn2_res)
 int local_transformer(Engine& E, hipStream_t st, const LocalT& L, int N_in, const float* x, int M, const int* node_idx, const int* group,
-                      const float* ppf, int K, float* out, const void* order = nullptr)
+                      const float* ppf, int K, float* out, const void* order = nullptr, const float* bn2_res = nullptr)
 {
     Arena& A = E.arena;
     const size_t mark = A.off;
@@ -272,9 +297,14 @@ int local_transformer(Engine& E, hipStream_t st, const LocalT& L, int N_in, cons
     a.group_idx = group; a.ppf = ppf; a.wvpe = L.wvpe; a.bvpe = L.bvpe; a.scale = 1.0f / sqrtf((float)(H / HEADS));
     a.out = att; a.ldo = H; a.node_order = order;
     CHK(roitr_local_attention(&a, st));
-    CHK(gemm(st, M, att, L.lin, hid));
-    CHK(roitr_add_layernorm(M, H, hid, f, node_idx, L.norm_w, L.norm_b, nullptr, 0, 1e-5f, y, st));
-    CHK(gemm(st, M, y, L.out_proj, out));
+    CHK(gemm_ln(st, M, att, L.lin, f, node_idx, L.norm_w, L.norm_b, nullptr, false, hid, y));
+    if (bn2_res) {
+        float* t = A.get<float>((size_t)M * L.out_dim);
+        if (A.fail) return ROITR_ERR_ARG;
+        CHK(gemm_ln(st, M, y, L.out_proj, nullptr, nullptr, L.bn2_w, L.bn2_b, bn2_res, true, t, out));
+    } else {
+        CHK(gemm(st, M, y, L.out_proj, out));
+    }
     A.off = mark;
     return 0;
 }
@@ -285,10 +315,7 @@ int block(Engine& E, hipStream_t st, const LocalT& L, int M, const float* x, con
 {
     Arena& A = E.arena;
     const size_t mark = A.off;
-    float* t = A.get<float>((size_t)M * L.out_dim);
-    if (A.fail) return ROITR_ERR_ARG;
-    CHK(local_transformer(E, st, L, M, x, M, nullptr, group, ppf, K, t, order));
-    CHK(roitr_add_layernorm(M, L.out_dim, t, nullptr, nullptr, L.bn2_w, L.bn2_b, x, 1, 1e-5f, out, st));
+    CHK(local_transformer(E, st, L, M, x, M, nullptr, group, ppf, K, out, order, x));
     A.off = mark;
     return 0;
 }
@@ -764,11 +791,9 @@ extern "C" int roitr_engine_forward(void* h, const RoitrForwardIO* io, hipStream
         float* x0 = A.get<float>((size_t)Tl * pl);
         xd[l] = A.get<float>((size_t)Tl * pl);
         if (A.fail) { roitr_set_error("arena exhausted (decoder)", __FILE__, __LINE__); return ROITR_ERR_ARG; }
-        CHK(gemm(st, Tl, xe[l], U.l1, a0));
-        CHK(roitr_add_layernorm(Tl, pl, a0, nullptr, nullptr, U.l1n_w, U.l1n_b, nullptr, 1, 1e-5f, a1, st));
+        CHK(gemm_ln(st, Tl, xe[l], U.l1, nullptr, nullptr, U.l1n_w, U.l1n_b, nullptr, true, a0, a1));
         (void)pc;
-        CHK(gemm(st, Tc, xd[l + 1], U.l2, b0));
-        CHK(roitr_add_layernorm(Tc, pl, b0, nullptr, nullptr, U.l2n_w, U.l2n_b, nullptr, 1, 1e-5f, b1, st));
+        CHK(gemm_ln(st, Tc, xd[l + 1], U.l2, nullptr, nullptr, U.l2n_w, U.l2n_b, nullptr, true, b0, b1));
         const int mcap_c = V.T[l];  // the coarser level's workspace was carved with m_capacity = T[l]
         CHK(roitr_knnquery_ex(NC, Tc, Tl, 3, p[l + 1], p[l], D.off[l + 1], D.off[l], i3, d3, nullptr, nullptr, nullptr, nullptr,
                               grid[l + 1] ? 1 : 0, mcap_c, knn_ws[l + 1], st));

@@ -58,11 +58,15 @@ __device__ __forceinline__ void load8(const float* __restrict__ p, int k, int K,
 constexpr int ZERO_ROW_LEN = 2048;
 __device__ __attribute__((aligned(16))) float g_zero_row[ZERO_ROW_LEN];
 
-template <bool FAST>
+// LN: fused LayerNorm epilogue (RoitrGemm::ln_*), N == 64: the finished 64x64 tile is parked row-major in the staging
+// LDS and every wave normalises 16 full rows with exactly the arithmetic (and summation order) of add_layernorm_kernel,
+// so the result is bitwise that of the two-launch sequence while the (M, 64) intermediate never touches HBM.
+template <bool FAST, bool LN>
 __global__ __launch_bounds__(256) void gemm_kernel(RoitrGemm g, int nx, int ny, int T)
 {
-    __shared__ __attribute__((aligned(16))) float As[2 * BM * LDR];
-    __shared__ __attribute__((aligned(16))) float Bs[2 * BN * LDR];
+    __shared__ __attribute__((aligned(16))) float smem[2 * BM * LDR + 2 * BN * LDR];
+    float* As = smem;
+    float* Bs = smem + 2 * BM * LDR;
     // 1-D XCD-aware tile grid: XCD x = blockIdx % 8 gets the contiguous tile range [x T/8, (x+1) T/8), N tiles of one
     // row block adjacent, so the A rows of a row block are fetched into ONE L2 instead of nx different ones
     const int tile = xcd_block_id(T);
@@ -168,6 +172,36 @@ __global__ __launch_bounds__(256) void gemm_kernel(RoitrGemm g, int nx, int ny, 
         }
         if (FAST) __builtin_amdgcn_sched_barrier(0);  // consumers of the prefetched registers stay below the MFMAs
     }
+    if (LN) {
+        static_assert(65 * BM <= 2 * BM * LDR + 2 * BN * LDR, "row-major tile must fit the staging LDS");
+        __syncthreads();   // every wave is done with the operand images
+        float* tile = smem;   // [64][65]
+        {
+            const int col = wn * 32 + (lane & 31);
+            const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int rl = wm * 32 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+                tile[rl * 65 + col] = acc[i] * g.alpha + bv;
+            }
+        }
+        __syncthreads();
+        const float gam = g.ln_gamma[lane], bet = g.ln_beta[lane];
+        for (int rl = wave; rl < BM; rl += 4) {
+            const int row = m0 + rl;
+            if (row >= g.M) break;   // wave-uniform
+            float t = tile[rl * 65 + lane];
+            if (g.ln_res) t += g.ln_res[(size_t)(g.ln_res_idx ? g.ln_res_idx[row] : row) * 64 + lane];
+            const float mean = wave_sum(t) / 64.0f;
+            const float d = t - mean;
+            const float rstd = 1.0f / sqrtf(wave_sum(d * d) / 64.0f + g.ln_eps);
+            float y = d * rstd * gam + bet;
+            if (g.ln_post) y += g.ln_post[(size_t)row * 64 + lane];
+            if (g.ln_relu) y = fmaxf(y, 0.f);
+            C[(size_t)row * g.ldc + lane] = y;
+        }
+        return;
+    }
     const int col = n0 + wn * 32 + (lane & 31);
     if (col < g.N) {
         const float bv = bias ? bias[col] : 0.f;
@@ -182,7 +216,6 @@ __global__ __launch_bounds__(256) void gemm_kernel(RoitrGemm g, int nx, int ny, 
         }
     }
 }
-
 
 }  // namespace
 
@@ -227,8 +260,12 @@ extern "C" int roitr_gemm(const RoitrGemm* g, hipStream_t stream)
     static const bool shapes = getenv("ROITR_GEMM_SHAPES") != nullptr;  // debug: per-shape timing table at exit (synchronous)
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (shapes) { hipEventCreate(&e0); hipEventCreate(&e1); hipEventRecord(e0, stream); }
-    if (fast) gemm_kernel<true><<<grid, 256, 0, stream>>>(*g, nx, ny, T);
-    else gemm_kernel<false><<<grid, 256, 0, stream>>>(*g, nx, ny, T);
+    if (g->ln_gamma) {
+        if (g->N != BN || g->batch != 1 || g->seg_off || g->relu || !g->ln_beta) return ROITR_ERR_UNSUPPORTED;
+        if (fast) gemm_kernel<true, true><<<grid, 256, 0, stream>>>(*g, nx, ny, T);
+        else gemm_kernel<false, true><<<grid, 256, 0, stream>>>(*g, nx, ny, T);
+    } else if (fast) gemm_kernel<true, false><<<grid, 256, 0, stream>>>(*g, nx, ny, T);
+    else gemm_kernel<false, false><<<grid, 256, 0, stream>>>(*g, nx, ny, T);
     if (shapes) {
         hipEventRecord(e1, stream); hipEventSynchronize(e1);
         float ms = 0; hipEventElapsedTime(&ms, e0, e1); hipEventDestroy(e0); hipEventDestroy(e1);

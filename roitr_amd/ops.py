@@ -150,7 +150,9 @@ class _Gemm(ctypes.Structure):
                 ("bias", _P), ("alpha", ctypes.c_float), ("relu", ctypes.c_int), ("C", _P), ("ldc", ctypes.c_int),
                 ("batch", ctypes.c_int), ("sA", ctypes.c_long), ("sW", ctypes.c_long), ("sC", ctypes.c_long),
                 ("sBias", ctypes.c_long), ("sAidx", ctypes.c_long), ("sWidx", ctypes.c_long), ("seg_off", _P),
-                ("seg_a0", ctypes.c_int), ("seg_w0", ctypes.c_int)]
+                ("seg_a0", ctypes.c_int), ("seg_w0", ctypes.c_int),
+                ("ln_gamma", _P), ("ln_beta", _P), ("ln_res", _P), ("ln_res_idx", _P), ("ln_post", _P),
+                ("ln_relu", ctypes.c_int), ("ln_eps", ctypes.c_float)]
 
 
 def linear(x, weight, bias=None, relu=False, alpha=1.0):
@@ -163,6 +165,21 @@ def linear(x, weight, bias=None, relu=False, alpha=1.0):
     g = _Gemm(M, N, K, L.ptr(x), L.ptr(None), K, L.ptr(None), 0, L.ptr(weight), K, L.ptr(None), 0, L.ptr(b), float(alpha), int(relu),
               L.ptr(out), N, 1, 0, 0, 0, 0, 0, 0, L.ptr(None), 0, 0)
     L.check(L.lib().roitr_gemm(ctypes.byref(g), L.stream_ptr()), "gemm")
+    return out
+
+
+def linear_layernorm(x, weight, bias, gamma, beta, res=None, res_idx=None, post=None, relu=False, eps=1e-5):
+    """[relu](LayerNorm(x @ weight.T + bias + res[res_idx]) * gamma + beta + post) in ONE launch (64 output channels):
+    the nn.Linear -> (+ residual) -> nn.LayerNorm call sites of attention.py:319, model/model.py:89-97,138-140."""
+    x, weight = x.contiguous().float(), weight.contiguous().float()
+    M, K = x.shape
+    N = weight.shape[0]
+    out = torch.empty((M, N), dtype=torch.float32, device=x.device)
+    c = lambda t, dt=torch.float32: None if t is None else t.contiguous().to(dt)
+    b, gm, bt, rs, ri, po = c(bias), c(gamma), c(beta), c(res), c(res_idx, torch.int32), c(post)
+    g = _Gemm(M, N, K, L.ptr(x), L.ptr(None), K, L.ptr(None), 0, L.ptr(weight), K, L.ptr(None), 0, L.ptr(b), 1.0, 0,
+              L.ptr(out), N, 1, 0, 0, 0, 0, 0, 0, L.ptr(None), 0, 0, L.ptr(gm), L.ptr(bt), L.ptr(rs), L.ptr(ri), L.ptr(po), int(relu), float(eps))
+    L.check(L.lib().roitr_gemm(ctypes.byref(g), L.stream_ptr()), "gemm+layernorm")
     return out
 
 

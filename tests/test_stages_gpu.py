@@ -149,3 +149,31 @@ def test_ragged_forward_matches_oracle():
         assert np.abs(out[k].cpu().numpy() - ref[k]).max() < 1e-4, k
     assert np.array_equal(out["_src_node_knn_indices"].cpu().numpy(), ref["_src_node_knn_indices"])
     assert np.array_equal(out["_tgt_node_knn_indices"].cpu().numpy(), ref["_tgt_node_knn_indices"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,K,with_res,with_idx,with_post,relu", [(1000, 64, True, False, True, True), (777, 128, True, True, False, False),
+                                                                   (64, 1, False, False, False, True), (130, 40, True, False, False, False)])
+def test_linear_layernorm_fused_epilogue(M, K, with_res, with_idx, with_post, relu):
+    """GEMM with the LayerNorm epilogue (nn.Linear -> + residual -> nn.LayerNorm -> + identity -> ReLU in one launch,
+    attention.py:319 / model/model.py:138-140) against the plain fp32 torch formula and against the two-launch path."""
+    from roitr_amd import ops
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(M, K, generator=g).cuda()
+    w = (torch.randn(64, K, generator=g) / max(K, 1) ** 0.5).cuda()
+    b = torch.randn(64, generator=g).cuda()
+    gam, bet = torch.randn(64, generator=g).cuda(), torch.randn(64, generator=g).cuda()
+    R = M + 13
+    res = torch.randn(R, 64, generator=g).cuda() if with_res else None
+    idx = torch.randint(0, R, (M,), generator=g).cuda() if with_idx else None
+    post = torch.randn(M, 64, generator=g).cuda() if with_post else None
+    got = ops.linear_layernorm(x, w, b, gam, bet, res=res, res_idx=idx, post=post, relu=relu)
+    t = x.double() @ w.double().T + b.double()
+    if res is not None:
+        t = t + (res[idx.long()] if idx is not None else res[:M]).double()
+    ref = torch.nn.functional.layer_norm(t, (64,), gam.double(), bet.double(), 1e-5)
+    if post is not None:
+        ref = ref + post.double()
+    if relu:
+        ref = ref.clamp_min(0)
+    assert torch.allclose(got.double(), ref, atol=2e-5, rtol=2e-5), float((got.double() - ref).abs().max())
