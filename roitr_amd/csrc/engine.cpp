@@ -160,7 +160,10 @@ int gemm_ln(hipStream_t st, int M, const float* A, const Lin& l, const float* re
     const int K = l.in, N = l.out;
     if (lda == 0) lda = K;
     if (ldw == 0) ldw = K;
-    if (fuse && N == 64) {
+    static const int fuse_max = [] { const char* e = getenv("ROITR_LN_FUSE_MAX"); return e ? atoi(e) : 128; }();
+    // measured per 128-pair forward: fusing the 64-wide layers -1.55 ms, + the 128-wide ones -0.4 ms, + the 256-wide ones
+    // +1.0 ms (64 x 256 tiles leave the coarse levels with too few, too fat blocks) -> default limit 128
+    if (fuse && (N == 64 || N == 128 || N == 256) && N <= fuse_max && K % 32 == 0 && lda % 4 == 0 && ldw % 4 == 0) {
         RoitrGemm g;
         memset(&g, 0, sizeof(g));
         g.M = M; g.N = N; g.K = K; g.A = A; g.lda = lda; g.W = w; g.ldw = ldw; g.bias = b; g.alpha = 1.0f; g.C = out; g.ldc = N; g.batch = 1;
@@ -328,8 +331,7 @@ int ffn_apply(Engine& E, hipStream_t st, const Ffn& F, int M, int C, const float
     float* s = A.get<float>((size_t)M * C);
     if (A.fail) return ROITR_ERR_ARG;
     CHK(gemm(st, M, x, F.expand, e, true));
-    CHK(gemm(st, M, e, F.squeeze, s));
-    CHK(roitr_add_layernorm(M, C, s, x, nullptr, F.n_w, F.n_b, nullptr, 0, 1e-5f, out, st));
+    CHK(gemm_ln(st, M, e, F.squeeze, x, nullptr, F.n_w, F.n_b, nullptr, false, s, out));
     A.off = mark;
     return 0;
 }
@@ -717,11 +719,10 @@ extern "C" int roitr_engine_forward(void* h, const RoitrForwardIO* io, hipStream
                     CHK(roitr_gemm(&gp, st));
                 }
                 // RPEAttentionLayer tail (geoattention.py:236-244) + AttentionOutput x2 (l.278-280)
-                CHK(gemm(st, T4, hid, L.lin, t1));
-                CHK(roitr_add_layernorm(T4, C4, t1, fcur, nullptr, L.n_w, L.n_b, nullptr, 0, 1e-5f, hid, st));
+                // (in place is safe for the fused form: a block reads and writes only its own 64 rows)
+                CHK(gemm_ln(st, T4, hid, L.lin, fcur, nullptr, L.n_w, L.n_b, nullptr, false, t1, hid));
                 CHK(ffn_apply(E, st, L.out, T4, C4, hid, fcur));
-                CHK(gemm(st, T4, t2, L.pos_lin, t1));
-                CHK(roitr_add_layernorm(T4, C4, t1, nullptr, nullptr, L.pn_w, L.pn_b, nullptr, 0, 1e-5f, t2, st));
+                CHK(gemm_ln(st, T4, t2, L.pos_lin, nullptr, nullptr, L.pn_w, L.pn_b, nullptr, false, t1, t2));
                 CHK(ffn_apply(E, st, L.pos, T4, C4, t2, pos));
                 CHK(tap(E, st, "geo.layer" + std::to_string(li) + ".pos", pos, sizeof(float) * (size_t)T4 * C4));
             } else {
@@ -740,9 +741,8 @@ extern "C" int roitr_engine_forward(void* h, const RoitrForwardIO* io, hipStream
                     m.offset = D.off[3]; m.cloud_of_row = D.cloud_of_node; m.partner = D.partner; m.scale = scale; m.nk_max = V.nmax[3];
                     m.out = hid; m.ldo = C4;
                     CHK(roitr_mha(&m, st));
-                    CHK(gemm(st, qn, hid + (size_t)q0 * C4, L.lin, t1 + (size_t)q0 * C4));
-                    CHK(roitr_add_layernorm(qn, C4, t1 + (size_t)q0 * C4, fcur + (size_t)q0 * C4, nullptr, L.n_w, L.n_b, nullptr, 0, 1e-5f,
-                                            t2 + (size_t)q0 * C4, st));
+                    CHK(gemm_ln(st, qn, hid + (size_t)q0 * C4, L.lin, fcur + (size_t)q0 * C4, nullptr, L.n_w, L.n_b, nullptr, false,
+                                t1 + (size_t)q0 * C4, t2 + (size_t)q0 * C4));
                     CHK(ffn_apply(E, st, L.out, qn, C4, t2 + (size_t)q0 * C4, fcur + (size_t)q0 * C4));
                 }
             }

@@ -58,13 +58,19 @@ __device__ __forceinline__ void load8(const float* __restrict__ p, int k, int K,
 constexpr int ZERO_ROW_LEN = 2048;
 __device__ __attribute__((aligned(16))) float g_zero_row[ZERO_ROW_LEN];
 
-// LN: fused LayerNorm epilogue (RoitrGemm::ln_*), N == 64: the finished 64x64 tile is parked row-major in the staging
-// LDS and every wave normalises 16 full rows with exactly the arithmetic (and summation order) of add_layernorm_kernel,
-// so the result is bitwise that of the two-launch sequence while the (M, 64) intermediate never touches HBM.
-template <bool FAST, bool LN>
+// TN: 32x32 accumulators per wave along N; the block tile is 64 x (64 TN).  TN = 1 is the GEMM of the path (see the
+// launcher for why wider tiles are not used for plain GEMMs); TN = 2 / 4 exist for the LayerNorm epilogue, which needs
+// whole rows (N = 128 / 256) inside one block.
+// LN: fused LayerNorm epilogue (RoitrGemm::ln_*), N == 64 TN: the finished tile is parked row-major in the staging LDS
+// and every wave normalises 16 full rows with exactly the arithmetic (and summation order) of add_layernorm_kernel<TN>,
+// so the result is bitwise that of the two-launch sequence while the (M, N) intermediate never touches HBM.
+template <bool FAST, int TN, bool LN>
 __global__ __launch_bounds__(256) void gemm_kernel(RoitrGemm g, int nx, int ny, int T)
 {
-    __shared__ __attribute__((aligned(16))) float smem[2 * BM * LDR + 2 * BN * LDR];
+    constexpr int TBN = BN * TN;
+    constexpr int RP = TN == 4 ? 32 : 64;   // rows parked per LayerNorm pass (keeps the static LDS under 64 KB at TN = 4)
+    constexpr int STAGE = 2 * BM * LDR + 2 * TBN * LDR, TILE = LN ? RP * (TBN + 1) : 0;
+    __shared__ __attribute__((aligned(16))) float smem[STAGE > TILE ? STAGE : TILE];
     float* As = smem;
     float* Bs = smem + 2 * BM * LDR;
     // 1-D XCD-aware tile grid: XCD x = blockIdx % 8 gets the contiguous tile range [x T/8, (x+1) T/8), N tiles of one
@@ -84,7 +90,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(RoitrGemm g, int nx, int ny, 
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int m0 = by_ * BM, n0 = bx_ * BN;
+    const int m0 = by_ * BM, n0 = bx_ * TBN;
     const int r = tid >> 2, kq = (tid & 3) * 8;
     if (g.seg_off) {  // ragged batch: this batch's row segments of A and W
         const int ia = g.seg_a0 + bz, iw = g.seg_w0 + bz;
@@ -95,7 +101,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(RoitrGemm g, int nx, int ny, 
         if (m0 >= g.M || n0 >= g.N) return;  // block-uniform
     }
 
-    const float* arow = nullptr; const float* arow2 = nullptr; const float* wrow = nullptr;
+    const float* arow = nullptr; const float* arow2 = nullptr; const float* wrow[TN];
     {
         const int am = m0 + r;
         if (am < g.M) {
@@ -105,39 +111,47 @@ __global__ __launch_bounds__(256) void gemm_kernel(RoitrGemm g, int nx, int ny, 
                 if (A2) arow2 = A2 + (size_t)src * g.lda;
             }
         }
-        const int wn_ = n0 + r;
-        if (wn_ < g.N) {
-            int src = w_idx ? w_idx[wn_] : wn_;
-            if (src >= 0 && (g.w_limit <= 0 || src < g.w_limit)) wrow = W + (size_t)src * g.ldw;
+#pragma unroll
+        for (int v = 0; v < TN; ++v) {
+            wrow[v] = nullptr;
+            const int wn_ = n0 + r + 64 * v;
+            if (wn_ < g.N) {
+                int src = w_idx ? w_idx[wn_] : wn_;
+                if (src >= 0 && (g.w_limit <= 0 || src < g.w_limit)) wrow[v] = W + (size_t)src * g.ldw;
+            }
         }
     }
     const bool a_vec = (g.lda % 4 == 0) && (((uintptr_t)A & 15) == 0) && (!A2 || ((uintptr_t)A2 & 15) == 0);
     const bool w_vec = (g.ldw % 4 == 0) && (((uintptr_t)W & 15) == 0);
 
-    f32x16 acc;
+    f32x16 acc[TN];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    for (int v = 0; v < TN; ++v)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[v][i] = 0.f;
 
-    float av[8], a2v[8], wv[8];
+    float av[8], a2v[8], wv[TN][8];
     if (FAST) {
         if (!arow) arow = g_zero_row;
         if (!arow2) arow2 = g_zero_row;
-        if (!wrow) wrow = g_zero_row;
+#pragma unroll
+        for (int v = 0; v < TN; ++v) if (!wrow[v]) wrow[v] = g_zero_row;
     }
+    auto ld8 = [](const float* p, float (&d)[8]) {
+        const float4 x = *reinterpret_cast<const float4*>(p), y = *reinterpret_cast<const float4*>(p + 4);
+        d[0] = x.x; d[1] = x.y; d[2] = x.z; d[3] = x.w; d[4] = y.x; d[5] = y.y; d[6] = y.z; d[7] = y.w;
+    };
     auto fetch = [&](int k) {
         if (FAST) {
-            const float4 a0 = *reinterpret_cast<const float4*>(arow + k), a1 = *reinterpret_cast<const float4*>(arow + k + 4);
-            const float4 w0 = *reinterpret_cast<const float4*>(wrow + k), w1 = *reinterpret_cast<const float4*>(wrow + k + 4);
-            av[0] = a0.x; av[1] = a0.y; av[2] = a0.z; av[3] = a0.w; av[4] = a1.x; av[5] = a1.y; av[6] = a1.z; av[7] = a1.w;
-            wv[0] = w0.x; wv[1] = w0.y; wv[2] = w0.z; wv[3] = w0.w; wv[4] = w1.x; wv[5] = w1.y; wv[6] = w1.z; wv[7] = w1.w;
-            if (A2) {  // kernel-argument uniform
-                const float4 c0 = *reinterpret_cast<const float4*>(arow2 + k), c1 = *reinterpret_cast<const float4*>(arow2 + k + 4);
-                a2v[0] = c0.x; a2v[1] = c0.y; a2v[2] = c0.z; a2v[3] = c0.w; a2v[4] = c1.x; a2v[5] = c1.y; a2v[6] = c1.z; a2v[7] = c1.w;
-            }
+            ld8(arow + k, av);
+#pragma unroll
+            for (int v = 0; v < TN; ++v) ld8(wrow[v] + k, wv[v]);
+            if (A2) ld8(arow2 + k, a2v);  // kernel-argument uniform
         } else {
             load8(arow, k, g.K, a_vec, av);
             load8(arow2, k, g.K, a_vec, a2v);
-            load8(wrow, k, g.K, w_vec, wv);
+#pragma unroll
+            for (int v = 0; v < TN; ++v) load8(wrow[v], k, g.K, w_vec, wv[v]);
         }
     };
 #pragma unroll
@@ -145,11 +159,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(RoitrGemm g, int nx, int ny, 
     fetch(kq);
     const int kh = lane >> 5, ml = lane & 31;
     const float4* ar = reinterpret_cast<const float4*>(As + (kh * BM + wm * 32 + ml) * LDR);
-    const float4* br = reinterpret_cast<const float4*>(Bs + (kh * BN + wn * 32 + ml) * LDR);
+    const float4* br = reinterpret_cast<const float4*>(Bs + (kh * TBN + wn * 32 * TN + ml) * LDR);
     float4* aw0 = reinterpret_cast<float4*>(As + (0 * BM + r) * LDR + (kq >> 1));
     float4* aw1 = reinterpret_cast<float4*>(As + (1 * BM + r) * LDR + (kq >> 1));
-    float4* bw0 = reinterpret_cast<float4*>(Bs + (0 * BN + r) * LDR + (kq >> 1));
-    float4* bw1 = reinterpret_cast<float4*>(Bs + (1 * BN + r) * LDR + (kq >> 1));
+    float4* bw0 = reinterpret_cast<float4*>(Bs + (0 * TBN + r) * LDR + (kq >> 1));
+    float4* bw1 = reinterpret_cast<float4*>(Bs + (1 * TBN + r) * LDR + (kq >> 1));
     for (int k0 = 0; k0 < g.K; k0 += BK) {
         __syncthreads();
         if (!FAST || A2) {
@@ -157,61 +171,103 @@ __global__ __launch_bounds__(256) void gemm_kernel(RoitrGemm g, int nx, int ny, 
             for (int i = 0; i < 8; ++i) av[i] += a2v[i];
         }
         *aw0 = make_float4(av[0], av[2], av[4], av[6]); *aw1 = make_float4(av[1], av[3], av[5], av[7]);
-        *bw0 = make_float4(wv[0], wv[2], wv[4], wv[6]); *bw1 = make_float4(wv[1], wv[3], wv[5], wv[7]);
+#pragma unroll
+        for (int v = 0; v < TN; ++v) {
+            bw0[v * 64 * LDR / 4] = make_float4(wv[v][0], wv[v][2], wv[v][4], wv[v][6]);
+            bw1[v * 64 * LDR / 4] = make_float4(wv[v][1], wv[v][3], wv[v][5], wv[v][7]);
+        }
         __syncthreads();
         if (k0 + BK < g.K) fetch(k0 + BK + kq);
-        float4 af[4], bf[4];
+        if (TN == 1) {
+            float4 af[4], bf[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { af[i] = ar[i]; bf[i] = br[i]; }
+            for (int i = 0; i < 4; ++i) { af[i] = ar[i]; bf[i] = br[i]; }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[i].x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[i].y, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[i].z, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[i].w, acc, 0, 0, 0);
+            for (int i = 0; i < 4; ++i) {
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[i].x, acc[0], 0, 0, 0);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[i].y, acc[0], 0, 0, 0);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[i].z, acc[0], 0, 0, 0);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[i].w, acc[0], 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 af = ar[q];
+                float4 bf[TN];
+#pragma unroll
+                for (int v = 0; v < TN; ++v) bf[v] = br[v * 32 * LDR / 4 + q];
+#pragma unroll
+                for (int v = 0; v < TN; ++v) {
+                    acc[v] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.x, bf[v].x, acc[v], 0, 0, 0);
+                    acc[v] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.y, bf[v].y, acc[v], 0, 0, 0);
+                    acc[v] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.z, bf[v].z, acc[v], 0, 0, 0);
+                    acc[v] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.w, bf[v].w, acc[v], 0, 0, 0);
+                }
+            }
         }
         if (FAST) __builtin_amdgcn_sched_barrier(0);  // consumers of the prefetched registers stay below the MFMAs
     }
     if (LN) {
-        static_assert(65 * BM <= 2 * BM * LDR + 2 * BN * LDR, "row-major tile must fit the staging LDS");
-        __syncthreads();   // every wave is done with the operand images
-        float* tile = smem;   // [64][65]
-        {
-            const int col = wn * 32 + (lane & 31);
-            const float bv = bias ? bias[col] : 0.f;
+        float* tile_ = smem;   // [RP][TBN + 1]
+        float gam[TN], bet[TN];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int rl = wm * 32 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
-                tile[rl * 65 + col] = acc[i] * g.alpha + bv;
+        for (int i = 0; i < TN; ++i) { gam[i] = g.ln_gamma[lane + 64 * i]; bet[i] = g.ln_beta[lane + 64 * i]; }
+        for (int pass = 0; pass < BM / RP; ++pass) {
+            __syncthreads();   // every wave is done with the operand images / the previous pass
+            if (RP == BM || wm == pass) {
+#pragma unroll
+                for (int v = 0; v < TN; ++v) {
+                    const int col = (wn * TN + v) * 32 + (lane & 31);
+                    const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const int rl = (RP == BM ? wm * 32 : 0) + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+                        tile_[rl * (TBN + 1) + col] = acc[v][i] * g.alpha + bv;
+                    }
+                }
             }
-        }
-        __syncthreads();
-        const float gam = g.ln_gamma[lane], bet = g.ln_beta[lane];
-        for (int rl = wave; rl < BM; rl += 4) {
-            const int row = m0 + rl;
-            if (row >= g.M) break;   // wave-uniform
-            float t = tile[rl * 65 + lane];
-            if (g.ln_res) t += g.ln_res[(size_t)(g.ln_res_idx ? g.ln_res_idx[row] : row) * 64 + lane];
-            const float mean = wave_sum(t) / 64.0f;
-            const float d = t - mean;
-            const float rstd = 1.0f / sqrtf(wave_sum(d * d) / 64.0f + g.ln_eps);
-            float y = d * rstd * gam + bet;
-            if (g.ln_post) y += g.ln_post[(size_t)row * 64 + lane];
-            if (g.ln_relu) y = fmaxf(y, 0.f);
-            C[(size_t)row * g.ldc + lane] = y;
+            __syncthreads();
+            for (int rl = wave; rl < RP; rl += 4) {
+                const int row = m0 + pass * RP + rl;
+                if (row >= g.M) break;   // wave-uniform
+                const float* rr = g.ln_res ? g.ln_res + (size_t)(g.ln_res_idx ? g.ln_res_idx[row] : row) * TBN : nullptr;
+                float t[TN];
+                float s_ = 0.f;
+#pragma unroll
+                for (int i = 0; i < TN; ++i) {
+                    t[i] = tile_[rl * (TBN + 1) + lane + 64 * i];
+                    if (rr) t[i] += rr[lane + 64 * i];
+                    s_ += t[i];
+                }
+                const float mean = wave_sum(s_) / (float)TBN;
+                float q_ = 0.f;
+#pragma unroll
+                for (int i = 0; i < TN; ++i) { const float d = t[i] - mean; q_ += d * d; }
+                const float rstd = 1.0f / sqrtf(wave_sum(q_) / (float)TBN + g.ln_eps);
+#pragma unroll
+                for (int i = 0; i < TN; ++i) {
+                    float y = (t[i] - mean) * rstd * gam[i] + bet[i];
+                    if (g.ln_post) y += g.ln_post[(size_t)row * TBN + lane + 64 * i];
+                    if (g.ln_relu) y = fmaxf(y, 0.f);
+                    C[(size_t)row * g.ldc + lane + 64 * i] = y;
+                }
+            }
         }
         return;
     }
-    const int col = n0 + wn * 32 + (lane & 31);
-    if (col < g.N) {
-        const float bv = bias ? bias[col] : 0.f;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int row = m0 + wm * 32 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
-            if (row < g.M) {
-                float v = acc[i] * g.alpha + bv;
-                if (g.relu) v = fmaxf(v, 0.f);
-                C[(size_t)row * g.ldc + col] = v;
+    for (int v = 0; v < TN; ++v) {
+        const int col = n0 + (wn * TN + v) * 32 + (lane & 31);
+        if (col < g.N) {
+            const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int row = m0 + wm * 32 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+                if (row < g.M) {
+                    float x = acc[v][i] * g.alpha + bv;
+                    if (g.relu) x = fmaxf(x, 0.f);
+                    C[(size_t)row * g.ldc + col] = x;
+                }
             }
         }
     }
@@ -242,14 +298,16 @@ extern "C" int roitr_gemm(const RoitrGemm* g, hipStream_t stream)
 {
     if (g->M <= 0 || g->N <= 0 || g->batch <= 0) return ROITR_OK;
     if (g->K <= 0 || !g->A || !g->W || !g->C) return ROITR_ERR_ARG;
-    const int nx = div_up(g->N, BN), ny = div_up(g->M, BM);
+    auto al16 = [](const void* p, long stride_floats) { return ((uintptr_t)p & 15) == 0 && (stride_floats % 4) == 0; };
+    const bool fast = g->K % BK == 0 && g->K <= ZERO_ROW_LEN && g->lda % 4 == 0 && g->ldw % 4 == 0 && al16(g->A, g->sA) && al16(g->W, g->sW) &&
+                      (!g->A2 || al16(g->A2, g->sA));
+    const int tn = g->ln_gamma ? g->N / BN : 1;   // LayerNorm epilogue: one block spans the row
+    if (g->ln_gamma && (g->N % BN || (tn != 1 && tn != 2 && tn != 4) || g->batch != 1 || g->seg_off || g->relu || !g->ln_beta)) return ROITR_ERR_UNSUPPORTED;
+    const int nx = div_up(g->N, BN * tn), ny = div_up(g->M, BM);
     const long Tl = (long)nx * ny * g->batch;
     if (Tl > 0x7ffffff0L) return ROITR_ERR_UNSUPPORTED;
     const int T = (int)Tl;
     const unsigned grid = (unsigned)xcd_grid(T);
-    auto al16 = [](const void* p, long stride_floats) { return ((uintptr_t)p & 15) == 0 && (stride_floats % 4) == 0; };
-    const bool fast = g->K % BK == 0 && g->K <= ZERO_ROW_LEN && g->lda % 4 == 0 && g->ldw % 4 == 0 && al16(g->A, g->sA) && al16(g->W, g->sW) &&
-                      (!g->A2 || al16(g->A2, g->sA));
     roitr_prof_begin(ROITR_PROF_GEMM, 2.0 * g->M * g->N * (double)g->K * g->batch, stream);
     // Measured and dropped (A/B on the forward bench): 64x128 / 128x128 multi-accumulator tiles (19.7 / 22.0 vs 16.9 ms of
     // GEMM per 128-pair forward), two K-slabs per barrier pair (7.9 vs 7.5 ms at 32 pairs), and a persistent-block
@@ -261,11 +319,12 @@ extern "C" int roitr_gemm(const RoitrGemm* g, hipStream_t stream)
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (shapes) { hipEventCreate(&e0); hipEventCreate(&e1); hipEventRecord(e0, stream); }
     if (g->ln_gamma) {
-        if (g->N != BN || g->batch != 1 || g->seg_off || g->relu || !g->ln_beta) return ROITR_ERR_UNSUPPORTED;
-        if (fast) gemm_kernel<true, true><<<grid, 256, 0, stream>>>(*g, nx, ny, T);
-        else gemm_kernel<false, true><<<grid, 256, 0, stream>>>(*g, nx, ny, T);
-    } else if (fast) gemm_kernel<true, false><<<grid, 256, 0, stream>>>(*g, nx, ny, T);
-    else gemm_kernel<false, false><<<grid, 256, 0, stream>>>(*g, nx, ny, T);
+        if (!fast) { if (tn != 1) return ROITR_ERR_UNSUPPORTED; gemm_kernel<false, 1, true><<<grid, 256, 0, stream>>>(*g, nx, ny, T); }
+        else if (tn == 1) gemm_kernel<true, 1, true><<<grid, 256, 0, stream>>>(*g, nx, ny, T);
+        else if (tn == 2) gemm_kernel<true, 2, true><<<grid, 256, 0, stream>>>(*g, nx, ny, T);
+        else gemm_kernel<true, 4, true><<<grid, 256, 0, stream>>>(*g, nx, ny, T);
+    } else if (fast) gemm_kernel<true, 1, false><<<grid, 256, 0, stream>>>(*g, nx, ny, T);
+    else gemm_kernel<false, 1, false><<<grid, 256, 0, stream>>>(*g, nx, ny, T);
     if (shapes) {
         hipEventRecord(e1, stream); hipEventSynchronize(e1);
         float ms = 0; hipEventElapsedTime(&ms, e0, e1); hipEventDestroy(e0); hipEventDestroy(e1);

@@ -152,26 +152,28 @@ def test_ragged_forward_matches_oracle():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("M,K,with_res,with_idx,with_post,relu", [(1000, 64, True, False, True, True), (777, 128, True, True, False, False),
-                                                                   (64, 1, False, False, False, True), (130, 40, True, False, False, False)])
-def test_linear_layernorm_fused_epilogue(M, K, with_res, with_idx, with_post, relu):
+@pytest.mark.parametrize("M,K,with_res,with_idx,with_post,relu,N", [(1000, 64, True, False, True, True, 64), (777, 128, True, True, False, False, 64),
+                                                                     (64, 1, False, False, False, True, 64), (130, 40, True, False, False, False, 64),
+                                                                     (900, 128, True, True, True, True, 128), (333, 512, True, False, False, False, 256),
+                                                                     (70, 256, False, False, True, True, 256)])
+def test_linear_layernorm_fused_epilogue(M, K, with_res, with_idx, with_post, relu, N):
     """GEMM with the LayerNorm epilogue (nn.Linear -> + residual -> nn.LayerNorm -> + identity -> ReLU in one launch,
     attention.py:319 / model/model.py:138-140) against the plain fp32 torch formula and against the two-launch path."""
     from roitr_amd import ops
     g = torch.Generator().manual_seed(5)
     x = torch.randn(M, K, generator=g).cuda()
-    w = (torch.randn(64, K, generator=g) / max(K, 1) ** 0.5).cuda()
-    b = torch.randn(64, generator=g).cuda()
-    gam, bet = torch.randn(64, generator=g).cuda(), torch.randn(64, generator=g).cuda()
+    w = (torch.randn(N, K, generator=g) / max(K, 1) ** 0.5).cuda()
+    b = torch.randn(N, generator=g).cuda()
+    gam, bet = torch.randn(N, generator=g).cuda(), torch.randn(N, generator=g).cuda()
     R = M + 13
-    res = torch.randn(R, 64, generator=g).cuda() if with_res else None
+    res = torch.randn(R, N, generator=g).cuda() if with_res else None
     idx = torch.randint(0, R, (M,), generator=g).cuda() if with_idx else None
-    post = torch.randn(M, 64, generator=g).cuda() if with_post else None
+    post = torch.randn(M, N, generator=g).cuda() if with_post else None
     got = ops.linear_layernorm(x, w, b, gam, bet, res=res, res_idx=idx, post=post, relu=relu)
     t = x.double() @ w.double().T + b.double()
     if res is not None:
         t = t + (res[idx.long()] if idx is not None else res[:M]).double()
-    ref = torch.nn.functional.layer_norm(t, (64,), gam.double(), bet.double(), 1e-5)
+    ref = torch.nn.functional.layer_norm(t, (N,), gam.double(), bet.double(), 1e-5)
     if post is not None:
         ref = ref + post.double()
     if relu:
