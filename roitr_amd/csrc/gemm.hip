@@ -313,6 +313,8 @@ extern "C" int roitr_gemm(const RoitrGemm* g, hipStream_t stream)
     // GEMM per 128-pair forward), two K-slabs per barrier pair (7.9 vs 7.5 ms at 32 pairs), and a persistent-block
     // variant that opens the next tile (row pointers + first slab in flight) before the store epilogue (18.3-19.8 vs
     // 16.9 ms): at K = 64..512 the hardware dispatcher overlapping 7 resident 64x64 blocks per CU beats all of them.
+    // Prefetch distance 2 (two alternating register sets) changes nothing either (45.7 vs 45.1 ms per forward): the
+    // staging loads are not what the waves wait for.
     // The kernel alone reaches 106 TFLOP/s at K = 2048 and 78 at K = 256 (scripts/bench_gemm.py); the no-memory MFMA
     // ceiling measured on this part is 143-157 TFLOP/s (scripts/micro/mfma_peak.hip).
     static const bool shapes = getenv("ROITR_GEMM_SHAPES") != nullptr;  // debug: per-shape timing table at exit (synchronous)
