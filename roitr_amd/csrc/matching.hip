@@ -381,15 +381,45 @@ __global__ void patch_gather_kernel(RoitrPatch a)
 // is run in the exponential domain with per-row max shifts: K'_ij = exp(S_ij - m_i), b = e^v,
 // a~_i = mu_i / (K' b)_i (= e^{u_i + m_i}), b_j = nu_j / (K'^T a~)_j -- the same iteration, no exp/log inside the loop.
 // Lane l keeps row l AND column l of the 64x64 block of K' in registers (128 VGPRs); the dustbin row/column are one
-// value per lane.  An iteration is two 64-term register dot products per lane against a vector broadcast out of LDS
-// (ds_read_b128, all lanes the same address) plus two DPP wave sums for the dustbin: no block barrier, no shuffles.
+// value per lane.  An iteration is two 64-term dot products per lane against a vector that lives one element per
+// lane: its elements reach the FMAs through DPP row rotations (a source modifier of the FMA) and three ds_bpermute
+// row-block shifts -- no LDS reads, no barrier, no broadcast traffic (the first version read the vector back out of LDS
+// with 32 ds_read_b128 per iteration and was bound by LDS bandwidth: 1.9 ms per 128-pair forward).
 // Masked rows/cols carry mu = 0 / K' = 0 exactly (the reference's -1e6 entries underflow to 0 in its logsumexp too).
 // The loop stops early only when b reproduced itself bit for bit (then every later iterate is identical).
 constexpr int OTN = 65;
+// ACC += KV * (B of lane (row, (col - N) & 15)): the DPP row rotate rides as a source modifier of the FMA (hipcc emits a
+// separate v_mov_b32_dpp per term from the builtin, which doubles the VALU work of the loop).  B is always written
+// several instructions before its first use here (the three ds_bpermute sit in between), which covers the
+// VALU-write -> DPP-read hazard the assembler cannot see inside inline asm.
+#define OT_FMAC_DPP(ACC, B, KV, N_) asm volatile("v_fmac_f32_dpp %0, %1, %2 row_ror:" #N_ " row_mask:0xf bank_mask:0xf" : "+v"(ACC) : "v"(B), "v"(KV))
+// s0..s3 += sum_n ror16<n>(B) * KARR[16 T + n]: one 16-lane row block of a 64-term dot product whose vector operand is
+// distributed over the lanes (lane j holds element j)
+#define OT_TERM(ACC, B, KARR, T_, N_) OT_FMAC_DPP(ACC, B, KARR[(T_) * 16 + (N_)], N_)
+#define OT_BLOCK(B, KARR, T_)                                                                                              \
+    s0 = fmaf(B, KARR[(T_) * 16], s0); OT_TERM(s1, B, KARR, T_, 1); OT_TERM(s2, B, KARR, T_, 2); OT_TERM(s3, B, KARR, T_, 3);     \
+    OT_TERM(s0, B, KARR, T_, 4); OT_TERM(s1, B, KARR, T_, 5); OT_TERM(s2, B, KARR, T_, 6); OT_TERM(s3, B, KARR, T_, 7);     \
+    OT_TERM(s0, B, KARR, T_, 8); OT_TERM(s1, B, KARR, T_, 9); OT_TERM(s2, B, KARR, T_, 10); OT_TERM(s3, B, KARR, T_, 11);   \
+    OT_TERM(s0, B, KARR, T_, 12); OT_TERM(s1, B, KARR, T_, 13); OT_TERM(s2, B, KARR, T_, 14); OT_TERM(s3, B, KARR, T_, 15)
+// K . x for the lane-distributed 64-vector x: the three other row blocks of x arrive by ds_bpermute (LDS crossbar, no
+// LDS storage), every product is then one DPP-modified FMA -- no LDS reads in the Sinkhorn loop at all
+__device__ __forceinline__ float ot_dot64(const float (&KARR)[64], float x, float init, int lane)
+{
+    const float x1 = __int_as_float(__builtin_amdgcn_ds_bpermute(((lane + 16) & 63) << 2, __float_as_int(x)));
+    const float x2 = __int_as_float(__builtin_amdgcn_ds_bpermute(((lane + 32) & 63) << 2, __float_as_int(x)));
+    const float x3 = __int_as_float(__builtin_amdgcn_ds_bpermute(((lane + 48) & 63) << 2, __float_as_int(x)));
+    float s0 = init, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    asm volatile("s_nop 1" : : "v"(x), "v"(s1), "v"(s2), "v"(s3));   // 2 wait states between the VALU write of x and its first DPP read
+    OT_BLOCK(x, KARR, 0);
+    OT_BLOCK(x1, KARR, 1);
+    OT_BLOCK(x2, KARR, 2);
+    OT_BLOCK(x3, KARR, 3);
+    return (s0 + s1) + (s2 + s3);
+}
 __global__ __launch_bounds__(64) void ot_kernel(RoitrOT a, unsigned long long* stats)
 {
     __shared__ float T[64][65];
-    __shared__ __attribute__((aligned(16))) float av[64], bv[64];
+    __shared__ __attribute__((aligned(16))) float av[64];
     const int patch = blockIdx.x;
     const int pair = patch / a.num_corr, p = patch % a.num_corr;
     const int lane = threadIdx.x;
@@ -423,39 +453,34 @@ __global__ __launch_bounds__(64) void ot_kernel(RoitrOT a, unsigned long long* s
     const float kdr = cml ? 1.0f : 0.f;               // K'[64][l] = exp(alpha - m_64), m_64 = alpha
     const float kdd = 1.0f;                           // K'[64][64]
     __syncthreads();
+    // rotated register order: slot 16 t + n of lane (R, c) pairs with vector element ((R + t) & 3) * 16 + ((c - n) & 15),
+    // the element DPP row_ror:n delivers from row block t of the vector
+    {
+        const int R = lane >> 4, c = lane & 15;
 #pragma unroll
-    for (int i = 0; i < 64; ++i) KC[i] = T[i][lane];
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int n = 0; n < 16; ++n) {
+                const int e = ((R + t) & 3) * 16 + ((c - n) & 15);
+                KR[t * 16 + n] = T[lane][e];
+                KC[t * 16 + n] = T[e][lane];
+            }
+    }
     // mu_i = exp(log_mu_i), nu likewise (modules.py:55-63)
     const float mu = rml ? expf(norm) : 0.f, nu = cml ? expf(norm) : 0.f;
     const float mu64 = expf(logf((float)nvc) + norm), nu64 = expf(logf((float)nvr) + norm);
     float al = 0.f, a64 = 0.f, bl = cml ? 1.0f : 0.f, b64 = 1.0f;   // v = 0
-    bv[lane] = bl;
-    const float4* av4 = reinterpret_cast<const float4*>(av);
-    const float4* bv4 = reinterpret_cast<const float4*>(bv);
     for (int it = 0; it < a.num_iter; ++it) {
-        __syncthreads();
-        float r0 = krd * b64, r1 = 0.f, r2 = 0.f, r3 = 0.f;
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const float4 t = bv4[q];
-            r0 = fmaf(KR[4 * q], t.x, r0); r1 = fmaf(KR[4 * q + 1], t.y, r1); r2 = fmaf(KR[4 * q + 2], t.z, r2); r3 = fmaf(KR[4 * q + 3], t.w, r3);
-        }
-        al = rml ? mu / ((r0 + r1) + (r2 + r3)) : 0.f;
+        // the dot products are cross-lane operations: evaluated by ALL lanes, outside the masked selects
+        const float rs = ot_dot64(KR, bl, krd * b64, lane);
+        al = rml ? mu / rs : 0.f;
         a64 = mu64 / (wave_sum(kdr * bl) + kdd * b64);
-        av[lane] = al;
-        __syncthreads();
-        float c0 = kdr * a64, c1 = 0.f, c2 = 0.f, c3 = 0.f;
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const float4 t = av4[q];
-            c0 = fmaf(KC[4 * q], t.x, c0); c1 = fmaf(KC[4 * q + 1], t.y, c1); c2 = fmaf(KC[4 * q + 2], t.z, c2); c3 = fmaf(KC[4 * q + 3], t.w, c3);
-        }
-        const float bn = cml ? nu / ((c0 + c1) + (c2 + c3)) : 0.f;
+        const float cs = ot_dot64(KC, al, kdr * a64, lane);
+        const float bn = cml ? nu / cs : 0.f;
         const float b64n = nu64 / (wave_sum(krd * al) + kdd * a64);
         const bool same = __ballot(__float_as_int(bn) != __float_as_int(bl)) == 0 && __float_as_int(b64n) == __float_as_int(b64);
         bl = bn; b64 = b64n;
         if (same) { if (stats && lane == 0) atomicAdd(stats + 1, (unsigned long long)(a.num_iter - 1 - it)); break; }
-        bv[lane] = bl;
     }
     if (stats && lane == 0) atomicAdd(stats, 1ull);
     // outputs = S + u + v - norm  with u_i = log(a~_i) - m_i, v_j = log(b_j)  (modules.py:27,66-67)
