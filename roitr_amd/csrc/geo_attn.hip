@@ -346,6 +346,68 @@ __global__ __launch_bounds__(256, R <= 20 ? 3 : 2) void mha_geo_kernel(RoitrMha 
         a.ebar[((size_t)row * NH + h) * C + tid] = (red[0][h * C + tid] + red[1][h * C + tid]) + (red[2][h * C + tid] + red[3][h * C + tid]);
 }
 
+
+// ------------------------------------------------------------------ plain multi-head attention (cross layers), C = 256, 4 heads
+// geoattention.py:26-66 on the same lane = channel-quad layout as mha_geo_kernel: key rows are read coalesced (one
+// float4 per lane, head = DPP row), the four waves split the keys, values are accumulated by thread = channel.
+__global__ __launch_bounds__(256) void mha_plain_kernel(RoitrMha a)
+{
+    constexpr int NH = 4, NKP = 128;
+    __shared__ float sc[NH][NKP];
+    const int row = a.q_row0 + blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hl = lane >> 4;
+    const int cl = a.cloud_of_row[row];
+    const int kc = a.partner ? a.partner[cl] : cl;
+    const int ks = kc == 0 ? 0 : a.offset[kc - 1], nk = a.offset[kc] - ks;
+    const float4 qv = reinterpret_cast<const float4*>(a.q + (size_t)row * a.ldq)[lane];
+    const float* kbase = a.k + (size_t)ks * a.ldk + lane * 4;
+    for (int j0 = wave; j0 < nk; j0 += 16) {   // 4 keys of this wave per trip, loads issued together
+        float4 kv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = j0 + 4 * u;
+            kv[u] = *reinterpret_cast<const float4*>(kbase + (size_t)(j < nk ? j : nk - 1) * a.ldk);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = j0 + 4 * u;
+            const float s = row_allsum(dot4(qv, kv[u]));
+            if (j < nk && (lane & 15) == 0) sc[hl][j] = s * a.scale;
+        }
+    }
+    __syncthreads();
+    {   // softmax over the keys: wave = head
+        const int h = wave;
+        float e1[NKP / 64];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int u = 0; u < NKP / 64; ++u) { const int j = lane + 64 * u; e1[u] = j < nk ? sc[h][j] : -INFINITY; mx = fmaxf(mx, e1[u]); }
+        mx = wave_max(mx);
+        float sm = 0.f;
+#pragma unroll
+        for (int u = 0; u < NKP / 64; ++u) { const int j = lane + 64 * u; e1[u] = j < nk ? expf(e1[u] - mx) : 0.f; sm += e1[u]; }
+        sm = wave_sum(sm);
+#pragma unroll
+        for (int u = 0; u < NKP / 64; ++u) { const int j = lane + 64 * u; if (j < nk) sc[h][j] = e1[u] / sm; }
+    }
+    __syncthreads();
+    {
+        const int h = tid >> 6;
+        const float* vp = a.v + (size_t)ks * a.ldv + tid;
+        float acc = 0.f;
+        int j = 0;
+        for (; j + 8 <= nk; j += 8) {
+            float vv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) vv[u] = vp[(size_t)(j + u) * a.ldv];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc = fmaf(sc[h][j + u], vv[u], acc);
+        }
+        for (; j < nk; ++j) acc = fmaf(sc[h][j], vp[(size_t)j * a.ldv], acc);
+        a.out[(size_t)row * a.ldo + tid] = acc;
+    }
+}
+
 }  // namespace
 
 extern "C" int roitr_geo_indices(int rows, const float* pts, const int* offset, const int* cloud_of_row, const long* eoff,
@@ -372,7 +434,10 @@ extern "C" int roitr_mha(const RoitrMha* a, hipStream_t stream)
     // self attention over E at the model's width: the single-pass register-resident kernel (nk_max bounds every cloud)
     const bool geo = a->E && !a->partner && a->C == 256 && a->heads == 4 && a->ldq % 4 == 0 && a->ldk % 4 == 0 && a->nk_max <= 128 &&
                      getenv("ROITR_MHA_GENERIC") == nullptr;
-    if (geo && a->nk_max <= 80) mha_geo_kernel<20><<<a->q_rows, 256, 0, stream>>>(*a);
+    const bool plain = !a->E && a->C == 256 && a->heads == 4 && a->ldq % 4 == 0 && a->ldk % 4 == 0 && a->nk_max <= 128 &&
+                       getenv("ROITR_MHA_GENERIC") == nullptr;
+    if (plain) mha_plain_kernel<<<a->q_rows, 256, 0, stream>>>(*a);
+    else if (geo && a->nk_max <= 80) mha_geo_kernel<20><<<a->q_rows, 256, 0, stream>>>(*a);
     else if (geo) mha_geo_kernel<32><<<a->q_rows, 256, 0, stream>>>(*a);
     else
     mha_kernel<<<a->q_rows, 256, floats * sizeof(float), stream>>>(*a);
