@@ -513,16 +513,18 @@ __global__ __launch_bounds__(256) void knn_lane_kernel(int m, int nsample, int b
         }
     };
     auto scan = [&](int s, int e) {
-        // four candidate loads in flight per lane (clamped addresses, masked distances): the loop is otherwise one
+        // NF candidate loads in flight per lane (clamped addresses, masked distances): the loop is otherwise one
         // dependent L2 round trip per candidate
-        for (int p = s; p < e; p += 4) {
-            const float4 c0_ = sorted[p], c1_ = sorted[min(p + 1, e - 1)], c2_ = sorted[min(p + 2, e - 1)], c3_ = sorted[min(p + 3, e - 1)];
-            const float d0 = sqdist3(qx, qy, qz, c0_.x, c0_.y, c0_.z);
-            const float d1 = p + 1 < e ? sqdist3(qx, qy, qz, c1_.x, c1_.y, c1_.z) : INFINITY;
-            const float d2_ = p + 2 < e ? sqdist3(qx, qy, qz, c2_.x, c2_.y, c2_.z) : INFINITY;
-            const float d3 = p + 3 < e ? sqdist3(qx, qy, qz, c3_.x, c3_.y, c3_.z) : INFINITY;
-            offer(d0, __float_as_int(c0_.w)); offer(d1, __float_as_int(c1_.w));
-            offer(d2_, __float_as_int(c2_.w)); offer(d3, __float_as_int(c3_.w));
+        constexpr int NF = 8;
+        for (int p = s; p < e; p += NF) {
+            float4 c[NF];
+#pragma unroll
+            for (int u = 0; u < NF; ++u) c[u] = sorted[min(p + u, e - 1)];
+#pragma unroll
+            for (int u = 0; u < NF; ++u) {
+                const float dd = p + u < e ? sqdist3(qx, qy, qz, c[u].x, c[u].y, c[u].z) : INFINITY;
+                offer(dd, __float_as_int(c[u].w));
+            }
         }
     };
     const float margin = 2e-4f * g.h;
