@@ -258,6 +258,18 @@ int roitr_engine_set_inject(void* engine, const char* name, const void* device_p
 /* level sizes the engine will use for a cloud of n points: out[0..3] (model/model.py:59-62 floor rule) */
 void roitr_level_sizes(int n, int* out4);
 
+
+/* ------------------------------------------------------------------ evaluators, batched over pairs
+ * lib/loss.py:195-206 Evaluator.evaluate_fine == registration/benchmark_utils.py:69-77: pair b owns correspondences
+ * [starts[b], starts[b+1]) of src_pts / tgt_pts; inliers[b] = #{ ||rot_b s + trans_b - t|| < radius }. */
+int roitr_inlier_counts(int pairs, const int* starts, const float* src_pts, const float* tgt_pts, const float* rot,
+                        const float* trans, float radius, int* inliers, roitr_stream_t stream);
+/* lib/loss.py:170-193 Evaluator.evaluate_coarse: hits[b] = #{ i < n_corr[b] : (tgt_corr[b,i], src_corr[b,i]) is one of
+ * the gt_count[b] ground-truth node pairs gt_idx[b,:,(tgt,src)] whose overlap exceeds acceptance_overlap }. */
+int roitr_coarse_hits(int pairs, int num_corr, const int* n_corr, const int* tgt_corr, const int* src_corr, int gt_cap,
+                      const int* gt_idx, const float* gt_overlaps, const int* gt_count, float acceptance_overlap, int* hits,
+                      roitr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

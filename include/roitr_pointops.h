@@ -85,6 +85,18 @@ int roitr_knnquery_ex(int b, int n, int m, int nsample, const float* xyz, const 
                       const float* ref_normals, const float* query_normals, int use_grid, int m_capacity, void* ws,
                       roitr_stream_t stream);
 
+/* ------------------------------------------------------------------ input preparation
+ * dataset/tdmatch.py:120-127: open3d estimate_normals(KDTreeSearchParamKNN(knn)) + dataset/common.py:312-320 normal_redirect.
+ * normals (n,3) = unit eigenvector of the smallest eigenvalue of the covariance of the knn nearest points (the point
+ * itself included), flipped towards view_point (3 host floats; NULL = leave Open3D's arbitrary sign).  use_grid as in
+ * roitr_knnquery_ex (this call builds the grid itself).  ws: roitr_normals_workspace_bytes(b, n, knn). */
+size_t roitr_normals_workspace_bytes(int b, int n, int knn);
+int roitr_estimate_normals(int b, int n, const float* xyz, const int* offset, int knn, int use_grid, const float* view_point,
+                           float* normals, void* ws, roitr_stream_t stream);
+/* dataset/common.py:312-320 on its own: out = (dot(view_point - p, n) < 0) ? -n : n */
+int roitr_normal_redirect(int n, const float* xyz, const float* normals_in, const float* view_point, float* normals_out,
+                          roitr_stream_t stream);
+
 int roitr_grouping_forward(int m, int nsample, int c, const float* input, const int* idx, float* output, roitr_stream_t stream);
 int roitr_grouping_backward(int m, int nsample, int c, const float* grad_output, const int* idx, float* grad_input, roitr_stream_t stream);
 int roitr_interpolation_forward(int n, int c, int k, const float* input, const int* idx, const float* weight, float* output, roitr_stream_t stream);

@@ -46,3 +46,8 @@ def ptr(t):
 def stream_ptr():
     import torch
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def c_float(x):
+    """A by-value float argument (ctypes would otherwise pass a Python float as a double)."""
+    return ctypes.c_float(float(x))

@@ -21,6 +21,8 @@ def main():
     ap.add_argument("--n-points", type=int, default=5000)
     ap.add_argument("--snapshot-dir", default="snapshot")
     ap.add_argument("--pairs-per-forward", type=int, default=8)
+    ap.add_argument("--evaluate", action="store_true", help="report mean PIR / IR (lib/loss.py Evaluator) computed on the device")
+    ap.add_argument("--estimate-normals", action="store_true", help="recompute the normals on the GPU (open3d knn=33 + normal_redirect)")
     args = ap.parse_args()
     config = Config(load_config(args.config))
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
@@ -41,7 +43,11 @@ def main():
                 sd[k].copy_(torch.from_numpy(closed_form_param(k, tuple(shape))))
         print(f"[roitr_amd] checkpoint {ckpt!r} not found: using closed-form weights (roitr_amd/weights.py)")
     data = SyntheticPairs(args.synthetic, args.n_points)
-    counts = Tester(config, model, data, args.snapshot_dir, args.pairs_per_forward, rank, world).test()
+    tester = Tester(config, model, data, args.snapshot_dir, args.pairs_per_forward, rank, world, evaluate=args.evaluate,
+                    estimate_normals=args.estimate_normals)
+    counts = tester.test()
+    if rank == 0 and tester.metrics:
+        print(f"[roitr_amd] PIR {tester.metrics['PIR']:.4f}  IR {tester.metrics['IR']:.4f}  over {tester.metrics['pairs']} pairs")
     if rank == 0:
         print(f"[roitr_amd] wrote {args.synthetic} result files under {args.snapshot_dir}/{config.benchmark}; "
               f"correspondences per rank: {counts}")

@@ -24,11 +24,17 @@ def load_pretrain(model, path):
 
 
 class Tester:
-    def __init__(self, config, model, dataset, snapshot_dir="snapshot", pairs_per_forward=8, rank=0, world=1):
+    def __init__(self, config, model, dataset, snapshot_dir="snapshot", pairs_per_forward=8, rank=0, world=1, evaluate=False,
+                 estimate_normals=False, view_point=(0.0, 0.0, 0.0)):
+        """evaluate: also compute PIR / IR per pair on the device (lib/loss.py:169-213 Evaluator) and return their means.
+        estimate_normals: ignore the dataset's normals and recompute them on the GPU from the points the way the
+        reference's dataset code does (open3d estimate_normals(knn=33) + normal_redirect, dataset/tdmatch.py:120-127)."""
         self.config, self.model, self.dataset = config, model, dataset
         self.snapshot_dir = snapshot_dir
         self.pairs_per_forward = pairs_per_forward
         self.rank, self.world = rank, world
+        self.evaluate, self.estimate_normals, self.view_point = evaluate, estimate_normals, view_point
+        self.metrics = None
 
     def _to_device(self, item, device):
         out = {}
@@ -48,12 +54,26 @@ class Tester:
         def load(s):
             ids = mine[s:s + self.pairs_per_forward]
             items = [self._to_device(self.dataset[i], device) for i in ids]
+            if self.estimate_normals:   # one batched call for all clouds of this forward
+                from .prep import estimate_normals
+                clouds = [it["raw_src_pcd"] for it in items] + [it["tgt_points"] for it in items]
+                off = torch.tensor([c.shape[0] for c in clouds], device=device).cumsum(0).to(torch.int32)
+                nrm = estimate_normals(torch.cat(clouds).float(), off, 33, self.view_point)
+                lo = [0] + off.tolist()
+                for k, it in enumerate(items):
+                    it["src_normals"] = nrm[lo[k]:lo[k + 1]]
+                    it["tgt_normals"] = nrm[lo[len(items) + k]:lo[len(items) + k + 1]]
             pairs = [dict(src_pcd=it["src_points"].contiguous(), tgt_pcd=it["tgt_points"].contiguous(),
                           src_feats=it["src_feats"].contiguous(), tgt_feats=it["tgt_feats"].contiguous(),
                           src_normals=it["src_normals"].contiguous(), tgt_normals=it["tgt_normals"].contiguous(),
                           rot=it["rot"], trans=it["trans"], src_raw_pcd=it["raw_src_pcd"].contiguous()) for it in items]
             return ids, items, pairs, self.model.launch_batch(pairs)
 
+        evaluator = None
+        if self.evaluate:
+            from .evaluate import Evaluator
+            evaluator = Evaluator(self.config)
+        sums = torch.zeros(3, dtype=torch.float64, device=device)   # sum IR, sum PIR, pairs
         with torch.no_grad():
             starts = list(range(0, len(mine), self.pairs_per_forward))
             nxt = load(starts[0]) if starts else None
@@ -61,6 +81,9 @@ class Tester:
                 ids, items, pairs, handle = nxt
                 # the next batch is loaded and enqueued before this one is unpacked and written to disk
                 nxt = load(starts[k + 1]) if k + 1 < len(starts) else None
+                if evaluator is not None:
+                    ir, pir, _, _ = evaluator.evaluate_batch(handle)
+                    sums += torch.stack([ir.double().sum(), torch.nan_to_num(pir.double()).sum(), torch.tensor(float(len(ids)), device=device, dtype=torch.float64)])
                 outs = self.model.finish_batch(handle)
                 for idx, it, p, o in zip(ids, items, pairs, outs):
                     data = dict()  # lib/tester.py:56-69
@@ -78,6 +101,11 @@ class Tester:
                         data["metric_index_list"] = it["metric_index"]
                     torch.save(data, os.path.join(out_dir, f"{idx}.pth"))
                     total_corr += int(o["corr_scores"].shape[0])
+        if evaluator is not None:
+            if torch.distributed.is_available() and torch.distributed.is_initialized():
+                torch.distributed.all_reduce(sums)   # RCCL: three doubles
+            n_eval = max(float(sums[2]), 1.0)
+            self.metrics = {"IR": float(sums[0]) / n_eval, "PIR": float(sums[1]) / n_eval, "pairs": int(sums[2])}
         return gather_counts(total_corr)
 
 

@@ -398,8 +398,63 @@ def fdmatch_golden(n=1024):
           "fine corr:", rec["out.corr_scores"].shape)
 
 
+def prep_eval_golden():
+    """dataset/common.py normal_redirect, lib/loss.py Evaluator, registration/benchmark_utils.py
+    get_inlier_ratio_correspondence on seeded inputs -> prep_eval.npz (the SURVEY.md 8f rows)."""
+    # registration/benchmark.py imports nibabel.quaternions at module level (absent here, never used on these functions)
+    nib = types.ModuleType("nibabel"); nib.quaternions = types.ModuleType("nibabel.quaternions")
+    sys.modules["nibabel"], sys.modules["nibabel.quaternions"] = nib, nib.quaternions
+    from dataset.common import normal_redirect
+    from lib.loss import Evaluator
+    from registration.benchmark_utils import get_inlier_ratio_correspondence
+    rng = np.random.default_rng(77)
+    rec = {}
+    # normal_redirect: float32 points / unit normals, three view points (one inside the cloud)
+    pts = rng.uniform(0, 2, (4000, 3)).astype(np.float32)
+    nrm = rng.normal(size=(4000, 3)); nrm = (nrm / np.linalg.norm(nrm, axis=1, keepdims=True)).astype(np.float32)
+    rec["redirect.points"], rec["redirect.normals"] = pts, nrm
+    for i, vp in enumerate([np.zeros(3), np.array([1.0, 1.0, 1.0]), np.array([-3.0, 0.5, 9.0])]):
+        rec[f"redirect.view{i}"] = vp
+        rec[f"redirect.out{i}"] = normal_redirect(pts, nrm, vp).astype(np.float32)
+    # evaluators: correspondences around the acceptance radius, ground-truth node pairs around the acceptance overlap
+    cfg = EasyDict(eval_acceptance_overlap=0.0, eval_acceptance_radius=0.1)
+    ev = Evaluator(cfg)
+    from scipy.spatial.transform import Rotation
+    for case, (nc, n_t, n_s, P) in enumerate([(3000, 78, 78, 256), (17, 20, 31, 40), (0, 16, 16, 8)]):
+        rot = Rotation.from_rotvec(rng.normal(size=3)).as_matrix().astype(np.float32)
+        trans = rng.uniform(-1, 1, (3, 1)).astype(np.float32)
+        src = rng.uniform(0, 2, (nc, 3)).astype(np.float32)
+        noise = rng.normal(size=(nc, 3)) * rng.uniform(0.0, 0.12, (nc, 1))
+        tgt = (src @ rot.T + trans.T + noise).astype(np.float32)
+        gt_idx = np.stack([rng.integers(0, n_t, 300), rng.integers(0, n_s, 300)], 1).astype(np.int64)
+        gt_ov = rng.uniform(-0.05, 0.5, 300).astype(np.float32)
+        gt_ov[::7] = 0.0
+        t_corr, s_corr = rng.integers(0, n_t, P).astype(np.int64), rng.integers(0, n_s, P).astype(np.int64)
+        t_corr[: P // 3], s_corr[: P // 3] = gt_idx[: P // 3, 0], gt_idx[: P // 3, 1]
+        od = dict(tgt_nodes=torch.zeros(n_t, 3), src_nodes=torch.zeros(n_s, 3), gt_node_corr_overlaps=torch.from_numpy(gt_ov),
+                  gt_node_corr_indices=torch.from_numpy(gt_idx), tgt_node_corr_indices=torch.from_numpy(t_corr),
+                  src_node_corr_indices=torch.from_numpy(s_corr), tgt_corr_points=torch.from_numpy(tgt), src_corr_points=torch.from_numpy(src))
+        dd = dict(rot=torch.from_numpy(rot)[None], trans=torch.from_numpy(trans)[None])
+        res = ev(od, dd)
+        pre = f"eval{case}."
+        rec.update({pre + "rot": rot, pre + "trans": trans, pre + "src": src, pre + "tgt": tgt, pre + "gt_idx": gt_idx.astype(np.int32),
+                    pre + "gt_ov": gt_ov, pre + "tgt_corr": t_corr.astype(np.int32), pre + "src_corr": s_corr.astype(np.int32),
+                    pre + "n_nodes": np.array([n_t, n_s], np.int32), pre + "PIR": np.float32(float(res["PIR"])),
+                    pre + "IR": np.float32(float(res["IR"]))})
+        if nc:
+            rec[pre + "IR_bu"] = np.float32(float(get_inlier_ratio_correspondence(torch.from_numpy(src), torch.from_numpy(tgt),
+                                                                                  torch.from_numpy(rot), torch.from_numpy(trans), 0.1)))
+    path = os.path.join(HERE, "prep_eval.npz")
+    np.savez_compressed(path, **rec)
+    print("wrote", path, "%.2f MB" % (os.path.getsize(path) / 1e6), {k: float(v) for k, v in rec.items() if k.endswith(("IR", "PIR", "IR_bu"))})
+
+
 if __name__ == "__main__":
-    if "--fdmatch" in sys.argv:
+    if "--prep-eval" in sys.argv:
+        install_stubs()
+        torch.manual_seed(0)
+        prep_eval_golden()
+    elif "--fdmatch" in sys.argv:
         sys.argv.remove("--fdmatch")
         install_stubs()
         torch.manual_seed(0)
