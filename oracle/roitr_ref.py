@@ -282,8 +282,22 @@ def fine_matching(ref_pts, src_pts, ref_masks, src_masks, score_mat, k, mutual=T
 
 
 # ------------------------------------------------------------------------------------------ whole forward
-def forward(sd, pair, cfg=None, taps=None, threads=1):
-    """RIGA_v2.forward (model/RIGA_v2.py:58-175) for one pair; sd: {state_dict key: fp32 ndarray}."""
+def forward(sd, pair, cfg=None, taps=None, threads=1, timings=None):
+    """RIGA_v2.forward (model/RIGA_v2.py:58-175) for one pair; sd: {state_dict key: fp32 ndarray}.
+    timings (optional dict): wall seconds per stage are ADDED to its keys (fps, knn_ppf, encoder, global, decoder, matching)."""
+    import time as _time
+
+    class _T:
+        def __init__(self, key):
+            self.key = key
+
+        def __enter__(self):
+            self.t0 = _time.perf_counter()
+
+        def __exit__(self, *a):
+            if timings is not None:
+                timings[self.key] = timings.get(self.key, 0.0) + _time.perf_counter() - self.t0
+
     cfg = cfg or {}
     P_ = cfg.get("num_est_coarse_corr", 256)
     limit = cfg.get("point_per_patch", 64)
@@ -306,17 +320,22 @@ def forward(sd, pair, cfg=None, taps=None, threads=1):
                 idx, p_n, n_n, o_n = np.arange(p.shape[0]), p, n, o
             else:
                 o_n = np.array([p.shape[0] // 4], np.int32)
-                idx = P.furthestsampling(p, o, o_n).astype(np.int64)
+                with _T("fps"):
+                    idx = P.furthestsampling(p, o, o_n).astype(np.int64)
                 p_n, n_n = p[idx], n[idx]
-            g_td = P.queryandgroup_idx(nsample[l], p, p_n, o, o_n, threads)
-            ppf_td = calc_ppf(p_n, n_n, p[g_td], n[g_td])
-            x = local_ppf_transformer(W, e + ".0.transformer", x, idx, g_td, ppf_td)
+            with _T("knn_ppf"):
+                g_td = P.queryandgroup_idx(nsample[l], p, p_n, o, o_n, threads)
+                ppf_td = calc_ppf(p_n, n_n, p[g_td], n[g_td])
+            with _T("encoder"):
+                x = local_ppf_transformer(W, e + ".0.transformer", x, idx, g_td, ppf_td)
             taps[f"{tag}.enc{l + 1}.0"] = x
-            g_s = P.queryandgroup_idx(nsample[l], p_n, p_n, o_n, o_n, threads)
-            ppf_s = calc_ppf(p_n, n_n, p_n[g_s], n_n[g_s])
-            for b in range(1, nblocks[l]):
-                x = block(W, f"{e}.{b}", x, g_s, ppf_s)
-                taps[f"{tag}.enc{l + 1}.{b}"] = x
+            with _T("knn_ppf"):
+                g_s = P.queryandgroup_idx(nsample[l], p_n, p_n, o_n, o_n, threads)
+                ppf_s = calc_ppf(p_n, n_n, p_n[g_s], n_n[g_s])
+            with _T("encoder"):
+                for b in range(1, nblocks[l]):
+                    x = block(W, f"{e}.{b}", x, g_s, ppf_s)
+                    taps[f"{tag}.enc{l + 1}.{b}"] = x
             lv.append(dict(p=p_n, n=n_n, x=x, g=g_s, ppf=ppf_s, down=idx))
             p, n = p_n, n_n
         return lv
@@ -326,6 +345,7 @@ def forward(sd, pair, cfg=None, taps=None, threads=1):
 
     # global transformer (geotransformer.py:94-133; ref = src side, model/model.py:214)
     g = "backbone.global_transformer"
+    _tg = _T("global"); _tg.__enter__()
     E0 = geo_embedding(W, g + ".embedding", S[3]["p"], C4)
     E1 = geo_embedding(W, g + ".embedding", T[3]["p"], C4)
     f0, f1 = W.lin(S[3]["x"], g + ".in_proj"), W.lin(T[3]["x"], g + ".in_proj")
@@ -340,6 +360,7 @@ def forward(sd, pair, cfg=None, taps=None, threads=1):
             f1 = cross_layer(W, lp, f1, f0, pos1, pos0)
         taps[f"geo.layer{i}"] = (f0, f1)
     g0, g1 = W.lin(f0, g + ".out_proj"), W.lin(f1, g + ".out_proj")
+    _tg.__exit__()
 
     def decoder_cloud(L, tag):
         """model/model.py:223-231"""
@@ -360,7 +381,9 @@ def forward(sd, pair, cfg=None, taps=None, threads=1):
             taps[f"{tag}.dec{l + 1}.1"] = x
         return x
 
-    s_x1, t_x1 = decoder_cloud(S, "src"), decoder_cloud(T, "tgt")
+    with _T("decoder"):
+        s_x1, t_x1 = decoder_cloud(S, "src"), decoder_cloud(T, "tgt")
+    _tm = _T("matching"); _tm.__enter__()
     s_d4 = S[1]["down"][S[2]["down"]][S[3]["down"]]
     src_nodes = pair["src_points"][s_d4]
     tgt_nodes = T[3]["p"]
@@ -394,6 +417,7 @@ def forward(sd, pair, cfg=None, taps=None, threads=1):
                tgt_node_corr_knn_masks=t_cm, matching_scores=ot)
     tp, sp, sc = fine_matching(t_cp, s_cp, t_cm, s_cm, ot[:, :-1, :-1], topk, True, cfg.get("fine_matching_confidence_threshold", 0.05))
     out.update(tgt_corr_points=tp, src_corr_points=sp, corr_scores=sc)
+    _tm.__exit__()
     return out
 
 
