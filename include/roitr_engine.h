@@ -133,6 +133,7 @@ typedef struct RoitrCoarse {
     float* scratch; long scratch_stride;
     int* tgt_corr; int* src_corr; float* corr_scores; int* n_corr;
     const float* xy; long xy_stride; int xy_ld;
+    int lds_cap;   /* filled in by the launcher (LDS keys per sort chunk); callers leave it 0 */
 } RoitrCoarse;
 size_t roitr_coarse_scratch_floats(int n_ref, int n_src);
 int roitr_coarse_matching(const RoitrCoarse* a, roitr_stream_t stream);

@@ -136,6 +136,65 @@ __global__ __launch_bounds__(256) void p2n_topk_kernel(const int* __restrict__ p
     }
 }
 
+constexpr int COARSE_LDS_KEYS = 16384;   // 128 KB of 64-bit keys
+// ------------------------------------------------------------------ block-wide "the `want` smallest 64-bit keys, sorted"
+// keys: LDS, lds_cap (power of two) entries.  total <= lds_cap: one bitonic sort.  Larger (e.g. 468 x 468 superpoint pairs
+// of a 30000-point cloud): the keys are sorted in LDS-sized chunks, every chunk contributes its W = pow2(want) smallest to
+// `spill` (global), and the spilled winners are reduced the same way until they fit -- the result is exactly the
+// `want` smallest keys of the whole set, ascending, in keys[0..want).
+__device__ __forceinline__ void block_bitonic_sort(unsigned long long* keys, int cap, int tid)
+{
+    for (int k = 2; k <= cap; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int e = tid; e < cap; e += 1024) {
+                const int p = e ^ j;
+                if (p > e) {
+                    const unsigned long long x = keys[e], y = keys[p];
+                    const bool up = (e & k) == 0;
+                    if ((x > y) == up) { keys[e] = y; keys[p] = x; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+template <typename KeyFn>
+__device__ __forceinline__ void block_select_smallest(KeyFn key_of, int total, int want, unsigned long long* keys, int lds_cap,
+                                                      unsigned long long* spill, int tid)
+{
+    int W = 1;
+    while (W < want) W <<= 1;
+    int count = total;
+    bool from_spill = false;
+    while (true) {
+        if (count <= lds_cap) {
+            int cap = 1;
+            while (cap < count) cap <<= 1;
+            for (int e = tid; e < cap; e += 1024) keys[e] = e < count ? (from_spill ? spill[e] : key_of(e)) : ~0ull;
+            __syncthreads();
+            block_bitonic_sort(keys, cap, tid);
+            return;
+        }
+        const int nchunks = (count + lds_cap - 1) / lds_cap;
+        for (int c = 0; c < nchunks; ++c) {
+            const int base = c * lds_cap;
+            for (int e = tid; e < lds_cap; e += 1024) {
+                const int g = base + e;
+                keys[e] = g < count ? (from_spill ? spill[g] : key_of(g)) : ~0ull;
+            }
+            __syncthreads();
+            block_bitonic_sort(keys, lds_cap, tid);
+            // chunk c's winners land at spill[c W ..): behind everything this and later chunks still read (W <= lds_cap)
+            for (int e = tid; e < W; e += 1024) spill[(size_t)c * W + e] = keys[e];
+            __syncthreads();
+        }
+        __threadfence_block();
+        count = nchunks * W;
+        from_spill = true;
+    }
+}
+
 // ------------------------------------------------------------------ CoarseMatching (model/modules.py:141-178)
 // one block (1024 threads) per pair.  ref = tgt nodes, src = src nodes (RIGA_v2.py:121).
 // scores[i][j] = exp(-square_distance(ref_i, src_j)) over mask-valid rows/cols, dual normalisation,
@@ -180,51 +239,28 @@ __global__ __launch_bounds__(1024) void coarse_match_kernel(RoitrCoarse a)
         M[e] = v;
     }
     __syncthreads();
-    // row / column sums over valid entries (sequential order within a row/col); nr + nsr <= 1024
-    {
+    // row / column sums over valid entries (sequential order within a row/col); the norms are dead from here on
+    for (int i = tid; i < nr + nsr; i += 1024) {
         float s = 0.f;
-        const int i = tid;
-        if (i < nr) { for (int j = 0; j < nsr; ++j) { const float v = M[(size_t)i * nsr + j]; if (v >= 0.f) s += v; } }
-        else if (i < nr + nsr) { const int j = i - nr; for (int r = 0; r < nr; ++r) { const float v = M[(size_t)r * nsr + j]; if (v >= 0.f) s += v; } }
-        __syncthreads();
-        if (i < nr) rowsum[i] = s; else if (i < nr + nsr) colsum[i - nr] = s;
-        __syncthreads();
+        if (i < nr) { for (int j = 0; j < nsr; ++j) { const float v = M[(size_t)i * nsr + j]; if (v >= 0.f) s += v; } rowsum[i] = s; }
+        else { const int j = i - nr; for (int r = 0; r < nr; ++r) { const float v = M[(size_t)r * nsr + j]; if (v >= 0.f) s += v; } colsum[j] = s; }
     }
+    __syncthreads();
     int nvr = 0, nvs = 0;
     for (int i = 0; i < nr; ++i) nvr += a.node_masks[t0 + i] ? 1 : 0;
     for (int j = 0; j < nsr; ++j) nvs += a.node_masks[s0 + j] ? 1 : 0;
     const int num = min(a.num_corr, nvr * nvs);
-    // keys: (~score bits, compacted flat index) ascending == score descending, reference flat order
+    // keys: (~score bits, flat index) ascending == score descending, reference flat order
     const int total = nr * nsr;
-    int cap = 1;
-    while (cap < total) cap <<= 1;
-    for (int e = tid; e < cap; e += 1024) {
-        unsigned long long key = ~0ull;
-        if (e < total) {
-            const float v = M[e];
-            if (v >= 0.f) {
-                const int i = e / nsr, j = e % nsr;
-                float sv = v;
-                if (a.dual_norm) sv = (v / (rowsum[i] + 1e-8f)) * (v / (colsum[j] + 1e-8f));
-                key = ((unsigned long long)(~__float_as_uint(sv)) << 32) | (unsigned)e;
-            }
-        }
-        keys[e] = key;
-    }
-    __syncthreads();
-    for (int k = 2; k <= cap; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int e = tid; e < cap; e += 1024) {
-                const int p = e ^ j;
-                if (p > e) {
-                    const unsigned long long x = keys[e], y = keys[p];
-                    const bool up = (e & k) == 0;
-                    if ((x > y) == up) { keys[e] = y; keys[p] = x; }
-                }
-            }
-            __syncthreads();
-        }
-    }
+    auto key_of = [&](int e) -> unsigned long long {
+        const float v = M[e];
+        if (!(v >= 0.f)) return ~0ull;
+        const int i = e / nsr, j = e % nsr;
+        float sv = v;
+        if (a.dual_norm) sv = (v / (rowsum[i] + 1e-8f)) * (v / (colsum[j] + 1e-8f));
+        return ((unsigned long long)(~__float_as_uint(sv)) << 32) | (unsigned)e;
+    };
+    block_select_smallest(key_of, total, max(num, 1), keys, a.lds_cap, reinterpret_cast<unsigned long long*>(((uintptr_t)(colsum + nsr + 8) + 7) & ~(uintptr_t)7), tid);
     for (int t = tid; t < a.num_corr; t += 1024) {
         int ri = -1, si = -1; float sv = 0.f;
         if (t < num) {
@@ -279,27 +315,10 @@ __global__ __launch_bounds__(1024) void adaptive_match_kernel(RoitrCoarse a, int
     const int kmin = min(min_num, nvalid);
     if (below < kmin) {
         // top-kmin smallest distances
-        int cap = 1;
-        while (cap < total) cap <<= 1;
-        for (int e = tid; e < cap; e += 1024) {
-            unsigned long long key = ~0ull;
-            if (e < total && M[e] >= 0.f) key = ((unsigned long long)__float_as_uint(M[e]) << 32) | (unsigned)e;
-            keys[e] = key;
-        }
-        __syncthreads();
-        for (int k = 2; k <= cap; k <<= 1) {
-            for (int j = k >> 1; j > 0; j >>= 1) {
-                for (int e = tid; e < cap; e += 1024) {
-                    const int p = e ^ j;
-                    if (p > e) {
-                        const unsigned long long x = keys[e], y = keys[p];
-                        const bool up = (e & k) == 0;
-                        if ((x > y) == up) { keys[e] = y; keys[p] = x; }
-                    }
-                }
-                __syncthreads();
-            }
-        }
+        auto key_of = [&](int e) -> unsigned long long {
+            return M[e] >= 0.f ? (((unsigned long long)__float_as_uint(M[e]) << 32) | (unsigned)e) : ~0ull;
+        };
+        block_select_smallest(key_of, total, max(kmin, 1), keys, a.lds_cap, reinterpret_cast<unsigned long long*>(((uintptr_t)(M + total + nr + nsr + 8) + 7) & ~(uintptr_t)7), tid);
         for (int t = tid; t < kmin; t += 1024) {
             const unsigned long long key = keys[t];
             const int e = (int)(unsigned)key;
@@ -641,17 +660,27 @@ extern "C" int roitr_point_to_node_partition(int b, int n_points, int n_nodes, c
     return ROITR_OK;
 }
 
-extern "C" size_t roitr_coarse_scratch_floats(int n_ref, int n_src) { return (size_t)n_ref * n_src + n_ref + n_src + 8; }
+// per pair: the (n_ref, n_src) score matrix, row / column sums, and the spill area of the chunked top-k (2 floats per
+// 64-bit key; at most ceil(total / 16384) chunks x 1024 winners in the first round)
+extern "C" size_t roitr_coarse_scratch_floats(int n_ref, int n_src)
+{
+    const size_t total = (size_t)n_ref * n_src;
+    const size_t spill_keys = total > COARSE_LDS_KEYS ? ((total + COARSE_LDS_KEYS - 1) / COARSE_LDS_KEYS) * 1024 + 64 : 0;
+    return total + n_ref + n_src + 16 + 2 * spill_keys;
+}
 
 extern "C" int roitr_coarse_matching(const RoitrCoarse* a, hipStream_t stream)
 {
     if (a->pairs <= 0) return ROITR_OK;
     long cap = 1;
     while (cap < (long)a->max_ref * a->max_src) cap <<= 1;
-    if (cap * 8 > 128 * 1024 || a->max_ref + a->max_src > 1024) return ROITR_ERR_UNSUPPORTED;
+    if (cap > COARSE_LDS_KEYS) cap = COARSE_LDS_KEYS;
+    if (a->num_corr > 1024) return ROITR_ERR_UNSUPPORTED;   // winners per chunk of the chunked top-k
     static const hipError_t attr_ = hipFuncSetAttribute((const void*)coarse_match_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
     (void)attr_;
-    coarse_match_kernel<<<a->pairs, 1024, cap * 8, stream>>>(*a);
+    RoitrCoarse c = *a;
+    c.lds_cap = (int)cap;
+    coarse_match_kernel<<<a->pairs, 1024, cap * 8, stream>>>(c);
     ROITR_LAUNCH_CHECK();
     return ROITR_OK;
 }
@@ -662,10 +691,13 @@ extern "C" int roitr_adaptive_matching(const RoitrCoarse* a, int min_num, float 
     if (!a->xy) return ROITR_ERR_ARG;
     long cap = 1;
     while (cap < (long)a->max_ref * a->max_src) cap <<= 1;
-    if (cap * 8 > 128 * 1024) return ROITR_ERR_UNSUPPORTED;
+    if (cap > COARSE_LDS_KEYS) cap = COARSE_LDS_KEYS;
+    if (min_num > 1024) return ROITR_ERR_UNSUPPORTED;
     static const hipError_t attr_ = hipFuncSetAttribute((const void*)adaptive_match_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
     (void)attr_;
-    adaptive_match_kernel<<<a->pairs, 1024, cap * 8, stream>>>(*a, min_num, threshold);
+    RoitrCoarse c = *a;
+    c.lds_cap = (int)cap;
+    adaptive_match_kernel<<<a->pairs, 1024, cap * 8, stream>>>(c, min_num, threshold);
     ROITR_LAUNCH_CHECK();
     return ROITR_OK;
 }

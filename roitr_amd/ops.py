@@ -44,7 +44,7 @@ class _Coarse(ctypes.Structure):
     _fields_ = [("pairs", ctypes.c_int), ("C", ctypes.c_int), ("num_corr", ctypes.c_int), ("dual_norm", ctypes.c_int),
                 ("max_ref", ctypes.c_int), ("max_src", ctypes.c_int), ("feats", _P), ("node_offset", _P), ("node_masks", _P),
                 ("scratch", _P), ("scratch_stride", ctypes.c_long), ("tgt_corr", _P), ("src_corr", _P), ("corr_scores", _P),
-                ("n_corr", _P), ("xy", _P), ("xy_stride", ctypes.c_long), ("xy_ld", ctypes.c_int)]
+                ("n_corr", _P), ("xy", _P), ("xy_stride", ctypes.c_long), ("xy_ld", ctypes.c_int), ("lds_cap", ctypes.c_int)]
 
 
 class _OT(ctypes.Structure):
