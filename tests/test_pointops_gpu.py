@@ -36,7 +36,7 @@ def cloud(rng, n, kind="uniform"):
 
 
 @pytest.mark.parametrize("kind", ["uniform", "lattice", "dup", "plane"])
-@pytest.mark.parametrize("sizes", [[5000], [1250], [312], [78], [16], [1024, 700, 2049], [8000], [3, 1, 130]])
+@pytest.mark.parametrize("sizes", [[5000], [1250], [312], [78], [16], [1024, 700, 2049], [8000], [3, 1, 130], [30000, 17000], [31000]])
 def test_fps_bit_exact(kind, sizes):
     from roitr_amd import pointops as P
     rng = np.random.default_rng(hash((kind, tuple(sizes))) % 2**32)
