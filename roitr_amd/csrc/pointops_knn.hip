@@ -426,6 +426,218 @@ __global__ __launch_bounds__(256) void knn_grid_kernel(int m, int nsample, const
     finish_query<NR>(L, o, q, nsample, lane, xyz, Q);
 }
 
+// ---------------------------------------------------------------- grid query with buffered selection (34 <= nsample + 1 <= 128)
+// For large k the one-at-a-time insertion of knn_grid_kernel (and the 66/101-slot register chains of knn_lane_kernel)
+// cost ~30 instructions per accepted candidate and almost every candidate of the first shells is accepted.  Here the
+// candidates of a shell that beat the current (nsample+1)-th distance are appended to an LDS buffer by ballot
+// compaction; once the buffer holds nsample+1 entries it is cut down to the <= 128 smallest by ONE histogram pass
+// (64 distance bins in LDS, prefix scan across the lanes, everything up to the bin that contains rank nsample+1 is
+// kept), and those are sorted by a 128-element bitonic network held two per lane.  Exactness: the selection keeps a
+// superset of the best nsample+1, the sort orders them by (distance, index), ties among the best nsample+1 go to the
+// replay kernel exactly as in the other kernels; a query whose buffers would overflow goes there as well.
+constexpr int SEL_CAP = 1024;
+
+// value of lane ^ J: DPP inside the 16-lane rows (quad permutes, row rotates: a few cycles, no LDS), ds_bpermute across
+template <int J>
+__device__ __forceinline__ int lane_xor(int v, int lane)
+{
+    if (J == 1) return __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, true);        // quad_perm [1,0,3,2]
+    if (J == 2) return __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, true);        // quad_perm [2,3,0,1]
+    if (J == 4) {
+        const int dn = __builtin_amdgcn_update_dpp(0, v, 0x124, 0xf, 0xf, true);       // row_ror:4  -> from lane - 4
+        const int up = __builtin_amdgcn_update_dpp(0, v, 0x12C, 0xf, 0xf, true);       // row_ror:12 -> from lane + 4
+        return (lane & 4) ? dn : up;
+    }
+    if (J == 8) return __builtin_amdgcn_update_dpp(0, v, 0x128, 0xf, 0xf, true);       // row_ror:8  -> lane ^ 8
+    return __shfl_xor(v, J, 64);
+}
+
+// sort the 128 (distance, index) pairs of a WaveList<2> ascending; element e = lane + 64 r
+template <int K, int J>
+__device__ __forceinline__ void sort128_step(WaveList<2>& L, int lane)
+{
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int e = lane + 64 * r;
+        const float pd = __int_as_float(lane_xor<J>(__float_as_int(L.d[r]), lane));
+        const int pi = lane_xor<J>(L.i[r], lane);
+        const bool up = (e & K) == 0;          // ascending block
+        const bool lower = (lane & J) == 0;    // this lane holds the lower position of the pair
+        // distances are >= 0: their bit patterns order like unsigned integers, so (distance, index) is one 64-bit compare
+        const unsigned long long mk_ = ((unsigned long long)__float_as_uint(L.d[r]) << 32) | (unsigned)L.i[r];
+        const unsigned long long pk_ = ((unsigned long long)__float_as_uint(pd) << 32) | (unsigned)pi;
+        const bool mine_gt = mk_ > pk_;
+        const bool take = (lower == up) ? mine_gt : !mine_gt;   // min to the lower position of ascending blocks
+        L.d[r] = take ? pd : L.d[r];
+        L.i[r] = take ? pi : L.i[r];
+    }
+}
+template <int K>
+__device__ __forceinline__ void sort128_stage(WaveList<2>& L, int lane)
+{
+    if (K >= 128) {   // partner = the lane's other register, ascending
+        const bool sw = (L.d[0] > L.d[1]) || (L.d[0] == L.d[1] && L.i[0] > L.i[1]);
+        const float td = sw ? L.d[1] : L.d[0]; const int ti = sw ? L.i[1] : L.i[0];
+        L.d[1] = sw ? L.d[0] : L.d[1]; L.i[1] = sw ? L.i[0] : L.i[1];
+        L.d[0] = td; L.i[0] = ti;
+    }
+    if (K >= 64) sort128_step<K, 32>(L, lane);
+    if (K >= 32) sort128_step<K, 16>(L, lane);
+    if (K >= 16) sort128_step<K, 8>(L, lane);
+    if (K >= 8) sort128_step<K, 4>(L, lane);
+    if (K >= 4) sort128_step<K, 2>(L, lane);
+    sort128_step<K, 1>(L, lane);
+}
+__device__ __forceinline__ void wave_sort128(WaveList<2>& L, int lane)
+{
+    sort128_stage<2>(L, lane); sort128_stage<4>(L, lane); sort128_stage<8>(L, lane); sort128_stage<16>(L, lane);
+    sort128_stage<32>(L, lane); sort128_stage<64>(L, lane); sort128_stage<128>(L, lane);
+}
+__global__ __launch_bounds__(256) void knn_gridsel_kernel(int m, int nsample, const float* __restrict__ xyz,
+                                                          const float* __restrict__ new_xyz, const int* __restrict__ offset,
+                                                          const int* __restrict__ new_offset, const RoitrGrid* __restrict__ grids,
+                                                          const int* __restrict__ cell_start, const float4* __restrict__ sorted, KnnOut o)
+{
+    __shared__ float bd_[4][SEL_CAP];
+    __shared__ int bi_[4][SEL_CAP];
+    __shared__ float ld_[4][128];
+    __shared__ int li_[4][128];
+    __shared__ int hist_[4][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int q = blockIdx.x * 4 + w;
+    if (q >= m) return;
+    float* bd = bd_[w]; int* bi = bi_[w]; float* ld = ld_[w]; int* li = li_[w]; int* hist = hist_[w];
+    int start, end, seg;
+    find_segment(q, offset, new_offset, start, end, seg);
+    const RoitrGrid g = grids[seg];
+    const int* cs = cell_start + (size_t)seg * (GRID_MAX_CELLS + 1);
+    Query Q = {new_xyz[(size_t)q * 3], new_xyz[(size_t)q * 3 + 1], new_xyz[(size_t)q * 3 + 2]};
+    WaveList<2> L;
+    L.init(start);
+    const int need = nsample + 1;   // keep the best nsample+1 exactly (tie detection)
+    float tau = KNN_FILL;
+    int cnt = 0;                    // entries in the LDS buffer (wave-uniform)
+    bool overflow = false, sorted_ok = false;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+
+    int c0[3];
+    {
+        const float t[3] = {(Q.x - g.ox) * g.inv_h, (Q.y - g.oy) * g.inv_h, (Q.z - g.oz) * g.inv_h};
+        const int dim[3] = {g.nx, g.ny, g.nz};
+#pragma unroll
+        for (int a = 0; a < 3; ++a) c0[a] = (int)fminf(fmaxf(t[a], 0.f), (float)(dim[a] - 1));
+    }
+    // buffer -> the <= 128 best in L, sorted; buffer front rewritten with them
+    auto reduce = [&]() {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        int n_in = cnt;
+        const float* sd = bd; const int* si = bi;
+        if (cnt > 128) {
+            float mn = INFINITY, mx = -INFINITY;
+            for (int e = lane; e < cnt; e += 64) { const float v = bd[e]; mn = fminf(mn, v); mx = fmaxf(mx, v); }
+            mn = -wave_max(-mn); mx = wave_max(mx);
+            if (!(mx > mn)) { overflow = true; return; }
+            const float scale = 63.999f / (mx - mn);
+            hist[lane] = 0;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            for (int e = lane; e < cnt; e += 64) atomicAdd(&hist[min(63, (int)((bd[e] - mn) * scale))], 1);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            int incl = hist[lane];
+#pragma unroll
+            for (int s_ = 1; s_ < 64; s_ <<= 1) { const int v = __shfl_up(incl, s_, 64); if (lane >= s_) incl += v; }
+            const unsigned long long ge = __ballot(incl >= need);
+            const int B = __ffsll((long long)ge) - 1;     // ge != 0: cnt >= need here
+            const int nsel = rl_i(incl, B);
+            if (nsel > 128) { overflow = true; return; }
+            int base = 0;
+            for (int e0 = 0; e0 < cnt; e0 += 64) {
+                const int e = e0 + lane;
+                const float v = e < cnt ? bd[e] : 0.f;
+                const bool keep = e < cnt && min(63, (int)((v - mn) * scale)) <= B;
+                const unsigned long long mk = __ballot(keep);
+                if (keep) { const int pos = base + __popcll(mk & lt_mask); ld[pos] = v; li[pos] = bi[e]; }
+                base += __popcll(mk);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            n_in = nsel; sd = ld; si = li;
+        }
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int e = lane + 64 * r;
+            L.d[r] = e < n_in ? sd[e] : KNN_FILL;
+            L.i[r] = e < n_in ? si[e] : start;
+        }
+        wave_sort128(L, lane);
+        // keep only what can still matter: the best `need` (everything behind is >= tau)
+        cnt = min(n_in, need);
+#pragma unroll
+        for (int r = 0; r < 2; ++r) { const int e = lane + 64 * r; if (e < cnt) { bd[e] = L.d[r]; bi[e] = L.i[r]; } }
+        tau = cnt >= need ? L.dist_at(nsample) : KNN_FILL;
+        sorted_ok = true;
+    };
+
+    const float margin = 2e-4f * g.h;
+    const int maxr = max(max(g.nx, g.ny), g.nz);
+    for (int r = 0; r <= maxr && !overflow; ++r) {
+        const int x0 = max(c0[0] - r, 0), x1 = min(c0[0] + r, g.nx - 1);
+        const int y0 = max(c0[1] - r, 0), y1 = min(c0[1] + r, g.ny - 1);
+        const int z0 = max(c0[2] - r, 0), z1 = min(c0[2] + r, g.nz - 1);
+        // rows of this shell, wave-uniform: a row on a y/z face contributes the run of cells [x0, x1], an interior row only
+        // its two (new) x end cells.  Every lane strides a run -- no cross-lane traffic in the enumeration.
+        // (Measured and dropped: issuing the first loads of 8 runs together, 7.9 vs 6.7 ms on the k = 64 stress case --
+        // the kernel is VALU-bound (SQ: 47 % active, 2800 VALU + 1600 SALU instructions per query), not load-latency-bound.)
+        auto scan_run = [&](int rs, int re) {
+            for (int p0 = rs; p0 < re && !overflow; p0 += 64) {
+                const int p = p0 + lane;
+                bool pass = false; float cd = 0.f; int ci = 0;
+                if (p < re) {
+                    const float4 c = sorted[p];
+                    cd = sqdist3(Q.x, Q.y, Q.z, c.x, c.y, c.z);
+                    ci = __float_as_int(c.w);
+                    pass = cd < tau;
+                }
+                const unsigned long long mk = __ballot(pass);
+                const int add = __popcll(mk);
+                if (cnt + add > SEL_CAP) { overflow = true; break; }
+                if (pass) { const int pos = cnt + __popcll(mk & lt_mask); bd[pos] = cd; bi[pos] = ci; }
+                cnt += add;
+                sorted_ok = sorted_ok && add == 0;
+            }
+        };
+        for (int cz = z0; cz <= z1 && !overflow; ++cz) {
+            for (int cy = y0; cy <= y1 && !overflow; ++cy) {
+                const int rowbase = (cz * g.ny + cy) * g.nx;
+                const bool face = (r == 0) || (cy == c0[1] - r) || (cy == c0[1] + r) || (cz == c0[2] - r) || (cz == c0[2] + r);
+                if (face) scan_run(cs[rowbase + x0], cs[rowbase + x1 + 1]);
+                else {
+                    const int xa = c0[0] - r, xb = c0[0] + r;
+                    if (xa >= 0) scan_run(cs[rowbase + xa], cs[rowbase + xa + 1]);
+                    if (xb < g.nx) scan_run(cs[rowbase + xb], cs[rowbase + xb + 1]);
+                }
+            }
+        }
+        if (overflow) break;
+        if (cnt >= need && !sorted_ok) reduce();
+        if (overflow) break;
+        float dmin = INFINITY;
+        if (x0 > 0) dmin = fminf(dmin, Q.x - __fmaf_rn((float)x0, g.h, g.ox));
+        if (x1 < g.nx - 1) dmin = fminf(dmin, __fmaf_rn((float)(x1 + 1), g.h, g.ox) - Q.x);
+        if (y0 > 0) dmin = fminf(dmin, Q.y - __fmaf_rn((float)y0, g.h, g.oy));
+        if (y1 < g.ny - 1) dmin = fminf(dmin, __fmaf_rn((float)(y1 + 1), g.h, g.oy) - Q.y);
+        if (z0 > 0) dmin = fminf(dmin, Q.z - __fmaf_rn((float)z0, g.h, g.oz));
+        if (z1 < g.nz - 1) dmin = fminf(dmin, __fmaf_rn((float)(z1 + 1), g.h, g.oz) - Q.z);
+        if (dmin == INFINITY) break;  // whole grid covered
+        const float dm = dmin - margin;
+        if (dm > 0.f && tau < dm * dm) break;
+    }
+    if (!overflow && !sorted_ok) reduce();   // fewer than nsample+1 candidates in the whole cloud, or a trailing append
+    if (overflow) {   // rare: hand the query to the exact replay
+        if (lane == 0) { const int slot = atomicAdd(o.tie_count, 1); o.tie_list[slot] = q; }
+        return;
+    }
+    finish_query<2>(L, o, q, nsample, lane, xyz, Q);
+}
+
 // Queries that are not the reference points themselves: counting-sort their indices by the cell of the REFERENCE grid
 // they fall into (one workgroup per cloud), so that the lane kernel walks them in cell order too.
 __global__ __launch_bounds__(1024) void sort_queries_kernel(const float* __restrict__ new_xyz, const int* __restrict__ new_offset,
@@ -846,6 +1058,7 @@ extern "C" int roitr_knnquery_ex(int b, int n, int m, int nsample, const float* 
     }
     static const int lane_min = [] { const char* e = getenv("ROITR_KNN_LANE_MIN"); return e ? atoi(e) : 8192; }();
     static const bool lane_brute = getenv("ROITR_KNN_NO_LANE_BRUTE") == nullptr;
+    static const bool gridsel = getenv("ROITR_KNN_NO_GRIDSEL") == nullptr;
     const bool lane_ok = use_grid && m >= lane_min && (!ppf || group_idx) && b > 0;
     const int self_sorted = (new_xyz == xyz && new_offset == offset && m == n) ? 1 : 0;
     // non-self queries: walk them in reference-cell order; the order array reuses the tie list's tail
@@ -863,6 +1076,8 @@ extern "C" int roitr_knnquery_ex(int b, int n, int m, int nsample, const float* 
         const int need = nsample + 1;
         if (need <= 2) LANE_CASE(2); else if (need <= 4) LANE_CASE(4); else if (need <= 10) LANE_CASE(10);
         else if (need <= 18) LANE_CASE(18); else LANE_CASE(34);
+    } else if (use_grid && gridsel && nsample + 1 <= 128) {
+        knn_gridsel_kernel<<<blocks, 256, 0, stream>>>(m, nsample, xyz, new_xyz, offset, new_offset, v.grids, v.cell_start, v.sorted, o);
     } else if (lane_ok && m >= 4 * lane_min) {
         if (nsample + 1 <= 66) LANE_CASE(66); else LANE_CASE(101);
     } else
