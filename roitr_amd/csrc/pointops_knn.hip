@@ -1072,7 +1072,8 @@ extern "C" int roitr_knnquery_ex(int b, int n, int m, int nsample, const float* 
 #define LANE_CASE(LC)                                                                                                        \
     knn_lane_kernel<LC><<<div_up(m, 256), 256, 0, stream>>>(m, nsample, b, xyz, new_xyz, offset, new_offset, v.grids, v.cell_start, \
                                                              v.sorted, o, self_sorted, qorder)
-    if (lane_ok && nsample + 1 <= 34) {
+    static const int sel_min = [] { const char* e = getenv("ROITR_KNN_SEL_MIN"); return e ? atoi(e) : 35; }();   // nsample + 1 from which the selection kernel takes over
+    if (lane_ok && nsample + 1 <= 34 && nsample + 1 < sel_min) {
         const int need = nsample + 1;
         if (need <= 2) LANE_CASE(2); else if (need <= 4) LANE_CASE(4); else if (need <= 10) LANE_CASE(10);
         else if (need <= 18) LANE_CASE(18); else LANE_CASE(34);
