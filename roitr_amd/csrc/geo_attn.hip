@@ -347,12 +347,112 @@ __global__ __launch_bounds__(256, R <= 20 ? 3 : 2) void mha_geo_kernel(RoitrMha 
 }
 
 
+// ------------------------------------------------------------------ the same for clouds with more than 128 superpoints
+// (up to the engine's 1024: 30000-point clouds have 468).  The E slab of a query row no longer fits the registers of a
+// block (n x 1 KB), so it is streamed twice -- still one coalesced float4 per lane and row, four rows in flight per
+// wave, the second pass mostly out of L2 / Infinity Cache -- instead of the generic kernel's one-row-per-lane walk.
+__global__ __launch_bounds__(256) void mha_geo_stream_kernel(RoitrMha a)
+{
+    constexpr int C = 256, NH = 4, NKP = 1024;
+    __shared__ __attribute__((aligned(16))) float sc[NH][NKP];
+    __shared__ __attribute__((aligned(16))) float sc2t[NKP * 4];
+    __shared__ __attribute__((aligned(16))) float red[4][NH * C];
+    const int row = a.q_row0 + blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hl = lane >> 4;
+    const int cl = a.cloud_of_row[row];
+    const int ks = cl == 0 ? 0 : a.offset[cl - 1], nk = a.offset[cl] - ks;
+    const int qi = row - ks;
+    const float* Erow = a.E + a.eoff[cl] * C + (size_t)qi * nk * C;
+    const float4 qv = reinterpret_cast<const float4*>(a.q + (size_t)row * a.ldq)[lane];
+    float4 qt4[NH];
+#pragma unroll
+    for (int h = 0; h < NH; ++h) qt4[h] = reinterpret_cast<const float4*>(a.qt + ((size_t)row * NH + h) * C)[lane];
+    const float qb = row_allsum(dot4(qv, reinterpret_cast<const float4*>(a.bp)[lane]));
+    // ---- scores: 4 key rows of this wave per trip (E and k rows requested together)
+    for (int j0 = wave; j0 < nk; j0 += 16) {
+        float4 ev[4], kv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = min(j0 + 4 * u, nk - 1);
+            ev[u] = reinterpret_cast<const float4*>(Erow + (size_t)j * C)[lane];
+            kv[u] = reinterpret_cast<const float4*>(a.k + (size_t)(ks + j) * a.ldk)[lane];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = j0 + 4 * u;
+            const float s1 = row_allsum(dot4(qv, kv[u]));
+            const float se0 = wave_sum(dot4(qt4[0], ev[u])), se1 = wave_sum(dot4(qt4[1], ev[u]));
+            const float se2 = wave_sum(dot4(qt4[2], ev[u])), se3 = wave_sum(dot4(qt4[3], ev[u]));
+            const float se = hl == 0 ? se0 : (hl == 1 ? se1 : (hl == 2 ? se2 : se3));
+            if (j < nk && (lane & 15) == 0) sc[hl][j] = (s1 + (se + qb)) * a.scale;
+        }
+    }
+    __syncthreads();
+    {   // softmax and diagonal-masked softmax: wave = head
+        const int h = wave;
+        float mx = -INFINITY, mx2 = -INFINITY;
+        for (int j = lane; j < nk; j += 64) { const float v = sc[h][j]; mx = fmaxf(mx, v); if (j != qi) mx2 = fmaxf(mx2, v); }
+        mx = wave_max(mx); mx2 = wave_max(mx2);
+        float sm = 0.f, sm2 = 0.f;
+        for (int j = lane; j < nk; j += 64) {
+            const float v = sc[h][j];
+            const float e1 = expf(v - mx), e2 = j != qi ? expf(v - mx2) : 0.f;
+            sc[h][j] = e1; sc2t[j * 4 + h] = e2; sm += e1; sm2 += e2;
+        }
+        sm = wave_sum(sm); sm2 = wave_sum(sm2);
+        for (int j = lane; j < nk; j += 64) { sc[h][j] /= sm; sc2t[j * 4 + h] /= sm2; }
+    }
+    __syncthreads();
+    {   // hidden: thread = channel
+        const int h = tid >> 6;
+        const float* vp = a.v + (size_t)ks * a.ldv + tid;
+        float acc = 0.f;
+        int j = 0;
+        for (; j + 8 <= nk; j += 8) {
+            float vv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) vv[u] = vp[(size_t)(j + u) * a.ldv];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc = fmaf(sc[h][j + u], vv[u], acc);
+        }
+        for (; j < nk; ++j) acc = fmaf(sc[h][j], vp[(size_t)j * a.ldv], acc);
+        a.out[(size_t)row * a.ldo + tid] = acc;
+    }
+    // ---- ebar: second pass over this wave's E rows
+    float4 acc[NH];
+#pragma unroll
+    for (int h = 0; h < NH; ++h) acc[h] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int j0 = wave; j0 < nk; j0 += 16) {
+        float4 ev[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) ev[u] = reinterpret_cast<const float4*>(Erow + (size_t)min(j0 + 4 * u, nk - 1) * C)[lane];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = j0 + 4 * u;
+            const float4 p2 = reinterpret_cast<const float4*>(sc2t)[j < nk ? j : 0];
+            const float w[4] = {j < nk ? p2.x : 0.f, j < nk ? p2.y : 0.f, j < nk ? p2.z : 0.f, j < nk ? p2.w : 0.f};
+#pragma unroll
+            for (int h = 0; h < NH; ++h) {
+                acc[h].x = fmaf(w[h], ev[u].x, acc[h].x); acc[h].y = fmaf(w[h], ev[u].y, acc[h].y);
+                acc[h].z = fmaf(w[h], ev[u].z, acc[h].z); acc[h].w = fmaf(w[h], ev[u].w, acc[h].w);
+            }
+        }
+    }
+#pragma unroll
+    for (int h = 0; h < NH; ++h) reinterpret_cast<float4*>(red[wave])[h * 64 + lane] = acc[h];
+    __syncthreads();
+#pragma unroll
+    for (int h = 0; h < NH; ++h)
+        a.ebar[((size_t)row * NH + h) * C + tid] = (red[0][h * C + tid] + red[1][h * C + tid]) + (red[2][h * C + tid] + red[3][h * C + tid]);
+}
+
 // ------------------------------------------------------------------ plain multi-head attention (cross layers), C = 256, 4 heads
 // geoattention.py:26-66 on the same lane = channel-quad layout as mha_geo_kernel: key rows are read coalesced (one
 // float4 per lane, head = DPP row), the four waves split the keys, values are accumulated by thread = channel.
+template <int NKP>   // keys per cloud bound (LDS score rows, softmax registers)
 __global__ __launch_bounds__(256) void mha_plain_kernel(RoitrMha a)
 {
-    constexpr int NH = 4, NKP = 128;
+    constexpr int NH = 4;
     __shared__ float sc[NH][NKP];
     const int row = a.q_row0 + blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hl = lane >> 4;
@@ -432,11 +532,19 @@ extern "C" int roitr_mha(const RoitrMha* a, hipStream_t stream)
     (void)attr_;
     roitr_prof_begin(ROITR_PROF_MHA, 0.0, stream);
     // self attention over E at the model's width: the single-pass register-resident kernel (nk_max bounds every cloud)
-    const bool geo = a->E && !a->partner && a->C == 256 && a->heads == 4 && a->ldq % 4 == 0 && a->ldk % 4 == 0 && a->nk_max <= 128 &&
-                     getenv("ROITR_MHA_GENERIC") == nullptr;
-    const bool plain = !a->E && a->C == 256 && a->heads == 4 && a->ldq % 4 == 0 && a->ldk % 4 == 0 && a->nk_max <= 128 &&
+    const bool geo_any = a->E && !a->partner && a->C == 256 && a->heads == 4 && a->ldq % 4 == 0 && a->ldk % 4 == 0 &&
+                         getenv("ROITR_MHA_GENERIC") == nullptr;
+    const bool geo = geo_any && a->nk_max <= 128;
+    if (geo_any && !geo && a->nk_max <= 1024) {
+        mha_geo_stream_kernel<<<a->q_rows, 256, 0, stream>>>(*a);
+        roitr_prof_end(ROITR_PROF_MHA, stream);
+        ROITR_LAUNCH_CHECK();
+        return ROITR_OK;
+    }
+    const bool plain = !a->E && a->C == 256 && a->heads == 4 && a->ldq % 4 == 0 && a->ldk % 4 == 0 && a->nk_max <= 1024 &&
                        getenv("ROITR_MHA_GENERIC") == nullptr;
-    if (plain) mha_plain_kernel<<<a->q_rows, 256, 0, stream>>>(*a);
+    if (plain && a->nk_max <= 128) mha_plain_kernel<128><<<a->q_rows, 256, 0, stream>>>(*a);
+    else if (plain) mha_plain_kernel<1024><<<a->q_rows, 256, 0, stream>>>(*a);
     else if (geo && a->nk_max <= 80) mha_geo_kernel<20><<<a->q_rows, 256, 0, stream>>>(*a);
     else if (geo) mha_geo_kernel<32><<<a->q_rows, 256, 0, stream>>>(*a);
     else
