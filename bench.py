@@ -106,7 +106,7 @@ def main():
                 model.forward_batch([pool[s]], want_gt=True)
             torch.cuda.synchronize()
             t1 = time.perf_counter()
-            n1 = 30
+            n1 = 60
             h1 = model.launch_batch([pool[0]], want_gt=True)
             for s in range(n1):
                 nx1 = model.launch_batch([pool[(s + 1) % len(pool)]], want_gt=True) if s + 1 < n1 else None
@@ -115,7 +115,7 @@ def main():
             torch.cuda.synchronize()
             d1 = time.perf_counter() - t1
         single = {"pairs_per_step": 1, "pairs_per_s": round(n1 / d1, 2), "ms_per_pair": round(1e3 * d1 / n1, 3),
-                  "note": "one pair per engine call, two calls in flight (launch-bound: ~800 kernel launches per forward)"}
+                  "note": "one pair per engine call, two calls in flight; bound by the ~800 dependent kernel dispatches of a forward (a HIP-graph replay of the same forward measures the same, scripts/bench_graph.py)"}
 
     # max over ranks of the timed region; total work = pairs of all ranks
     if distributed:

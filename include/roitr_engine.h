@@ -252,6 +252,11 @@ void roitr_engine_destroy(void* engine);
 int roitr_engine_set_param(void* engine, const char* name, const float* device_ptr, long numel);
 int roitr_engine_finalize(void* engine, roitr_stream_t stream);
 int roitr_engine_forward(void* engine, const RoitrForwardIO* io, roitr_stream_t stream);
+/* Same forward, replayed as ONE hipGraphLaunch once the same (sizes, io buffers) combination has been seen twice
+ * (1st call: plain forward; 2nd: capture + instantiate; then replay).  `stream` must be a real (non-NULL) stream.
+ * The caller keeps the io buffers at fixed addresses and re-fills them between calls. */
+int roitr_engine_forward_graph(void* engine, const RoitrForwardIO* io, roitr_stream_t stream);
+int roitr_engine_graph_count(void* engine);
 /* Test taps: after stage `name` its output tensor is copied to `device_ptr` (NULL removes the tap);
  * inject: the stage output is REPLACED by the tensor at device_ptr before the forward continues. */
 int roitr_engine_set_tap(void* engine, const char* name, void* device_ptr);

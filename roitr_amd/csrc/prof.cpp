@@ -39,6 +39,12 @@ void drain()
 }
 }  // namespace
 
+extern "C" int roitr_prof_is_enabled(void)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    return g_on ? 1 : 0;
+}
+
 extern "C" void roitr_prof_enable(int on)
 {
     std::lock_guard<std::mutex> lk(g_mu);

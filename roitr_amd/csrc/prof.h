@@ -25,6 +25,7 @@ enum {
 void roitr_prof_begin(int cls, double bytes, hipStream_t st);
 void roitr_prof_end(int cls, hipStream_t st);
 extern "C" void roitr_prof_enable(int on);
+extern "C" int roitr_prof_is_enabled(void);
 extern "C" void roitr_prof_reset(void);
 extern "C" void roitr_prof_next_bytes(int cls, double bytes);
 extern "C" int roitr_prof_read(int cls, double* ms, long* launches, double* bytes);

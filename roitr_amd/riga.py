@@ -297,18 +297,27 @@ class RIGA_v2(nn.Module):
     def level_sizes(n):
         return [n, n // 4, n // 4 // 4, n // 4 // 4 // 4]
 
-    def forward_batch(self, pairs, want_gt=True):
+    def forward_batch(self, pairs, want_gt=True, graph=False):
         """pairs: list of dicts with the forward() arguments as keys.  Returns a list of output dicts.
 
         All B pairs go through the engine in ONE batched pass (clouds laid out src_0..src_{B-1},
         tgt_0..tgt_{B-1}); the only host synchronisation is the final read of the correspondence count."""
-        return self.finish_batch(self.launch_batch(pairs, want_gt))
+        return self.finish_batch(self.launch_batch(pairs, want_gt, graph=graph))
 
-    def launch_batch(self, pairs, want_gt=True):
+    GRAPH_RING = 3   # persistent io buffer sets per shape in graph mode
+
+    def launch_batch(self, pairs, want_gt=True, graph=False):
         """Enqueue the batched forward on the current stream and return a handle for finish_batch().  Nothing here waits
         for the GPU: a caller may launch batch s+1 before finishing batch s, so the device never idles while the host
-        unpacks results (outputs are per-call tensors, the engine's scratch arena is re-used in stream order)."""
+        unpacks results (outputs are per-call tensors, the engine's scratch arena is re-used in stream order).
+
+        graph=True: the forward of a repeated shape is replayed as ONE HIP graph launch (roitr_engine_forward_graph)
+        instead of ~800 kernel launches -- what makes the one-pair-per-call mode fast.  The inputs are copied into, and the
+        results live in, persistent buffers that are re-used every GRAPH_RING-th call of the same shape: consume a
+        result before launching GRAPH_RING more batches of that shape."""
         self._ensure_engine()
+        if graph:
+            return self._launch_graph(pairs, want_gt)
         dev = pairs[0]["src_pcd"].device
         B = len(pairs)
         f32 = torch.float32
@@ -363,6 +372,75 @@ class RIGA_v2(nn.Module):
         done.record()
         keep = (geom, pout, nrm, feats, rot, trans, arr, meta_dev)   # inputs stay alive until the forward has run
         return dict(pairs=pairs, out=out, B=B, P=P, n_all=n_all, n4=n4, have_gt=have_gt, meta_host=meta_host, done=done, keep=keep)
+
+    def _launch_graph(self, pairs, want_gt):
+        dev = pairs[0]["src_pcd"].device
+        B = len(pairs)
+        f32, i32 = torch.float32, torch.int32
+        n_all = [int(p["src_raw_pcd"].shape[0]) for p in pairs] + [int(p["tgt_pcd"].shape[0]) for p in pairs]
+        have_gt = want_gt and pairs[0].get("rot") is not None
+        key = (tuple(n_all), have_gt)
+        if not hasattr(self, "_graph_slots"):
+            self._graph_slots, self._graph_stream = {}, torch.cuda.Stream()
+        ring = self._graph_slots.setdefault(key, {"pos": 0, "slots": []})
+        T = sum(n_all)
+        n4 = [self.level_sizes(n)[3] for n in n_all]
+        T4, n4max = sum(n4), max(n4)
+        C = 256 * self.factor
+        P = self.num_est_coarse_corr if self.factor == 1 else n4max * n4max
+        Lm = self.point_per_patch
+        cap = B * P * Lm * self.fine_topk
+        if len(ring["slots"]) < self.GRAPH_RING:
+            z = lambda shape, dt=f32: torch.empty(shape, dtype=dt, device=dev)
+            out = dict(node_xyz=z((T4, 3)), node_feats=z((T4, C)), point_feats=z((T, C)), node_masks=z((T4,), i32),
+                       node_knn_idx=z((T4, Lm), i32), node_knn_mask=z((T4, Lm), i32), tgt_corr=z((B, P), i32), src_corr=z((B, P), i32),
+                       corr_scores=z((B, P)), n_corr=z((B,), i32), tgt_knn_pts=z((B, P, Lm, 3)), src_knn_pts=z((B, P, Lm, 3)),
+                       tgt_knn_masks=z((B, P, Lm), i32), src_knn_masks=z((B, P, Lm), i32), matching_scores=z((B, P, Lm + 1, Lm + 1)),
+                       out_tgt_pts=z((cap, 3)), out_src_pts=z((cap, 3)), out_scores=z((cap,)), out_patch=z((cap,), i32),
+                       fine_offsets=z((B * P,), i32), n_out=z((1,), i32))
+            if have_gt:
+                out.update(gt_node_occ=z((T4,)), gt_corr_idx=z((B, n4max * n4max, 2), i32), gt_corr_overlaps=z((B, n4max * n4max)),
+                           gt_corr_count=z((B,), i32))
+            n_meta = (B + 1) + B + (B if have_gt else 0)
+            slot = dict(geom=z((T, 3)), pout=z((T, 3)), nrm=z((T, 3)), feats=z((T, 1)), rot=z((B, 3, 3)) if have_gt else None,
+                        trans=z((B, 3)) if have_gt else None, out=out, meta_dev=z((n_meta,), i32),
+                        meta_host=torch.empty((n_meta,), dtype=i32, pin_memory=True), arr=(ctypes.c_int * (2 * B))(*n_all))
+            io = _CForwardIO()
+            io.pairs = B
+            io.n_points = ctypes.cast(slot["arr"], ctypes.POINTER(ctypes.c_int))
+            io.points_geom, io.normals, io.feats, io.points_out = L.ptr(slot["geom"]), L.ptr(slot["nrm"]), L.ptr(slot["feats"]), L.ptr(slot["pout"])
+            io.rot, io.trans = L.ptr(slot["rot"]), L.ptr(slot["trans"])
+            for k, v in out.items():
+                setattr(io, k, L.ptr(v))
+            slot["io"] = io
+            ring["slots"].append(slot)
+            slot_i = len(ring["slots"]) - 1
+        else:
+            slot_i = ring["pos"] % self.GRAPH_RING
+        ring["pos"] += 1
+        slot = ring["slots"][slot_i]
+        out = slot["out"]
+        gs = self._graph_stream
+        gs.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(gs):
+            cat = lambda ks, kt, dst: torch.cat([p[ks].to(f32) for p in pairs] + [p[kt].to(f32) for p in pairs], 0, out=dst)
+            cat("src_raw_pcd", "tgt_pcd", slot["geom"]); cat("src_pcd", "tgt_pcd", slot["pout"])
+            cat("src_normals", "tgt_normals", slot["nrm"]); cat("src_feats", "tgt_feats", slot["feats"])
+            if have_gt:
+                torch.stack([p["rot"].reshape(3, 3).to(f32) for p in pairs], out=slot["rot"])
+                torch.stack([p["trans"].reshape(3).to(f32) for p in pairs], out=slot["trans"])
+            L.check(L.lib().roitr_engine_forward_graph(self._engine, ctypes.byref(slot["io"]), L.stream_ptr()), "engine_forward_graph")
+            parts = [out["fine_offsets"].view(B, P)[:, 0], out["n_out"], out["n_corr"]] + ([out["gt_corr_count"]] if have_gt else [])
+            torch.cat(parts, out=slot["meta_dev"])
+            slot["meta_host"].copy_(slot["meta_dev"], non_blocking=True)
+            done = torch.cuda.Event()
+            done.record()
+        keep = (slot["geom"], slot["pout"], slot["nrm"], slot["feats"], slot["rot"], slot["trans"], slot["arr"], slot["meta_dev"])
+        return dict(pairs=pairs, out=out, B=B, P=P, n_all=n_all, n4=n4, have_gt=have_gt, meta_host=slot["meta_host"], done=done, keep=keep)
+
+    def graph_count(self):
+        """Forwards currently held as instantiated HIP graphs."""
+        return int(L.lib().roitr_engine_graph_count(self._engine)) if self._engine is not None else 0
 
     def finish_batch(self, h):
         """Wait for the forward of launch_batch() and unpack it per pair (the one host synchronisation of the path)."""
