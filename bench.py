@@ -39,6 +39,7 @@ def parse():
     ap.add_argument("--pairs-per-step", type=int, default=256)
     ap.add_argument("--n-points", type=int, default=5000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-single-pair", action="store_true", help="skip the one-pair-per-call measurement (profiling passes)")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=20.0)
     return ap.parse_args()
 
@@ -100,7 +101,7 @@ def main():
     # the reference's own loop feeds ONE pair per forward (DataLoader batch_size 1, lib/tester.py:24-53): report that mode
     # too (rank 0, outside the timed region above), so the batched headline can be read against it
     single = None
-    if rank == 0 and not distributed:
+    if rank == 0 and not distributed and not args.no_single_pair:
         with torch.no_grad():
             for s in range(3):
                 model.forward_batch([pool[s]], want_gt=True)
