@@ -170,7 +170,10 @@ extern "C" int roitr_geo_embed(long rows, int C, int angle_k, const float* d_idx
     const long mt = (rows + BM - 1) / BM;
     if (mt > 0x7fffffffL) return ROITR_ERR_UNSUPPORTED;
     static const int nj_env = [] { const char* e = getenv("ROITR_GEO_NJ"); return e ? atoi(e) : 0; }();
-    // measured (B=32, N=5000, C=256): NJ=1 1.90 ms (156 VGPRs, 3 blocks/CU), NJ=2 2.27 ms (284 VGPRs, 1 block/CU)
+    // measured (B=32, N=5000, C=256): NJ=1 1.90 ms (156 VGPRs, 3 blocks/CU), NJ=2 2.27 ms (284 VGPRs, 1 block/CU).
+    // Also measured and dropped: one staged weight slab shared by the three angle passes (3 x 2 accumulators per wave, 199
+    // VGPRs, 2 blocks/CU): 7.32 vs 7.37 ms per 128-pair forward -- weight traffic / barriers are not what holds the kernel
+    // at 66 % of the MFMA peak; NJ=1 with 128 VGPRs forced (4 blocks/CU, 92 spills): 7.76 ms.
     const int nj = (C % 256 == 0 && nj_env == 2) ? 2 : 1;
     roitr_prof_begin(ROITR_PROF_GEO_EMBED, 2.0 * rows * (1.0 + angle_k) * (double)C * C, stream);
     if (nj == 2)
