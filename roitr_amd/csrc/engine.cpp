@@ -547,7 +547,7 @@ extern "C" int roitr_engine_forward(void* h, const RoitrForwardIO* io, hipStream
 
     // ---------------- arena sizing (upper bound from the sizes)
     {
-        size_t need = (size_t)T1 * 4 * (64 * f * 14 + 256 * f * 2 + 600) + (size_t)etot * C4 * 4 * 11 + (size_t)T4 * C4 * 4 * 40 +
+        size_t need = (size_t)T1 * 4 * (64 * f * 14 + 256 * f * 2 + 600) + (size_t)etot * (C4 * 4 + 64) /* E once + its index arrays */ + (size_t)T4 * C4 * 4 * 40 +
                       (size_t)B * P_ * (LIM * LIM * 3 + (LIM + 1) * (LIM + 1) + LIM * 16) * 4 + ((size_t)64 << 20);
         for (int l = 0; l < 4; ++l) need += roitr_knn_workspace_bytes(NC, V.T[l], T1) + 1024;
         need += (size_t)B * (roitr_coarse_scratch_floats(V.nmax[3], V.nmax[3]) + (size_t)2 * V.nmax[3] * V.nmax[3]) * 4 + 1024;
