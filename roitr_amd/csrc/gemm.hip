@@ -25,6 +25,9 @@
 #include "prof.h"
 #include "roitr_engine.h"
 
+#ifndef GEMM_WIDE_STORE
+#define GEMM_WIDE_STORE 1
+#endif
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -67,6 +70,7 @@ __device__ __attribute__((aligned(16))) float g_zero_row[ZERO_ROW_LEN];
 template <bool FAST, int TN, bool LN>
 __global__ __launch_bounds__(256) void gemm_kernel(RoitrGemm g, int nx, int ny, int T)
 {
+    constexpr bool WIDE_STORE = GEMM_WIDE_STORE != 0;
     constexpr int TBN = BN * TN;
     constexpr int RP = TN == 4 ? 32 : 64;   // rows parked per LayerNorm pass (keeps the static LDS under 64 KB at TN = 4)
     constexpr int STAGE = 2 * BM * LDR + 2 * TBN * LDR, TILE = LN ? RP * (TBN + 1) : 0;
@@ -256,6 +260,34 @@ __global__ __launch_bounds__(256) void gemm_kernel(RoitrGemm g, int nx, int ny, 
                     C[(size_t)row * g.ldc + lane + 64 * i] = y;
                 }
             }
+        }
+        return;
+    }
+    if (TN == 1 && WIDE_STORE && n0 + BN <= g.N && (g.ldc & 3) == 0 && (((uintptr_t)C) & 15) == 0) {
+        // full 64-column tile: transpose through the staging LDS and store 16 bytes per lane (4 store instructions per
+        // wave instead of 16 four-byte ones)
+        constexpr int TP = BN + 4;   // row pitch: 16-byte aligned rows
+        static_assert(BM * TP <= 2 * BM * LDR + 2 * TBN * LDR || TN != 1, "tile must fit the staging LDS");
+        __syncthreads();
+        float* tile_ = smem;
+        {
+            const int col = wn * 32 + (lane & 31);
+            const float bv = bias ? bias[n0 + col] : 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int rl = wm * 32 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+                float x = acc[0][i] * g.alpha + bv;
+                if (g.relu) x = fmaxf(x, 0.f);
+                tile_[rl * TP + col] = x;
+            }
+        }
+        __syncthreads();
+        const int c4 = (tid & 15) * 4;
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+            const int rl = pass * 16 + (tid >> 4);
+            const int row = m0 + rl;
+            if (row < g.M) *reinterpret_cast<float4*>(C + (size_t)row * g.ldc + n0 + c4) = *reinterpret_cast<const float4*>(tile_ + rl * TP + c4);
         }
         return;
     }
