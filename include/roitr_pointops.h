@@ -97,6 +97,11 @@ int roitr_estimate_normals(int b, int n, const float* xyz, const int* offset, in
 int roitr_normal_redirect(int n, const float* xyz, const float* normals_in, const float* view_point, float* normals_out,
                           roitr_stream_t stream);
 
+/* kNN(1) distances for a radius test (lib/utils.py:509-521 get_node_occlusion_score): exact when < cap2, otherwise any
+ * value >= cap2.  Same workspace / grid rules as roitr_knnquery_ex. */
+int roitr_knn_within(int b, int n, int m, const float* xyz, const float* new_xyz, const int* offset, const int* new_offset,
+                     float cap2, float* dist2, int use_grid, int m_capacity, void* ws, roitr_stream_t stream);
+
 int roitr_grouping_forward(int m, int nsample, int c, const float* input, const int* idx, float* output, roitr_stream_t stream);
 int roitr_grouping_backward(int m, int nsample, int c, const float* grad_output, const int* idx, float* grad_input, roitr_stream_t stream);
 int roitr_interpolation_forward(int n, int c, int k, const float* input, const int* idx, const float* weight, float* output, roitr_stream_t stream);

@@ -941,11 +941,10 @@ extern "C" int roitr_engine_forward(void* h, const RoitrForwardIO* io, hipStream
         if (io->gt_node_occ) {
             // kNN(1) of every padded target point among the transformed padded source points, and back (l.509-510)
             if (use_grid) CHK(roitr_knn_build_grid(B, Tsp, Ttp, src_p, off_s, ws_s, st));
-            CHK(roitr_knnquery_ex(B, Tsp, Ttp, 1, src_p, tgt_p, off_s, off_t, nullptr, d2p + Tsp, nullptr, nullptr, nullptr, nullptr,
-                                  use_grid, Ttp, ws_s, st));
+            const float occ_cap2 = E.cfg.occlusion_radius * E.cfg.occlusion_radius * 1.01f;   // only `distance < radius` is read
+            CHK(roitr_knn_within(B, Tsp, Ttp, src_p, tgt_p, off_s, off_t, occ_cap2, d2p + Tsp, use_grid, Ttp, ws_s, st));
             if (use_grid) CHK(roitr_knn_build_grid(B, Ttp, Tsp, tgt_p, off_t, ws_t, st));
-            CHK(roitr_knnquery_ex(B, Ttp, Tsp, 1, tgt_p, src_p, off_t, off_s, nullptr, d2p, nullptr, nullptr, nullptr, nullptr, use_grid,
-                                  Tsp, ws_t, st));
+            CHK(roitr_knn_within(B, Ttp, Tsp, tgt_p, src_p, off_t, off_s, occ_cap2, d2p, use_grid, Tsp, ws_t, st));
             CHK(roitr_node_occlusion_score(T4, LIM, D.cloud_of_node, D.off[0], kidx, kmask, node_masks, d2p, E.cfg.occlusion_radius,
                                            io->gt_node_occ, st));
         }

@@ -690,7 +690,7 @@ __global__ __launch_bounds__(256) void knn_lane_kernel(int m, int nsample, int b
                                                        const float* __restrict__ new_xyz, const int* __restrict__ offset,
                                                        const int* __restrict__ new_offset, const RoitrGrid* __restrict__ grids,
                                                        const int* __restrict__ cell_start, const float4* __restrict__ sorted, KnnOut o,
-                                                       int self_sorted, const int* __restrict__ qorder)
+                                                       int self_sorted, const int* __restrict__ qorder, float cap2)
 {
     const int t = blockIdx.x * 256 + threadIdx.x;
     if (t >= m) return;
@@ -769,7 +769,9 @@ __global__ __launch_bounds__(256) void knn_lane_kernel(int m, int nsample, int b
 #pragma unroll
         for (int j = 0; j < L - 1; ++j) tau = (j == nsample) ? d[j] : tau;
         const float dm = dmin - margin;
-        if (dm > 0.f && tau < dm * dm) break;
+        // cap2 < inf (roitr_knn_within): the caller only compares the distances against sqrt(cap2), so the search may stop
+        // as soon as everything unseen is farther than that
+        if (dm > 0.f && fminf(tau, cap2) < dm * dm) break;
     }
     bool tie = false;
 #pragma unroll
@@ -1037,6 +1039,8 @@ extern "C" const void* roitr_knn_sorted_points(int b, int n, int m_capacity, voi
 
 // The general entry point.  use_grid != 0 requires a prior roitr_knn_build_grid on the same ws.
 // Outputs idx / dist2 / group_idx / ppf are each optional (null = not wanted).
+namespace { float g_knn_cap2 = INFINITY; }
+
 extern "C" int roitr_knnquery_ex(int b, int n, int m, int nsample, const float* xyz, const float* new_xyz, const int* offset,
                                  const int* new_offset, int* idx, float* dist2, int* group_idx, float* ppf,
                                  const float* ref_normals, const float* query_normals, int use_grid, int m_capacity, void* ws,
@@ -1071,7 +1075,7 @@ extern "C" int roitr_knnquery_ex(int b, int n, int m, int nsample, const float* 
     }
 #define LANE_CASE(LC)                                                                                                        \
     knn_lane_kernel<LC><<<div_up(m, 256), 256, 0, stream>>>(m, nsample, b, xyz, new_xyz, offset, new_offset, v.grids, v.cell_start, \
-                                                             v.sorted, o, self_sorted, qorder)
+                                                             v.sorted, o, self_sorted, qorder, g_knn_cap2)
     static const int sel_min = [] { const char* e = getenv("ROITR_KNN_SEL_MIN"); return e ? atoi(e) : 35; }();   // nsample + 1 from which the selection kernel takes over
     if (lane_ok && nsample + 1 <= 34 && nsample + 1 < sel_min) {
         const int need = nsample + 1;
@@ -1128,4 +1132,18 @@ extern "C" void knnquery_cuda_launcher(int m, int nsample, const float* xyz, con
     }
     (void)roitr_knnquery_ex(0, 0, m, nsample, xyz, new_xyz, offset, new_offset, idx, dist2, nullptr, nullptr, nullptr, nullptr, 0, m,
                             g_legacy_ws, nullptr);
+}
+
+
+// Nearest-neighbour distances for a radius test: dist2[q] is exact whenever it is < cap2; queries whose nearest
+// reference point is farther than sqrt(cap2) get SOME value >= cap2 (the ring search stops as soon as everything unseen
+// is beyond the cap).  lib/utils.py:509-521 only evaluates `nearest distance < overlap radius`.
+extern "C" int roitr_knn_within(int b, int n, int m, const float* xyz, const float* new_xyz, const int* offset, const int* new_offset,
+                                float cap2, float* dist2, int use_grid, int m_capacity, void* ws, hipStream_t stream)
+{
+    g_knn_cap2 = cap2;
+    const int rc = roitr_knnquery_ex(b, n, m, 1, xyz, new_xyz, offset, new_offset, nullptr, dist2, nullptr, nullptr, nullptr, nullptr, use_grid,
+                                     m_capacity, ws, stream);
+    g_knn_cap2 = INFINITY;
+    return rc;
 }
