@@ -34,8 +34,8 @@ MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32-input MFMA = the fp32 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--pairs-per-step", type=int, default=256)
     ap.add_argument("--n-points", type=int, default=5000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -83,7 +83,8 @@ def main():
         for s in range(args.warmup):
             model.forward_batch(batch(s), want_gt=True)
         barrier()
-        model.profile_reset()
+        if not os.environ.get("ROITR_BENCH_NOPROF"):
+            model.profile_reset()
         t0 = time.perf_counter()
         n_corr_total = 0
         # two batches in flight: batch s+1 is enqueued before the host unpacks batch s (launch_batch never waits for the

@@ -27,6 +27,21 @@ hipEvent_t get_event()
     return e;
 }
 
+// fold finished brackets from the front of the queue back into the totals and the event pool (non-blocking), so a long
+// timed region re-uses a few thousand events instead of creating two per bracketed launch
+void recycle()
+{
+    size_t n = 0;
+    while (n < g_done.size() && hipEventQuery(g_done[n].b) == hipSuccess) {
+        Rec& r = g_done[n];
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) { g_ms[r.cls] += ms; g_bytes[r.cls] += r.bytes; g_launches[r.cls] += 1; }
+        g_pool.push_back(r.a); g_pool.push_back(r.b);
+        ++n;
+    }
+    if (n) g_done.erase(g_done.begin(), g_done.begin() + n);
+}
+
 void drain()
 {
     for (auto& r : g_done) {
@@ -55,6 +70,11 @@ extern "C" void roitr_prof_reset(void)
 {
     std::lock_guard<std::mutex> lk(g_mu);
     drain();
+    while (g_pool.size() < 4096) {   // events are created here, not inside the region that is about to be timed
+        hipEvent_t e = nullptr;
+        if (hipEventCreate(&e) != hipSuccess) break;
+        g_pool.push_back(e);
+    }
     for (int i = 0; i < ROITR_PROF_CLASSES; ++i) { g_ms[i] = 0; g_bytes[i] = 0; g_launches[i] = 0; }
 }
 
@@ -78,6 +98,7 @@ void roitr_prof_begin(int cls, double bytes, hipStream_t st)
 {
     if (!g_on) return;
     std::lock_guard<std::mutex> lk(g_mu);
+    if (g_pool.size() < 2 && g_done.size() > 256) recycle();
     Rec r; r.cls = cls; r.bytes = bytes >= 0.0 ? bytes : g_next_bytes[cls]; r.a = get_event(); r.b = get_event();
     (void)hipEventRecord(r.a, st);
     g_open.push_back(r);
