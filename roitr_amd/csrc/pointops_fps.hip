@@ -94,7 +94,8 @@ __global__ __launch_bounds__(BLOCK) void fps_kernel(const float* __restrict__ xy
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float2* slots = reinterpret_cast<float2*>(smem);                       // [2][NW] : (max d2, tie word as float bits)
     int* sidx = reinterpret_cast<int*>(smem + 2 * NW * sizeof(float2));    // [FPS_IDX_CAP]
-    float4* spts = reinterpret_cast<float4*>(smem + 2 * NW * sizeof(float2) + FPS_IDX_CAP * sizeof(int));  // [lds_pts]
+    // xyz copy for the winner lookup, three planes of lds_pts floats (12 B per point: two 5000-point clouds share a CU)
+    float* spts = reinterpret_cast<float*>(smem + 2 * NW * sizeof(float2) + FPS_IDX_CAP * sizeof(int));
 
     const int bid = blockIdx.x;
     const int start_n = bid == 0 ? 0 : offset[bid - 1];
@@ -119,7 +120,7 @@ __global__ __launch_bounds__(BLOCK) void fps_kernel(const float* __restrict__ xy
             const float* p = xyz + (size_t)(start_n + koff) * 3;
             px[j] = p[0]; py[j] = p[1]; pz[j] = p[2];
             pt[j] = tmp[start_n + koff];
-            if (pts_in_lds) spts[koff] = make_float4(px[j], py[j], pz[j], 0.f);
+            if (pts_in_lds) { spts[koff] = px[j]; spts[lds_pts + koff] = py[j]; spts[2 * lds_pts + koff] = pz[j]; }
         } else {
             px[j] = py[j] = pz[j] = 0.f;
             pt[j] = -1.f;
@@ -169,8 +170,8 @@ __global__ __launch_bounds__(BLOCK) void fps_kernel(const float* __restrict__ xy
         int old = start_n;
         if (gd >= 0.f) old = start_n + (int)(0x1FFFFFu - ((gtb - 1u) & 0x1FFFFFu));
         if (pts_in_lds) {
-            const float4 q = spts[old - start_n];
-            ox = q.x; oy = q.y; oz = q.z;
+            const int oi = old - start_n;
+            ox = spts[oi]; oy = spts[lds_pts + oi]; oz = spts[2 * lds_pts + oi];
         } else if (n > 0) {
             const float* p = xyz + (size_t)old * 3;
             ox = p[0]; oy = p[1]; oz = p[2];
@@ -233,7 +234,7 @@ __global__ __launch_bounds__(BLOCK) void fps_stream_kernel(const float* __restri
 
 size_t fps_lds_bytes(int block, int lds_pts)
 {
-    return (size_t)2 * (block / 64) * sizeof(float2) + FPS_IDX_CAP * sizeof(int) + (size_t)lds_pts * sizeof(float4);
+    return (size_t)2 * (block / 64) * sizeof(float2) + FPS_IDX_CAP * sizeof(int) + (size_t)lds_pts * 3 * sizeof(float);
 }
 
 // cuda_utils.h:11-14: the block size the reference would launch, same double-precision formula
