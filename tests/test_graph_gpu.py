@@ -45,3 +45,19 @@ def test_graph_forward_equals_plain_forward():
         h1 = model.launch_batch([pairs[5]], graph=True)
         _same(model.finish_batch(h0)[0], ref[4])
         _same(model.finish_batch(h1)[0], ref[5])
+
+
+def test_forward_is_deterministic_and_batch_invariant():
+    """Same pairs twice, and inside differently composed batches: every output bit-identical (atomics only hand out
+    slots whose order never reaches the results; every kernel is row-local)."""
+    from roitr_amd.synthetic import make_pair
+    from tests.gpu_util import build_model, pair_to_device
+    model = build_model("3DMatch")
+    pairs = [pair_to_device(make_pair(n, config=2, pair_index=i)) for i, n in enumerate((2000, 1024, 3000, 1500))]
+    with torch.no_grad():
+        a = model.forward_batch(pairs)
+        b = model.forward_batch(pairs)
+        c = model.forward_batch([pairs[2], pairs[0]])
+    for x, y in zip(a, b):
+        _same(x, y)
+    _same(c[0], a[2]); _same(c[1], a[0])
