@@ -61,6 +61,12 @@ int roitr_sinusoid(long rows, int C, const float* vals, const float* div_term, f
 /* Fused positional_encoding.py:139-154: out[r,:] = proj_d(sinusoid(d_idx[r])) + max_k proj_a(sinusoid(a_idx[r,k])) */
 int roitr_geo_embed(long rows, int C, int angle_k, const float* d_idx, const float* a_idx, const float* div_term,
                     const float* Wd, const float* bd, const float* Wa, const float* ba, float* out, roitr_stream_t stream);
+/* OPT-IN: the same embedding on the bf16 matrix cores with three-way split operands (x = hi + mid + lo, six partial
+ * products kept: error of the order of fp32 rounding).  W*3: 3 * C * C uint16 made by roitr_split3_bf16. */
+int roitr_split3_bf16(long n, const float* src, unsigned short* dst, roitr_stream_t stream);
+int roitr_geo_embed_split(long rows, int C, int angle_k, const float* d_idx, const float* a_idx, const float* div_term,
+                          const unsigned short* Wd3, const float* bd, const unsigned short* Wa3, const float* ba, float* out,
+                          roitr_stream_t stream);
 /* E = P_d + max_k P_a[:, k, :] (positional_encoding.py:146-152) */
 int roitr_geo_combine(long rows, int C, int k, const float* pd, const float* pa, float* out, roitr_stream_t stream);
 int roitr_gather_rows(long rows, int C, const float* in, const int* idx, int limit, float* out, roitr_stream_t stream);

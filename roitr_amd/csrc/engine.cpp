@@ -98,6 +98,7 @@ struct Engine {
     LocalT dec[4];
     Up up[4];
     Lin geo_in, geo_out, proj_d, proj_a, coarse_proj, fine_proj;
+    unsigned short* proj_d3 = nullptr; unsigned short* proj_a3 = nullptr;   // opt-in split-bf16 planes (ROITR_GEO_SPLIT=1)
     const float* geo_div = nullptr;
     float* geo_div_own = nullptr;
     std::vector<GeoLayer> geo;
@@ -509,6 +510,14 @@ extern "C" int roitr_engine_finalize(void* h, hipStream_t st)
             E.geo_div = E.geo_div_own;
         }
     }
+    if (getenv("ROITR_GEO_SPLIT")) {   // opt-in: three bf16 planes of the two embedding projections
+        E.proj_d3 = E.warena.get<unsigned short>((size_t)3 * C4 * C4);
+        E.proj_a3 = E.warena.get<unsigned short>((size_t)3 * C4 * C4);
+        if (!E.warena.fail) {
+            CHK(roitr_split3_bf16((long)C4 * C4, E.proj_d.w, E.proj_d3, st));
+            CHK(roitr_split3_bf16((long)C4 * C4, E.proj_a.w, E.proj_a3, st));
+        }
+    }
     if (E.warena.fail) { roitr_set_error("derived-weight arena exhausted", __FILE__, __LINE__); return ROITR_ERR_ARG; }
     E.finalized = true;
     return 0;
@@ -702,7 +711,10 @@ extern "C" int roitr_engine_forward(void* h, const RoitrForwardIO* io, hipStream
         CHK(roitr_geo_indices(T4, p[3], D.off[3], D.cloud_of_node, D.eoff, 0.2f, 15.0f, 3, V.nmax[3], d_idx, a_idx, st));
         CHK(tap(E, st, "geo.d_idx", d_idx, sizeof(float) * etot));
         CHK(tap(E, st, "geo.a_idx", a_idx, sizeof(float) * etot * 3));
-        CHK(roitr_geo_embed(etot, C4, 3, d_idx, a_idx, E.geo_div, E.proj_d.w, E.proj_d.b, E.proj_a.w, E.proj_a.b, Emb, st));
+        if (E.proj_d3)
+            CHK(roitr_geo_embed_split(etot, C4, 3, d_idx, a_idx, E.geo_div, E.proj_d3, E.proj_d.b, E.proj_a3, E.proj_a.b, Emb, st));
+        else
+            CHK(roitr_geo_embed(etot, C4, 3, d_idx, a_idx, E.geo_div, E.proj_d.w, E.proj_d.b, E.proj_a.w, E.proj_a.b, Emb, st));
         CHK(tap(E, st, "geo.emb", Emb, sizeof(float) * (size_t)etot * C4));
 
         float* fcur = A.get<float>((size_t)T4 * C4);

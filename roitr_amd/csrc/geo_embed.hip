@@ -159,6 +159,174 @@ __global__ __launch_bounds__(256) void geo_embed_kernel(long rows, int C, int an
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// OPT-IN (ROITR_GEO_SPLIT=1), not the default path: the same embedding on the bf16 matrix cores with fp32-level
+// accuracy.  Every fp32 operand is split into three bf16 pieces (x = hi + mid + lo, 8 + 8 + 8 mantissa bits, exact),
+// and a product keeps the six piece pairs down to 2^-24: hh, hm, mh, hl, lh, mm -- six v_mfma_f32_32x32x16_bf16
+// (fp32 accumulate, bf16 products are exact in fp32) instead of eight v_mfma_f32_32x32x2_f32 per 16 k, at 16x the
+// rate per instruction: 2.7x less matrix-pipe time for an error of the order of fp32 rounding itself (measured against
+// the fp32 kernel in tests/test_stages_gpu.py).  The weights are split once at engine finalize.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ unsigned bf16_rne(float x)
+{
+    unsigned u = __float_as_uint(x);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return u >> 16;
+}
+__device__ __forceinline__ void split3(float x, unsigned& h, unsigned& m, unsigned& l)
+{
+    h = bf16_rne(x);
+    const float r1 = x - __uint_as_float(h << 16);
+    m = bf16_rne(r1);
+    const float r2 = r1 - __uint_as_float(m << 16);
+    l = bf16_rne(r2);
+}
+
+__global__ void split3_bf16_kernel(long n, const float* __restrict__ src, unsigned short* __restrict__ dst)
+{
+    const long i = blockIdx.x * 256L + threadIdx.x;
+    if (i >= n) return;
+    unsigned h, m, l;
+    split3(src[i], h, m, l);
+    dst[i] = (unsigned short)h; dst[n + i] = (unsigned short)m; dst[2 * n + i] = (unsigned short)l;
+}
+
+
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// (x, y) -> packed bf16 pairs of the three pieces (v_cvt_pk_bf16_f32, round to nearest even); low half = x
+__device__ __forceinline__ void split3_pair(float x, float y, unsigned& h, unsigned& m, unsigned& l)
+{
+    f32x2 v = {x, y};
+    h = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+    f32x2 r1 = {x - __uint_as_float(h << 16), y - __uint_as_float(h & 0xFFFF0000u)};
+    m = __builtin_bit_cast(unsigned, __builtin_convertvector(r1, bf16x2));
+    f32x2 r2 = {r1[0] - __uint_as_float(m << 16), r1[1] - __uint_as_float(m & 0xFFFF0000u)};
+    l = __builtin_bit_cast(unsigned, __builtin_convertvector(r2, bf16x2));
+}
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+__device__ __forceinline__ lds_ptr_t to_lds(const void* p) { return (lds_ptr_t)(unsigned)(uintptr_t)p; }
+
+// Tile 64 x 128, 4 waves side by side along N (2 accumulators each).  Two LDS stages; the weight planes go global -> LDS
+// by DMA (global_load_lds_dwordx4: with the matrix time cut 2.7x the ds_write path of the fp32 kernel would be the
+// bottleneck), the generated A planes by ds_write_b128.  LDS rows are 4 chunks of 8 bf16, unpadded (the DMA writes
+// linearly); chunk c of row r lives at physical chunk c ^ ((r >> 2) & 3): conflict-free b128 fragment reads.
+__global__ __launch_bounds__(256) void geo_embed_split_kernel(long rows, int C, int angle_k, const float* __restrict__ d_idx,
+                                                              const float* __restrict__ a_idx, const float* __restrict__ div_term,
+                                                              const unsigned short* __restrict__ Wd3, const float* __restrict__ bd,
+                                                              const unsigned short* __restrict__ Wa3, const float* __restrict__ ba,
+                                                              float* __restrict__ out)
+{
+    constexpr int BNW = 128;
+    __shared__ __attribute__((aligned(1024))) uint4 Bs[2][3][BNW * 4];   // [stage][plane][row][chunk]
+    __shared__ __attribute__((aligned(16))) uint4 As[2][3][BM * 4];
+    __shared__ float divs[512];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long m0 = (long)blockIdx.y * BM;
+    const int n0 = blockIdx.x * BNW;
+    const int r = tid >> 2, ck = tid & 3, kq = ck * 8;
+    for (int i = tid; i < C / 2; i += 256) divs[i] = div_term[i];
+    const long arow = m0 + r;
+    const bool arow_ok = arow < rows;
+    const int kg = lane >> 5, ml = lane & 31;
+    const size_t plane = (size_t)C * C;
+    const int a_wr = r * 4 + (ck ^ ((r >> 2) & 3));
+    // DMA assignment: 24 one-KB pieces per slab (3 planes x 8 groups of 16 rows), 6 per wave; lane -> row 16 u + lane / 4,
+    // physical chunk lane % 4
+    int dma_p[6], dma_lds[6]; size_t dma_src[6];
+#pragma unroll
+    for (int t = 0; t < 6; ++t) {
+        const int idx = wave * 6 + t, p = idx >> 3, u = idx & 7;
+        const int row = 16 * u + (lane >> 2);
+        const int lc = (lane & 3) ^ ((row >> 2) & 3);
+        dma_p[t] = p; dma_lds[t] = p * (BNW * 4) + u * 64;
+        dma_src[t] = (size_t)p * plane + (size_t)(n0 + row) * C + 8 * lc;
+    }
+    f32x16 amax[2], acc[2];
+    __syncthreads();
+    for (int pass = 0; pass <= angle_k; ++pass) {
+        const bool dist = pass == angle_k;
+        const unsigned short* W3 = dist ? Wd3 : Wa3;
+        float val = 0.f;
+        if (arow_ok) val = dist ? d_idx[arow] : a_idx[arow * angle_k + pass];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+        auto dma = [&](int stage, int k0) {
+#pragma unroll
+            for (int t = 0; t < 6; ++t)
+                __builtin_amdgcn_global_load_lds(W3 + dma_src[t] + k0, to_lds(&Bs[stage][0][0] + dma_lds[t]), 16, 0, 0);
+        };
+        auto gen = [&](int stage, int k0) {   // this thread's 8 consecutive k of the embedding row -> three bf16 planes
+            const int f0 = (k0 + kq) >> 1;
+            unsigned hh[4], mm[4], ll[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float sn, cs;
+                sincos_cw(val * divs[f0 + i], sn, cs);
+                split3_pair(sn, cs, hh[i], mm[i], ll[i]);
+            }
+            As[stage][0][a_wr] = make_uint4(hh[0], hh[1], hh[2], hh[3]);
+            As[stage][1][a_wr] = make_uint4(mm[0], mm[1], mm[2], mm[3]);
+            As[stage][2][a_wr] = make_uint4(ll[0], ll[1], ll[2], ll[3]);
+        };
+        __syncthreads();   // the previous pass is done with both stages
+        dma(0, 0);
+        gen(0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        int stage = 0;
+        for (int k0 = 0; k0 < C; k0 += BK) {
+            const bool more = k0 + BK < C;
+            if (more) dma(stage ^ 1, k0 + BK);
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {   // two k-steps of 16 per slab
+                const int ch = 2 * s2 + kg;
+                bf16x8 a[3][2], b[3];
+#pragma unroll
+                for (int p = 0; p < 3; ++p) {
+                    a[p][0] = __builtin_bit_cast(bf16x8, As[stage][p][ml * 4 + (ch ^ ((ml >> 2) & 3))]);
+                    a[p][1] = __builtin_bit_cast(bf16x8, As[stage][p][(32 + ml) * 4 + (ch ^ ((ml >> 2) & 3))]);
+                    const int br = wave * 32 + ml;
+                    b[p] = __builtin_bit_cast(bf16x8, Bs[stage][p][br * 4 + (ch ^ ((br >> 2) & 3))]);
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {   // smallest terms first
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2][i], b[0], acc[i], 0, 0, 0);   // l h
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[2], acc[i], 0, 0, 0);   // h l
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][i], b[1], acc[i], 0, 0, 0);   // m m
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][i], b[0], acc[i], 0, 0, 0);   // m h
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[1], acc[i], 0, 0, 0);   // h m
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[0], acc[i], 0, 0, 0);   // h h
+                }
+            }
+            if (more) gen(stage ^ 1, k0 + BK);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            stage ^= 1;
+        }
+        if (!dist) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) amax[i][e] = pass == 0 ? acc[i][e] : fmaxf(amax[i][e], acc[i][e]);
+        }
+    }
+    const int col = n0 + wave * 32 + (lane & 31);
+    const float bdv = bd[col], bav = ba[col];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const long row = m0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+            if (row < rows) out[(size_t)row * C + col] = (acc[i][e] + bdv) + (amax[i][e] + bav);
+        }
+}
+
 }  // namespace
 
 // d_idx (rows), a_idx (rows, angle_k), div_term (C/2), proj_d / proj_a weights (C,C) + biases, out (rows, C)
@@ -180,6 +348,32 @@ extern "C" int roitr_geo_embed(long rows, int C, int angle_k, const float* d_idx
         geo_embed_kernel<2><<<dim3(C / 256, (unsigned)mt), 256, 0, stream>>>(rows, C, angle_k, d_idx, a_idx, div_term, Wd, bd, Wa, ba, out);
     else
         geo_embed_kernel<1><<<dim3(C / 128, (unsigned)mt), 256, 0, stream>>>(rows, C, angle_k, d_idx, a_idx, div_term, Wd, bd, Wa, ba, out);
+    roitr_prof_end(ROITR_PROF_GEO_EMBED, stream);
+    ROITR_LAUNCH_CHECK();
+    return ROITR_OK;
+}
+
+
+/* OPT-IN split-bf16 form of roitr_geo_embed (see geo_embed_split_kernel): W*3 = the three bf16 planes of the (C, C) weight
+ * made by roitr_split3_bf16 (3 * C * C uint16). */
+extern "C" int roitr_split3_bf16(long n, const float* src, unsigned short* dst, hipStream_t stream)
+{
+    if (n <= 0) return ROITR_OK;
+    split3_bf16_kernel<<<(unsigned)((n + 255) / 256), 256, 0, stream>>>(n, src, dst);
+    ROITR_LAUNCH_CHECK();
+    return ROITR_OK;
+}
+
+extern "C" int roitr_geo_embed_split(long rows, int C, int angle_k, const float* d_idx, const float* a_idx, const float* div_term,
+                                     const unsigned short* Wd3, const float* bd, const unsigned short* Wa3, const float* ba, float* out,
+                                     hipStream_t stream)
+{
+    if (rows <= 0) return ROITR_OK;
+    if (C % 128 || C > 1024 || angle_k < 1) return ROITR_ERR_UNSUPPORTED;
+    const long mt = (rows + BM - 1) / BM;
+    if (mt > 0x7fffffffL) return ROITR_ERR_UNSUPPORTED;
+    roitr_prof_begin(ROITR_PROF_GEO_EMBED, 2.0 * rows * (1.0 + angle_k) * (double)C * C, stream);
+    geo_embed_split_kernel<<<dim3(C / 128, (unsigned)mt), 256, 0, stream>>>(rows, C, angle_k, d_idx, a_idx, div_term, Wd3, bd, Wa3, ba, out);
     roitr_prof_end(ROITR_PROF_GEO_EMBED, stream);
     ROITR_LAUNCH_CHECK();
     return ROITR_OK;

@@ -207,3 +207,25 @@ def adaptive_superpoint_matching(src_feats, tgt_feats, src_masks, tgt_masks, min
                                         L.stream_ptr()), "adaptive_matching")
     n = int(nc.item())
     return ia[:n].long(), ib[:n].long(), sc[:n]
+
+
+def geo_embed(d_idx, a_idx, div_term, w_d, b_d, w_a, b_a, split=False):
+    """positional_encoding.py:139-154 fused: proj_d(sinusoid(d_idx)) + max_k proj_a(sinusoid(a_idx[:, k])) for `rows` index
+    rows.  split=True: the opt-in three-way bf16 split on the bf16 matrix cores (fp32-level accuracy)."""
+    rows, k = int(a_idx.shape[0]), int(a_idx.shape[1])
+    C = int(w_d.shape[0])
+    f = lambda t: t.contiguous().float()
+    d_idx, a_idx, div_term, w_d, b_d, w_a, b_a = map(f, (d_idx, a_idx, div_term, w_d, b_d, w_a, b_a))
+    out = torch.empty((rows, C), dtype=torch.float32, device=d_idx.device)
+    lib = L.lib()
+    if split:
+        wd3 = torch.empty((3, C, C), dtype=torch.int16, device=out.device)
+        wa3 = torch.empty((3, C, C), dtype=torch.int16, device=out.device)
+        L.check(lib.roitr_split3_bf16(ctypes.c_long(C * C), L.ptr(w_d), L.ptr(wd3), L.stream_ptr()), "split3")
+        L.check(lib.roitr_split3_bf16(ctypes.c_long(C * C), L.ptr(w_a), L.ptr(wa3), L.stream_ptr()), "split3")
+        L.check(lib.roitr_geo_embed_split(ctypes.c_long(rows), C, k, L.ptr(d_idx), L.ptr(a_idx), L.ptr(div_term), L.ptr(wd3), L.ptr(b_d),
+                                          L.ptr(wa3), L.ptr(b_a), L.ptr(out), L.stream_ptr()), "geo_embed_split")
+    else:
+        L.check(lib.roitr_geo_embed(ctypes.c_long(rows), C, k, L.ptr(d_idx), L.ptr(a_idx), L.ptr(div_term), L.ptr(w_d), L.ptr(b_d),
+                                    L.ptr(w_a), L.ptr(b_a), L.ptr(out), L.stream_ptr()), "geo_embed")
+    return out

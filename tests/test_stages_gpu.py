@@ -227,3 +227,27 @@ def test_forward_at_10000_matches_oracle():
     got = set(zip(out["tgt_node_corr_indices"].cpu().tolist(), out["src_node_corr_indices"].cpu().tolist()))
     exp = set(zip(ref["tgt_node_corr_indices"].tolist(), ref["src_node_corr_indices"].tolist()))
     assert len(got & exp) >= 0.97 * len(exp)   # near-tied coarse scores may swap at the cut-off
+
+
+@pytest.mark.gpu
+def test_geo_embed_fp32_and_split_bf16_against_float64():
+    """The fused geometric embedding against a float64 evaluation of positional_encoding.py:139-154, for the default fp32
+    MFMA kernel and for the opt-in three-way-split bf16 kernel: both must sit at fp32 rounding level."""
+    from roitr_amd import ops
+    rng = np.random.default_rng(4)
+    C, rows = 256, 1000
+    d = (rng.uniform(0, 3, rows) / 0.2).astype(np.float32)
+    a = (rng.uniform(0, np.pi, (rows, 3)) * 180 / (15 * np.pi)).astype(np.float32)
+    div = np.exp(np.arange(0, C, 2).astype(np.float32) * np.float32(-np.log(10000.0) / C)).astype(np.float32)
+    wd, wa = (rng.normal(size=(C, C)) / 16).astype(np.float32), (rng.normal(size=(C, C)) / 16).astype(np.float32)
+    bd, ba = rng.normal(size=C).astype(np.float32), rng.normal(size=C).astype(np.float32)
+
+    def emb(v):   # SinusoidalPositionalEmbedding: [sin(v w0), cos(v w0), sin(v w1), ...]
+        om = v.astype(np.float64)[..., None] * div.astype(np.float64)
+        return np.stack([np.sin(om), np.cos(om)], -1).reshape(*v.shape, C)
+    ref = emb(d) @ wd.astype(np.float64).T + bd + (emb(a) @ wa.astype(np.float64).T + ba).max(1)
+    scale = np.abs(ref).max()
+    for split in (False, True):
+        got = ops.geo_embed(dev(d), dev(a), dev(div), dev(wd), dev(bd), dev(wa), dev(ba), split=split).cpu().numpy().astype(np.float64)
+        err = np.abs(got - ref).max() / scale
+        assert err < 3e-6, (split, err)
