@@ -173,6 +173,9 @@ typedef struct RoitrFine {
     const float* row_pts; const float* col_pts; const float* global_scores;
     unsigned char* flags; int* counts; int* offsets; int* n_out;
     float* out_row_pts; float* out_col_pts; float* out_scores; int* out_patch;
+    long out_cap;   /* rows the out_* arrays hold (0 = caller guarantees pairs*num_corr*limit*limit): the emitter never writes past
+                       it and *n_out is clamped to it.  Worst case per patch: limit*k rows when mutual, 2*limit*k otherwise
+                       (row top-k OR column top-k, modules.py:259-266). */
 } RoitrFine;
 int roitr_fine_matching(const RoitrFine* a, roitr_stream_t stream);
 
@@ -244,7 +247,7 @@ typedef struct RoitrForwardIO {
     float* tgt_knn_pts; float* src_knn_pts;    /* (B,P,L,3) */
     int* tgt_knn_masks; int* src_knn_masks;    /* (B,P,L) */
     float* matching_scores;    /* (B,P,L+1,L+1) */
-    float* out_tgt_pts; float* out_src_pts; float* out_scores; int* out_patch;  /* capacity B*P*L*fine_topk rows */
+    float* out_tgt_pts; float* out_src_pts; float* out_scores; int* out_patch;  /* capacity B*P*L*fine_topk rows (x2 when fine_mutual == 0) */
     int* fine_offsets;         /* (B*P) first output row of every patch */
     int* n_out;                /* (1) total correspondences */
     float* gt_node_occ;        /* (T4) node occlusion scores, src clouds then tgt clouds; needs rot/trans */

@@ -431,7 +431,10 @@ def closed_form_state(factor=1):
     return sd
 
 
-def timed_baseline(n_points, budget_s=20.0, max_pairs=16):
+FDMATCH_CFG = {"adaptive": True, "num_est_coarse_corr": 128, "fine_matching_topk": 2}   # configs/test/fdmatch.yaml
+
+
+def timed_baseline(n_points, budget_s=20.0, max_pairs=16, benchmark="3DMatch", seed_config=2):
     """bench.py cpu_baseline ('port'): full forwards of pairs of the bench workload on this host's cores.
 
     FPS/kNN run in the C restatement (kNN split over all cores with threads; FPS is inherently serial per
@@ -439,17 +442,19 @@ def timed_baseline(n_points, budget_s=20.0, max_pairs=16):
     one after the other until `budget_s` seconds of wall time are used (at least one pair, at most `max_pairs`)."""
     from roitr_amd.synthetic import make_pair
     cores = len(os.sched_getaffinity(0))
-    sd = closed_form_state()
+    fd = benchmark in ("4DMatch", "4DLoMatch")
+    sd = closed_form_state(2 if fd else 1)
+    cfg = dict(FDMATCH_CFG) if fd else None
     pairs = 0
     ncorr = 0
     dt = 0.0
     while pairs < max_pairs and (pairs == 0 or dt < budget_s):
-        pair = make_pair(n_points, config=2, pair_index=pairs)
+        pair = make_pair(n_points, config=seed_config, pair_index=pairs)
         t0 = time.perf_counter()
-        out = forward(sd, pair, threads=cores)
+        out = forward(sd, pair, cfg=cfg, threads=cores)
         dt += time.perf_counter() - t0
         ncorr += int(out["corr_scores"].shape[0])
         pairs += 1
     return {"value": round(pairs / dt, 5), "unit": "pairs/s", "cores": cores, "kind": "port",
-            "sample": f"{pairs} pair(s), N={n_points} pts/cloud, full forward each, oracle/roitr_ref.py (numpy fp32 + C FPS/kNN), "
-                      f"{dt:.2f} s wall, {ncorr} correspondences"}
+            "sample": f"{pairs} pair(s), N={n_points} pts/cloud, {benchmark} settings, full fp32 forward each, oracle/roitr_ref.py "
+                      f"(numpy fp32 + C FPS/kNN), {dt:.2f} s wall, {ncorr} correspondences"}

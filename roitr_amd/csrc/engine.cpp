@@ -410,6 +410,13 @@ extern "C" int roitr_engine_finalize(void* h, hipStream_t st)
 {
     Engine& E = *(Engine*)h;
     E.err.clear();
+    // captured forwards replay kernels that read the parameter / derived-weight pointers of the previous finalize
+    for (auto& g : E.graphs) {
+        if (g.exec) (void)hipGraphExecDestroy(g.exec);
+        if (g.graph) (void)hipGraphDestroy(g.graph);
+        if (g.pin) (void)hipHostFree(g.pin);
+    }
+    E.graphs.clear();
     const int f = E.cfg.factor;
     const int C4 = 256 * f;
     // ---- resolve names (model/model.py:146-184 module tree)
@@ -879,7 +886,7 @@ extern "C" int roitr_engine_forward(void* h, const RoitrForwardIO* io, hipStream
     int* counts = A.get<int>(NP);
     int* offsets = io->fine_offsets ? io->fine_offsets : A.get<int>(NP);
     int* n_out = io->n_out ? io->n_out : A.get<int>(1);
-    const size_t cap = NP * LIM * (size_t)E.cfg.fine_topk;
+    const size_t cap = NP * LIM * (size_t)E.cfg.fine_topk * (E.cfg.fine_mutual ? 1 : 2);   // row top-k OR column top-k when not mutual
     float* o_t = io->out_tgt_pts ? io->out_tgt_pts : A.get<float>(cap * 3);
     float* o_s = io->out_src_pts ? io->out_src_pts : A.get<float>(cap * 3);
     float* o_sc = io->out_scores ? io->out_scores : A.get<float>(cap);
@@ -932,7 +939,7 @@ extern "C" int roitr_engine_forward(void* h, const RoitrForwardIO* io, hipStream
         fm.n_corr = n_corr; fm.ot = ot; fm.row_masks = tmask; fm.col_masks = smask; fm.row_pts = tpts; fm.col_pts = spts;
         fm.global_scores = E.cfg.fine_use_global_score ? cscore : nullptr;
         fm.flags = flags; fm.counts = counts; fm.offsets = offsets; fm.n_out = n_out;
-        fm.out_row_pts = o_t; fm.out_col_pts = o_s; fm.out_scores = o_sc; fm.out_patch = io->out_patch;
+        fm.out_row_pts = o_t; fm.out_col_pts = o_s; fm.out_scores = o_sc; fm.out_patch = io->out_patch; fm.out_cap = (long)cap;
         CHK(roitr_fine_matching(&fm, st));
     }
     // ---------------- ground-truth side outputs (RIGA_v2.py:91-116), only when rot / trans are given

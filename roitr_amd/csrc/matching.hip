@@ -583,7 +583,8 @@ __global__ __launch_bounds__(256) void fine_flag_kernel(RoitrFine a)
 }
 
 // exclusive scan of per-patch counts (single block), total -> *n_out
-__global__ __launch_bounds__(1024) void fine_scan_kernel(int n, const int* __restrict__ counts, int* __restrict__ offsets, int* __restrict__ n_out)
+__global__ __launch_bounds__(1024) void fine_scan_kernel(int n, const int* __restrict__ counts, int* __restrict__ offsets, int* __restrict__ n_out,
+                                                         long out_cap)
 {
     __shared__ int wsum[16];
     __shared__ int carry_s;
@@ -606,7 +607,7 @@ __global__ __launch_bounds__(1024) void fine_scan_kernel(int n, const int* __res
         if (tid == 1023) carry_s = carry + wb + incl;
         __syncthreads();
     }
-    if (tid == 0) *n_out = carry_s;
+    if (tid == 0) *n_out = (out_cap > 0 && carry_s > out_cap) ? (int)out_cap : carry_s;
 }
 
 // row-major (patch, i, j) compaction -- the order of torch.nonzero (modules.py:282)
@@ -630,9 +631,10 @@ __global__ __launch_bounds__(256) void fine_emit_kernel(RoitrFine a)
     int pos = a.offsets[patch] + incl - c;
     for (int w = 0; w < wave; ++w) pos += wsum[w];
     const float g = a.global_scores ? a.global_scores[patch] : 1.0f;
+    const long cap = a.out_cap > 0 ? a.out_cap : 0x7fffffffL;
     for (int u = 0; u < per; ++u) {
         const int e = tid * per + u;
-        if (fl[e]) {
+        if (fl[e] && pos < cap) {
             const int i = e / L, j = e % L;
             const float* rp = a.row_pts + ((size_t)patch * L + i) * 3;
             const float* cp = a.col_pts + ((size_t)patch * L + j) * 3;
@@ -736,7 +738,7 @@ extern "C" int roitr_fine_matching(const RoitrFine* a, hipStream_t stream)
     const int patches = a->pairs * a->num_corr;
     fine_flag_kernel<<<patches, 256, 0, stream>>>(*a);
     ROITR_LAUNCH_CHECK();
-    fine_scan_kernel<<<1, 1024, 0, stream>>>(patches, a->counts, a->offsets, a->n_out);
+    fine_scan_kernel<<<1, 1024, 0, stream>>>(patches, a->counts, a->offsets, a->n_out, a->out_cap);
     ROITR_LAUNCH_CHECK();
     fine_emit_kernel<<<patches, 256, 0, stream>>>(*a);
     ROITR_LAUNCH_CHECK();

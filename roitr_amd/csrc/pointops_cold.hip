@@ -1,7 +1,8 @@
 // The pointops entry points RoITr exports but never calls on its inference path:
 // grouping / interpolation / subtraction / aggregation, forward and backward.  Built complete so the
 // pybind-level API (pointops_api.cpp:15-22) has no holes.  All are HBM-bound gathers/scatters:
-// one thread per 4 consecutive channels where the channel count allows (16-B accesses), grid-stride.
+// one thread per output element (scalar 4-B accesses, consecutive threads on consecutive channels, so a
+// wave reads/writes contiguous runs), grid-stride with 64-bit indexing.  Cold path: not vectorised.
 //
 // Ownership/zeroing conventions follow the reference: `+=`-style outputs must arrive zeroed
 // (functions/pointops.py:146,199); backward scatters use atomics like the reference kernels.

@@ -100,6 +100,11 @@ void roitr_prof_begin(int cls, double bytes, hipStream_t st)
     std::lock_guard<std::mutex> lk(g_mu);
     if (g_pool.size() < 2 && g_done.size() > 256) recycle();
     Rec r; r.cls = cls; r.bytes = bytes >= 0.0 ? bytes : g_next_bytes[cls]; r.a = get_event(); r.b = get_event();
+    // MFMA work issued inside an open engine phase is also booked on the phase: the "bytes" of a phase class are the FLOPs
+    // of its GEMM / geo_embed launches (bench.py prices the global-transformer phase against the MFMA peak with them)
+    if (cls == ROITR_PROF_GEMM || cls == ROITR_PROF_GEO_EMBED)
+        for (auto& o : g_open)
+            if (o.cls >= ROITR_PROF_PH_GEOM && o.cls <= ROITR_PROF_PH_FORWARD) o.bytes += r.bytes;
     (void)hipEventRecord(r.a, st);
     g_open.push_back(r);
 }

@@ -17,6 +17,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("config")
     ap.add_argument("--pretrain", default=None)
+    ap.add_argument("--closed-form-weights", action="store_true",
+                    help="ignore any checkpoint and fill the model with the deterministic closed-form weights of roitr_amd/weights.py "
+                         "(parity / benchmark runs without a released checkpoint)")
     ap.add_argument("--synthetic", type=int, default=8, help="number of synthetic pairs (no datasets ship with this repo)")
     ap.add_argument("--n-points", type=int, default=5000)
     ap.add_argument("--snapshot-dir", default="snapshot")
@@ -31,8 +34,10 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.distributed.init_process_group("nccl")
     model = create_model(config).cuda()
-    ckpt = args.pretrain or config.get("pretrain")
-    if ckpt and os.path.exists(ckpt):
+    ckpt = None if args.closed_form_weights else (args.pretrain or config.get("pretrain"))
+    if ckpt:
+        if not os.path.exists(ckpt):   # lib/trainer.py:128-130 _load_pretrain: raise ValueError('no checkpoint found')
+            raise ValueError(f"=> no checkpoint found at '{ckpt}' (pass --closed-form-weights to run without one)")
         load_pretrain(model, ckpt)
     else:
         from .riga import state_dict_layout
@@ -41,7 +46,7 @@ def main():
         for k, shape, kind in state_dict_layout(model.factor, model.architecture):
             if kind == "param":
                 sd[k].copy_(torch.from_numpy(closed_form_param(k, tuple(shape))))
-        print(f"[roitr_amd] checkpoint {ckpt!r} not found: using closed-form weights (roitr_amd/weights.py)")
+        print("[roitr_amd] no checkpoint given: using closed-form weights (roitr_amd/weights.py)")
     data = SyntheticPairs(args.synthetic, args.n_points)
     tester = Tester(config, model, data, args.snapshot_dir, args.pairs_per_forward, rank, world, evaluate=args.evaluate,
                     estimate_normals=args.estimate_normals)

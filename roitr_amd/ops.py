@@ -56,7 +56,7 @@ class _Fine(ctypes.Structure):
     _fields_ = [("pairs", ctypes.c_int), ("num_corr", ctypes.c_int), ("limit", ctypes.c_int), ("k", ctypes.c_int),
                 ("mutual", ctypes.c_int), ("conf", ctypes.c_float), ("n_corr", _P), ("ot", _P), ("row_masks", _P),
                 ("col_masks", _P), ("row_pts", _P), ("col_pts", _P), ("global_scores", _P), ("flags", _P), ("counts", _P),
-                ("offsets", _P), ("n_out", _P), ("out_row_pts", _P), ("out_col_pts", _P), ("out_scores", _P), ("out_patch", _P)]
+                ("offsets", _P), ("n_out", _P), ("out_row_pts", _P), ("out_col_pts", _P), ("out_scores", _P), ("out_patch", _P), ("out_cap", ctypes.c_long)]
 
 
 def point_to_node_partition(points, nodes, point_limit):
@@ -138,7 +138,7 @@ def fine_matching(ref_knn_points, src_knn_points, ref_knn_masks, src_knn_masks, 
     ms = matching_scores.contiguous().float()
     gs = global_scores.contiguous().float() if global_scores is not None else None
     a = _Fine(1, B, Lm, int(k), int(mutual), float(confidence_threshold), L.ptr(nc), L.ptr(ms), L.ptr(rm), L.ptr(cm), L.ptr(rp),
-              L.ptr(cp), L.ptr(gs), L.ptr(flags), L.ptr(counts), L.ptr(offs), L.ptr(n_out), L.ptr(o_r), L.ptr(o_c), L.ptr(o_s), L.ptr(None))
+              L.ptr(cp), L.ptr(gs), L.ptr(flags), L.ptr(counts), L.ptr(offs), L.ptr(n_out), L.ptr(o_r), L.ptr(o_c), L.ptr(o_s), L.ptr(None), cap)
     L.check(L.lib().roitr_fine_matching(ctypes.byref(a), L.stream_ptr()), "fine_matching")
     n = int(n_out.item())
     return o_r[:n], o_c[:n], o_s[:n]

@@ -306,6 +306,19 @@ class RIGA_v2(nn.Module):
 
     GRAPH_RING = 3   # persistent io buffer sets per shape in graph mode
 
+    @staticmethod
+    def _have_gt(pairs, want_gt):
+        """The ground-truth side outputs need rot AND trans for EVERY pair of the batch; a mixed batch is an error
+        (the engine computes them for all pairs of a call or for none)."""
+        if not want_gt:
+            return False
+        flags = [p.get("rot") is not None and p.get("trans") is not None for p in pairs]
+        if any(flags) and not all(flags):
+            missing = [i for i, f in enumerate(flags) if not f]
+            raise L.RoitrError(f"pairs {missing} of this batch have no rot/trans while others do: pass want_gt=False or give "
+                               "every pair its ground-truth transform")
+        return all(flags)
+
     def launch_batch(self, pairs, want_gt=True, graph=False):
         """Enqueue the batched forward on the current stream and return a handle for finish_batch().  Nothing here waits
         for the GPU: a caller may launch batch s+1 before finishing batch s, so the device never idles while the host
@@ -336,7 +349,7 @@ class RIGA_v2(nn.Module):
         n4max = max(n4)
         P = self.num_est_coarse_corr if self.factor == 1 else n4max * n4max   # adaptive matching: every node pair may qualify
         Lm = self.point_per_patch
-        cap = B * P * Lm * self.fine_topk
+        cap = B * P * Lm * self.fine_topk * (1 if self.fine_mutual else 2)   # row top-k OR column top-k when not mutual
         z = lambda shape, dt=f32: torch.empty(shape, dtype=dt, device=dev)  # every buffer is fully written by the engine
         i32 = torch.int32
         out = dict(node_xyz=z((T4, 3)), node_feats=z((T4, C)), point_feats=z((T, C)), node_masks=z((T4,), i32),
@@ -345,7 +358,7 @@ class RIGA_v2(nn.Module):
                    tgt_knn_masks=z((B, P, Lm), i32), src_knn_masks=z((B, P, Lm), i32), matching_scores=z((B, P, Lm + 1, Lm + 1)),
                    out_tgt_pts=z((cap, 3)), out_src_pts=z((cap, 3)), out_scores=z((cap,)), out_patch=z((cap,), i32),
                    fine_offsets=z((B * P,), i32), n_out=z((1,), i32))
-        have_gt = want_gt and pairs[0].get("rot") is not None
+        have_gt = self._have_gt(pairs, want_gt)
         if have_gt:
             out.update(gt_node_occ=z((T4,)), gt_corr_idx=z((B, n4max * n4max, 2), i32), gt_corr_overlaps=z((B, n4max * n4max)),
                        gt_corr_count=z((B,), i32))
@@ -378,7 +391,7 @@ class RIGA_v2(nn.Module):
         B = len(pairs)
         f32, i32 = torch.float32, torch.int32
         n_all = [int(p["src_raw_pcd"].shape[0]) for p in pairs] + [int(p["tgt_pcd"].shape[0]) for p in pairs]
-        have_gt = want_gt and pairs[0].get("rot") is not None
+        have_gt = self._have_gt(pairs, want_gt)
         key = (tuple(n_all), have_gt)
         if not hasattr(self, "_graph_slots"):
             self._graph_slots, self._graph_stream = {}, torch.cuda.Stream()
@@ -389,7 +402,7 @@ class RIGA_v2(nn.Module):
         C = 256 * self.factor
         P = self.num_est_coarse_corr if self.factor == 1 else n4max * n4max
         Lm = self.point_per_patch
-        cap = B * P * Lm * self.fine_topk
+        cap = B * P * Lm * self.fine_topk * (1 if self.fine_mutual else 2)   # row top-k OR column top-k when not mutual
         if len(ring["slots"]) < self.GRAPH_RING:
             z = lambda shape, dt=f32: torch.empty(shape, dtype=dt, device=dev)
             out = dict(node_xyz=z((T4, 3)), node_feats=z((T4, C)), point_feats=z((T, C)), node_masks=z((T4,), i32),
@@ -435,8 +448,23 @@ class RIGA_v2(nn.Module):
             slot["meta_host"].copy_(slot["meta_dev"], non_blocking=True)
             done = torch.cuda.Event()
             done.record()
+        # the replay ran on the private capture stream: order every later use of the engine's shared scratch arena and of
+        # these output slots (a plain launch_batch, evaluate_batch, user code on the current stream) behind it
+        torch.cuda.current_stream().wait_stream(gs)
         keep = (slot["geom"], slot["pout"], slot["nrm"], slot["feats"], slot["rot"], slot["trans"], slot["arr"], slot["meta_dev"])
         return dict(pairs=pairs, out=out, B=B, P=P, n_all=n_all, n4=n4, have_gt=have_gt, meta_host=slot["meta_host"], done=done, keep=keep)
+
+    def max_scores_per_pair(self):
+        """Correspondence capacity of one pair's result record (shard.py): exact for the 3DMatch settings; the adaptive
+        4DMatch matching may select every node pair, there the record keeps 4x its min_num_correspondences patches."""
+        from .shard import max_scores_per_pair
+        patches = self.num_est_coarse_corr if self.factor == 1 else 4 * self.num_est_coarse_corr
+        return max_scores_per_pair(patches, self.point_per_patch, self.fine_topk, self.fine_mutual)
+
+    def batch_records(self, handle, pair_ids, aux=None):
+        """The result records (shard.py layout) of a FINISHED batch, packed on the device."""
+        from .shard import pack_records
+        return pack_records(pair_ids, handle["starts"], handle["out"]["out_scores"], self.max_scores_per_pair(), aux)
 
     def graph_count(self):
         """Forwards currently held as instantiated HIP graphs."""
@@ -448,6 +476,7 @@ class RIGA_v2(nn.Module):
         h["done"].synchronize()
         meta = h["meta_host"].tolist()
         starts, n_corr, gt_cnt = meta[:B + 1], meta[B + 1:2 * B + 1], meta[2 * B + 1:]
+        h["starts"] = starts   # row offsets of every pair in out_scores (+ total): shard.pack_records reads them
         o_pts = np.cumsum([0] + n_all)
         o_nod = np.cumsum([0] + n4)
         results = []

@@ -32,8 +32,19 @@ def _normals(rng, pts):
     return n
 
 
-def make_pair(n_src, n_tgt=None, config=2, pair_index=0, overlap=0.6, jitter=0.002):
-    """Returns a dict of float32 numpy arrays following the reference input contract."""
+def euler_zyx(a):
+    """scipy Rotation.from_euler('zyx', a).as_matrix() (dataset/tdmatch.py:102): extrinsic rotations about z, then y, then x."""
+    cz, sz, cy, sy, cx, sx = np.cos(a[0]), np.sin(a[0]), np.cos(a[1]), np.sin(a[1]), np.cos(a[2]), np.sin(a[2])
+    rz = np.array([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1.0]])
+    ry = np.array([[cy, 0, sy], [0, 1.0, 0], [-sy, 0, cy]])
+    rx = np.array([[1.0, 0, 0], [0, cx, -sx], [0, sx, cx]])
+    return rx @ ry @ rz
+
+
+def make_pair(n_src, n_tgt=None, config=2, pair_index=0, overlap=0.6, jitter=0.002, rotated=None):
+    """Returns a dict of float32 numpy arrays following the reference input contract.
+    rotated (default: config == 3, BASELINE config 3 "3DLoMatch rotated"): the test-time rotation of dataset/tdmatch.py:99-112 --
+    a seeded full-range euler rotation applied to the source or the target cloud, folded into rot / trans."""
     n_tgt = n_src if n_tgt is None else n_tgt
     rng = np.random.default_rng(1000 * config + pair_index)
     # one scene, two crops along x that share `overlap` of their extent
@@ -51,6 +62,17 @@ def make_pair(n_src, n_tgt=None, config=2, pair_index=0, overlap=0.6, jitter=0.0
     rot = random_rotation(rng)
     trans = rng.uniform(-1.0, 1.0, (3, 1))
     tgt = tgt_scene @ rot.T + trans.T
+    if rotated is None:
+        rotated = config == 3
+    if rotated:
+        rot_ab = euler_zyx(rng.random(3) * np.pi * 2.0)
+        if rng.random() > 0.5:
+            src = src @ rot_ab.T
+            rot = rot @ rot_ab.T
+        else:
+            tgt = tgt @ rot_ab.T
+            rot = rot_ab @ rot
+            trans = rot_ab @ trans
     src_n = _normals(rng, src)
     tgt_n = _normals(rng, tgt)
     f32 = np.float32

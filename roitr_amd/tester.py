@@ -5,13 +5,15 @@ Per pair it writes `{snapshot_dir}/{benchmark}/{idx}.pth` with exactly the keys 
 Differences by design: pairs are sharded over ranks by their GLOBAL index (pair i -> rank i mod W, the file name
 keeps the global index -- the reference's DDP test mode would overwrite files), several
 pairs go through the engine per forward (`pairs_per_forward`), and checkpoints load through the same
-'module.'-stripping rule as lib/trainer.py:94-130.
+'module.'-stripping rule as lib/trainer.py:94-130.  At the end of the run ONE collective (shard.gather_result_records:
+a gather of the fixed-size per-pair records {pair id, #correspondences, IR, PIR, match scores} over RCCL) brings every
+rank's results to rank 0; `Tester.records` holds them there.
 """
 import os
 
 import torch
 
-from .shard import gather_counts, pairs_for_rank
+from .shard import gather_result_records, pairs_for_rank, slots_per_rank
 
 
 def load_pretrain(model, path):
@@ -35,6 +37,7 @@ class Tester:
         self.rank, self.world = rank, world
         self.evaluate, self.estimate_normals, self.view_point = evaluate, estimate_normals, view_point
         self.metrics = None
+        self.records = None   # rank 0 after test(): shard.GatheredRecords {pair id: match scores}
 
     def _to_device(self, item, device):
         out = {}
@@ -50,7 +53,6 @@ class Tester:
         mine = pairs_for_rank(n, self.rank, self.world)
         device = next(self.model.parameters()).device
         self.model.eval()
-        total_corr = 0
         def load(s):
             ids = mine[s:s + self.pairs_per_forward]
             items = [self._to_device(self.dataset[i], device) for i in ids]
@@ -73,7 +75,7 @@ class Tester:
         if self.evaluate:
             from .evaluate import Evaluator
             evaluator = Evaluator(self.config)
-        sums = torch.zeros(3, dtype=torch.float64, device=device)   # sum IR, sum PIR, pairs
+        blocks = []   # packed result records of every batch (device)
         with torch.no_grad():
             starts = list(range(0, len(mine), self.pairs_per_forward))
             nxt = load(starts[0]) if starts else None
@@ -81,10 +83,12 @@ class Tester:
                 ids, items, pairs, handle = nxt
                 # the next batch is loaded and enqueued before this one is unpacked and written to disk
                 nxt = load(starts[k + 1]) if k + 1 < len(starts) else None
+                aux = None
                 if evaluator is not None:
                     ir, pir, _, _ = evaluator.evaluate_batch(handle)
-                    sums += torch.stack([ir.double().sum(), torch.nan_to_num(pir.double()).sum(), torch.tensor(float(len(ids)), device=device, dtype=torch.float64)])
+                    aux = torch.stack([ir.float(), pir.float()], 1)
                 outs = self.model.finish_batch(handle)
+                blocks.append(self.model.batch_records(handle, ids, aux))
                 for idx, it, p, o in zip(ids, items, pairs, outs):
                     data = dict()  # lib/tester.py:56-69
                     data["src_raw_pcd"] = p["src_raw_pcd"].cpu()
@@ -100,13 +104,24 @@ class Tester:
                     if benchmark in ("4DMatch", "4DLoMatch") and "metric_index" in it:
                         data["metric_index_list"] = it["metric_index"]
                     torch.save(data, os.path.join(out_dir, f"{idx}.pth"))
-                    total_corr += int(o["corr_scores"].shape[0])
+        # ---- the one collective of the run: every rank's records -> rank 0 (RCCL over xGMI under torch.distributed.run)
+        max_scores = self.model.max_scores_per_pair()
+        from .shard import empty_records
+        mine_block = torch.cat(blocks, 0) if blocks else empty_records(0, max_scores, device)
+        self.records = gather_result_records(mine_block, slots_per_rank(n, self.world), max_scores)
+        if self.records is None:     # ranks other than 0
+            return None
+        counts = [0] * self.world
+        for pid, cnt in self.records.n_scores.items():
+            counts[pid % self.world] += cnt
         if evaluator is not None:
-            if torch.distributed.is_available() and torch.distributed.is_initialized():
-                torch.distributed.all_reduce(sums)   # RCCL: three doubles
-            n_eval = max(float(sums[2]), 1.0)
-            self.metrics = {"IR": float(sums[0]) / n_eval, "PIR": float(sums[1]) / n_eval, "pairs": int(sums[2])}
-        return gather_counts(total_corr)
+            # PIR of a pair without coarse correspondences is the mean of an empty tensor = nan in the reference
+            # (lib/loss.py:191): such pairs are left out of the PIR mean (and counted) instead of poisoning it or counting as 0
+            irs = [a[0] for a in self.records.aux.values()]
+            pirs = [a[1] for a in self.records.aux.values() if a[1] == a[1]]
+            self.metrics = {"IR": sum(irs) / max(len(irs), 1), "PIR": sum(pirs) / max(len(pirs), 1), "pairs": len(irs),
+                            "pairs_without_coarse": len(irs) - len(pirs)}
+        return counts
 
 
 class SyntheticPairs(torch.utils.data.Dataset):

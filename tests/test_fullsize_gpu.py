@@ -1,0 +1,98 @@
+"""GPU parity at the FULL sizes of BASELINE.json configs 4 and 5 (and the reference's 30000-point cap) against the CPU oracle.
+
+  * config 5: N = 30000, k = 64 kNN (+ fused PPF): neighbour indices and squared distances bit-equal to oracle/pointops_ref.c,
+    PPF within 3e-6 of oracle/roitr_ref.calc_ppf, one cloud and a 4-cloud batch;
+  * config 4 sizes: 4DMatch settings, N = 8000 per cloud, fp32 engine vs oracle/roitr_ref.forward (the oracle's 4DMatch
+    configuration is pinned to the reference by tests/test_oracle_cpu.py::test_oracle_4dmatch_forward_matches_reference_golden);
+  * 3DMatch settings at the reference's point cap N = 30000 (dataset/tdmatch.py:41): engine vs oracle.
+Tolerances (north star): indices / partition identical, fp32 features within 1e-4.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from gpu_util import build_model, pair_to_device  # noqa: E402
+from oracle import pointops_cpu as O  # noqa: E402  (checker only)
+from oracle import roitr_ref as R  # noqa: E402  (checker only)
+
+CORES = len(os.sched_getaffinity(0))
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def unit(rng, n):
+    v = rng.standard_normal((n, 3))
+    return (v / np.linalg.norm(v, axis=1, keepdims=True)).astype(np.float32)
+
+
+@pytest.mark.parametrize("sizes", [[30000], [30000, 30000, 29000, 30000]])
+def test_knn64_ppf_at_30000(sizes):
+    from roitr_amd import pointops as P
+    rng = np.random.default_rng(500 + len(sizes))
+    n = sum(sizes)
+    xyz = (rng.random((n, 3)) * 2).astype(np.float32)
+    nrm = unit(rng, n)
+    off = np.cumsum(sizes).astype(np.int32)
+    ridx, rd2 = O.knnquery_raw(65, xyz, xyz, off, off, threads=CORES)
+    idx, d2 = P.knnquery_raw(65, dev(xyz), dev(xyz), dev(off), dev(off))
+    assert np.array_equal(d2.cpu().numpy(), rd2)
+    assert np.array_equal(idx.cpu().numpy(), ridx)
+    grp, ppf = P.knn_ppf(64, dev(xyz), dev(xyz), dev(nrm), dev(nrm), dev(off), dev(off))
+    grp = grp.cpu().numpy()
+    assert np.array_equal(grp, ridx[:, 1:])          # queryandgroup drops column 0 (pointops.py:88-89)
+    ppf = ppf.cpu().numpy()
+    for lo in range(0, n, 16384):                     # oracle PPF in slabs (memory)
+        hi = min(lo + 16384, n)
+        g = grp[lo:hi].astype(np.int64)
+        ref = R.calc_ppf(xyz[lo:hi], nrm[lo:hi], xyz[g], nrm[g])
+        np.testing.assert_allclose(ppf[lo:hi], ref, rtol=0, atol=3e-6)
+
+
+def _check_forward(out, ref, feat_atol=1e-4):
+    for k in ("src_nodes", "tgt_nodes"):
+        assert np.array_equal(out[k].cpu().numpy(), ref[k]), k
+    for k in ("src_node_feats", "tgt_node_feats", "src_point_feats", "tgt_point_feats"):
+        err = float(np.abs(out[k].cpu().numpy() - ref[k]).max())
+        assert err < feat_atol, (k, err)
+    for side in ("src", "tgt"):
+        assert np.array_equal(out[f"_{side}_node_knn_indices"].cpu().numpy(), ref[f"_{side}_node_knn_indices"]), side
+        assert np.array_equal(out[f"_{side}_node_masks"].cpu().numpy(), ref[f"_{side}_node_masks"]), side
+
+
+def test_4dmatch_forward_at_8000_matches_oracle():
+    """BASELINE config 4 sizes in fp32: N = 8000 per cloud, factor-2 widths, adaptive coarse matching, top-2 fine matching."""
+    from roitr_amd.synthetic import make_pair
+    pair = make_pair(8000, config=4, pair_index=2)
+    model = build_model("4DMatch")
+    with torch.no_grad():
+        out = model.forward(**pair_to_device(pair))
+    ref = R.forward(R.closed_form_state(2), pair, cfg=dict(R.FDMATCH_CFG), threads=CORES)
+    _check_forward(out, ref)
+    # adaptive matching: the selected node pairs are identical as a set (near-equal scores may swap places in the order)
+    got = sorted(zip(out["tgt_node_corr_indices"].tolist(), out["src_node_corr_indices"].tolist()))
+    want = sorted(zip(ref["tgt_node_corr_indices"].tolist(), ref["src_node_corr_indices"].tolist()))
+    assert got == want
+    n, nr = out["corr_scores"].shape[0], ref["corr_scores"].shape[0]
+    assert abs(n - nr) <= max(3, 0.02 * nr), (n, nr)
+    sc = out["corr_scores"].cpu().numpy()
+    assert (sc > 0.05).all()
+
+
+def test_3dmatch_forward_at_30000_matches_oracle():
+    """The reference's point cap (30000 per cloud -> 468 superpoints): streaming FPS, streaming self attention, chunked coarse top-k."""
+    from roitr_amd.synthetic import make_pair
+    pair = make_pair(30000, config=5, pair_index=0)
+    model = build_model("3DMatch")
+    with torch.no_grad():
+        out = model.forward(**pair_to_device(pair))
+    ref = R.forward(R.closed_form_state(), pair, threads=CORES)
+    _check_forward(out, ref)
+    got = set(zip(out["tgt_node_corr_indices"].tolist(), out["src_node_corr_indices"].tolist()))
+    want = set(zip(ref["tgt_node_corr_indices"].tolist(), ref["src_node_corr_indices"].tolist()))
+    assert len(got & want) >= 0.98 * len(want)       # top-256 of 468 x 468 scores: ties at the cut may differ

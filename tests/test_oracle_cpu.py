@@ -130,3 +130,26 @@ def test_adaptive_matching_stage(golden_stages):
         ia, ib, sc = R.adaptive_matching(s["coarse.ref_f"], s["coarse.src_f"], s["coarse.ref_m"], s["coarse.src_m"], mn, 0.75)
         assert np.array_equal(ia, s[f"{tag}.a_idx"]) and np.array_equal(ib, s[f"{tag}.b_idx"])
         np.testing.assert_allclose(sc, s[f"{tag}.scores"], rtol=1e-5)
+
+
+def test_oracle_4dmatch_forward_matches_reference_golden():
+    """The oracle in its 4DMatch configuration (factor 2 widths, AdaptiveSuperPointMatching, top-2 fine matching) against the
+    end-to-end tensors captured from the reference (make_golden.py fdmatch_golden): pins the checker the full-size 4DMatch
+    GPU tests (tests/test_fullsize_gpu.py) rely on."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "pair_4dmatch_n1024.npz"))
+    out = R.forward(R.closed_form_state(2), inputs(g), cfg=dict(R.FDMATCH_CFG), threads=4)
+    for k in ("src_nodes", "tgt_nodes"):
+        assert np.array_equal(out[k], g["out." + k])
+    for k in ("src_node_feats", "tgt_node_feats"):
+        assert np.abs(out[k] - g["out." + k]).max() < ATOL
+    for k in ("src_point_feats", "tgt_point_feats"):
+        assert np.abs(out[k][::8] - g[f"out.{k}.every8"]).max() < ATOL
+    assert np.array_equal(out["tgt_node_corr_indices"], g["out.tgt_node_corr_indices"])
+    assert np.array_equal(out["src_node_corr_indices"], g["out.src_node_corr_indices"])
+    ms, ref = out["matching_scores"][::8], g["out.matching_scores.every8"]
+    tm = np.concatenate([out["tgt_node_corr_knn_masks"][::8], np.ones((ref.shape[0], 1), bool)], 1)
+    sm = np.concatenate([out["src_node_corr_knn_masks"][::8], np.ones((ref.shape[0], 1), bool)], 1)
+    valid = tm[:, :, None] & sm[:, None, :]
+    assert np.abs(ms - ref)[valid].max() < 1e-4
+    assert out["corr_scores"].shape[0] == g["out.corr_scores"].shape[0]

@@ -1,0 +1,47 @@
+"""GPU: the one collective of the path through RCCL.  A 1-rank 'nccl' process group is created on the box in a child
+process (bounded by a timeout so that a wedged RCCL init cannot hang the suite) and the product's own
+shard.gather_result_records round-trips the records of a real engine batch through it."""
+import os
+import subprocess
+import sys
+import textwrap
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = textwrap.dedent("""
+    import os, sys, json
+    sys.path.insert(0, %r)
+    import torch, torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    from roitr_amd.harness import build_model, pair_to_device
+    from roitr_amd.shard import gather_result_records
+    from roitr_amd.synthetic import make_pair
+    model = build_model("3DMatch")
+    pairs = [pair_to_device(make_pair(1024, config=1, pair_index=i)) for i in range(3)]
+    with torch.no_grad():
+        h = model.launch_batch(pairs)
+        outs = model.finish_batch(h)
+    block = model.batch_records(h, [10, 11, 12])
+    rec = gather_result_records(block, 4, model.max_scores_per_pair())
+    ok = all(torch.equal(rec[10 + i], outs[i]["corr_scores"].cpu()) for i in range(3))
+    print("RESULT " + json.dumps({"backend": rec.backend, "ranks": rec.ranks_seen, "n": len(rec), "equal": ok,
+                                  "counts": [rec.n_scores[10 + i] for i in range(3)], "trunc": rec.truncated}), flush=True)
+    dist.destroy_process_group()
+""") % ROOT
+
+
+def test_result_gather_through_rccl_world1(tmp_path):
+    import json
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29577", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+    res = [json.loads(l.split("RESULT ", 1)[1]) for l in r.stdout.splitlines() if "RESULT " in l]
+    assert res and res[0]["backend"] == "nccl" and res[0]["ranks"] == 1 and res[0]["n"] == 3
+    assert res[0]["equal"] and res[0]["trunc"] == [] and sum(res[0]["counts"]) > 0

@@ -10,15 +10,26 @@ WORKER = textwrap.dedent("""
     import os, sys, json
     sys.path.insert(0, %r)
     import torch, torch.distributed as dist
-    from roitr_amd.shard import pairs_for_rank, gather_counts, gather_result_records
+    from roitr_amd.shard import pairs_for_rank, gather_counts, gather_result_records, pack_records, slots_per_rank
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     mine = pairs_for_rank(7, rank, world)
     counts = gather_counts(sum(mine))
-    recs = [(i, torch.arange(i + 1, dtype=torch.float32) * (rank + 1)) for i in mine]
-    merged = gather_result_records(recs)
+    # the tester's path: records of a finished engine batch packed from (pair ids, row offsets, flat scores, aux)
+    lens = [i + 1 for i in mine]
+    starts = [0]
+    for n in lens:
+        starts.append(starts[-1] + n)
+    flat = torch.cat([torch.arange(n, dtype=torch.float32) * (rank + 1) for n in lens])
+    aux = torch.tensor([[0.5 * i, float("nan") if i == 3 else 0.25 * i] for i in mine], dtype=torch.float32)
+    MAXS = 6   # pair 6 has 7 scores: its tail is cut and flagged
+    block = pack_records(mine, starts, flat, MAXS, aux)
+    merged = gather_result_records(block, slots_per_rank(7, world), MAXS)
     out = {"rank": rank, "mine": mine, "counts": counts,
-           "merged": None if merged is None else {str(k): v.tolist() for k, v in sorted(merged.items())}}
+           "merged": None if merged is None else {str(k): v.tolist() for k, v in sorted(merged.items())},
+           "meta": None if merged is None else {"n": {str(k): v for k, v in merged.n_scores.items()}, "trunc": merged.truncated,
+                                                "ranks": merged.ranks_seen, "backend": merged.backend,
+                                                "aux": {str(k): [a if a == a else None for a in v] for k, v in merged.aux.items()}}}
     print("RESULT " + json.dumps(out), flush=True)
     dist.destroy_process_group()
 """) % ROOT
@@ -54,4 +65,21 @@ def test_two_process_gather_gloo(tmp_path):
     assert sorted(map(int, merged)) == list(range(7))
     for i in range(7):
         scale = 1 if i % 2 == 0 else 2
-        assert merged[str(i)] == [float(v * scale) for v in range(i + 1)]
+        assert merged[str(i)] == [float(v * scale) for v in range(min(i + 1, 6))]
+    meta = by_rank[0]["meta"]
+    assert meta["ranks"] == 2 and meta["backend"] == "gloo" and meta["trunc"] == [6]
+    assert meta["n"] == {str(i): i + 1 for i in range(7)}            # true counts survive the cut
+    assert meta["aux"]["2"] == [1.0, 0.5] and meta["aux"]["3"] == [1.5, None]   # IR / PIR ride in the header (nan kept)
+
+
+def test_single_process_records_round_trip():
+    """No process group: the same call returns the local records (what bench.py --gpus 1 and a 1-GPU tester run use)."""
+    import torch
+    sys.path.insert(0, ROOT)
+    from roitr_amd.shard import gather_result_records, max_scores_per_pair
+    assert max_scores_per_pair(256, 64, 3) == 49152 and max_scores_per_pair(256, 64, 3, mutual=False) == 98304
+    recs = [(5, torch.tensor([0.25, 0.5])), (9, torch.zeros(0)), (2, torch.arange(4.0), (0.75, 0.125))]
+    got = gather_result_records(recs, 4, 8)
+    assert got.backend == "local" and got.ranks_seen == 1 and len(got) == 3 and sorted(got.keys()) == [2, 5, 9]
+    assert got[5].tolist() == [0.25, 0.5] and got[9].numel() == 0 and got[2].tolist() == [0.0, 1.0, 2.0, 3.0]
+    assert got.aux[2] == (0.75, 0.125) and got.n_scores == {5: 2, 9: 0, 2: 4}

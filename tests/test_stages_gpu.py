@@ -98,8 +98,14 @@ def test_tester_writes_reference_result_files(tmp_path):
     ckpt = tmp_path / "model.pth"
     torch.save({"epoch": 1, "state_dict": {"module." + k: v.cpu() for k, v in src.state_dict().items()}}, ckpt)
     model = load_pretrain(create_model(test_config("3DMatch")), str(ckpt)).cuda()
-    counts = Tester(test_config("3DMatch"), model, SyntheticPairs(3, 1024, config=1), str(tmp_path), pairs_per_forward=2).test()
+    tester = Tester(test_config("3DMatch"), model, SyntheticPairs(3, 1024, config=1), str(tmp_path), pairs_per_forward=2)
+    counts = tester.test()
     assert len(counts) == 1
+    # the run's result records (what the one gather of a multi-GPU run carries to rank 0): every pair's match scores
+    assert sorted(tester.records.keys()) == [0, 1, 2] and tester.records.truncated == []
+    for i in range(3):
+        assert torch.equal(tester.records[i], torch.load(tmp_path / "3DMatch" / f"{i}.pth")["confidence"])
+    assert counts[0] == sum(tester.records.n_scores.values())
     for i in range(3):
         d = torch.load(tmp_path / "3DMatch" / f"{i}.pth")
         assert set(d) == {"src_raw_pcd", "src_pcd", "tgt_pcd", "src_nodes", "tgt_nodes", "src_node_desc", "tgt_node_desc",
