@@ -62,8 +62,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-single-pair", action="store_true", help="skip the one-pair-per-call measurement (profiling passes)")
     ap.add_argument("--no-profile-pass", action="store_true", help="skip the instrumented repeat of the timed steps (no rooflines)")
-    ap.add_argument("--rccl-selftest", action="store_true",
-                    help="N=1 without torch.distributed.run: create a 1-rank RCCL group so that the result gather runs through RCCL")
+    ap.add_argument("--no-rccl-selftest", action="store_true",
+                    help="N=1 without torch.distributed.run: do NOT create the 1-rank RCCL group the result gather otherwise runs through")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=20.0)
     return ap.parse_args()
 
@@ -83,10 +83,14 @@ def main():
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl")  # RCCL on ROCm
-    elif args.rccl_selftest:
+    elif not args.no_rccl_selftest:
+        # one GPU, no launcher: a 1-rank RCCL group, so that the path's collective goes through RCCL here as well
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29591")
-        dist.init_process_group("nccl", rank=0, world_size=1)
+        os.environ.setdefault("MASTER_PORT", str(29600 + os.getpid() % 300))
+        try:
+            dist.init_process_group("nccl", rank=0, world_size=1)
+        except Exception as e:   # e.g. the port is taken: the gather then stays local (reported as backend "local")
+            print(f"[bench] 1-rank RCCL group not created: {e}", file=sys.stderr)
 
     from roitr_amd.harness import build_model, pair_to_device
     from roitr_amd.shard import gather_result_records, pairs_for_rank
@@ -138,6 +142,8 @@ def main():
     with torch.no_grad():
         for s in range(args.warmup):
             model.forward_batch(batch(s), want_gt=True)
+        # the collective once, untimed: the first call creates the RCCL communicator and loads the packing kernels
+        run_steps(0, 1, gather=True)
         barrier()
         gc.collect()
         gc.disable()   # a generation-2 collection of the result dicts costs ~40 ms every dozen steps

@@ -39,8 +39,20 @@ typedef struct RoitrGemm {
      * i.e. the GEMM followed by roitr_add_layernorm in one launch (ln_res / ln_post rows are 64 floats, dense). */
     const float* ln_gamma; const float* ln_beta; const float* ln_res; const int* ln_res_idx; const float* ln_post;
     int ln_relu; float ln_eps;
+    /* bf16 operand mode (0 = the fp32 kernel above): a mask of ROITR_BF16_*.  The products run on the bf16 matrix cores with
+     * fp32 accumulation; W MUST be stored bf16 (ROITR_BF16_W: `W` then points to uint16 data, ldw / sW in elements), A is
+     * fp32 and rounded while it is staged unless ROITR_BF16_A says it is stored bf16 (`A` -> uint16, A2 unsupported), C is
+     * written bf16 (uint16, ldc / sC in elements) with ROITR_BF16_C.  bias / ln_* stay fp32.  Needs K % 64 == 0 and
+     * 16-byte aligned rows (roitr_gemm_bf16_supported). */
+    int bf16;
 } RoitrGemm;
+#define ROITR_BF16_W 1
+#define ROITR_BF16_A 2
+#define ROITR_BF16_C 4
 int roitr_gemm(const RoitrGemm* g, roitr_stream_t stream);
+int roitr_gemm_bf16_supported(const RoitrGemm* g);
+/* fp32 -> bf16 (round to nearest even), n elements; dst 4-byte aligned */
+int roitr_f32_to_bf16(long n, const float* src, unsigned short* dst, roitr_stream_t stream);
 
 /* ------------------------------------------------------------------ row-wise layers */
 /* out = act( LayerNorm(x + res[res_idx]) * gamma + beta (+ post_add) ); res, res_idx, post_add optional.
@@ -67,6 +79,10 @@ int roitr_split3_bf16(long n, const float* src, unsigned short* dst, roitr_strea
 int roitr_geo_embed_split(long rows, int C, int angle_k, const float* d_idx, const float* a_idx, const float* div_term,
                           const unsigned short* Wd3, const float* bd, const unsigned short* Wa3, const float* ba, float* out,
                           roitr_stream_t stream);
+/* bf16 operand form (engine operand_dtype = 1): Wd / Wa = the (C, C) weights stored bf16, sinusoid rounded to bf16, fp32 accumulate */
+int roitr_geo_embed_bf16(long rows, int C, int angle_k, const float* d_idx, const float* a_idx, const float* div_term,
+                         const unsigned short* Wd, const float* bd, const unsigned short* Wa, const float* ba, float* out,
+                         roitr_stream_t stream);
 /* E = P_d + max_k P_a[:, k, :] (positional_encoding.py:146-152) */
 int roitr_geo_combine(long rows, int C, int k, const float* pd, const float* pa, float* out, roitr_stream_t stream);
 int roitr_gather_rows(long rows, int C, const float* in, const int* idx, int limit, float* out, roitr_stream_t stream);
@@ -224,6 +240,10 @@ typedef struct RoitrEngineConfig {
     int adaptive_coarse;   /* 1 = AdaptiveSuperPointMatching (4DMatch): num_corr is then its min_num_correspondences and
                               the per-pair patch capacity becomes n_tgt_nodes_max * n_src_nodes_max */
     float occlusion_radius;/* lib/utils.py:485 overlap_thres */
+    int operand_dtype;     /* 0 = fp32 everywhere (the reference's arithmetic); 1 = bf16 operand storage for the dense layers
+                              (BASELINE config 4): weights stored bf16 once at finalize, activations rounded to bf16 as MFMA
+                              operands, GEMM-to-GEMM intermediates stored bf16, fp32 accumulation / bias / LayerNorm / softmax;
+                              FPS, kNN, PPF, partition, coarse scores, optimal transport and fine matching stay fp32 */
 } RoitrEngineConfig;
 
 typedef struct RoitrForwardIO {

@@ -42,6 +42,7 @@ constexpr int GRID_MIN_POINTS = 768;  // clouds at or below this are scanned bru
 
 struct Lin {
     const float* w = nullptr; const float* b = nullptr; int out = 0, in = 0;
+    const unsigned short* wb = nullptr;   // the weight stored in bf16 (operand_dtype = 1 only)
 };
 
 struct LocalT {  // LocalPPFTransformer (+ derived weights)
@@ -49,6 +50,7 @@ struct LocalT {  // LocalPPFTransformer (+ derived weights)
     const float* norm_w = nullptr; const float* norm_b = nullptr;
     int in_dim = 0, H = 0, out_dim = 0;
     float* wqkv = nullptr;  // rows: [Wq (H) ; Wqp (5*HEADS) ; Wk (H) ; Wv (H)] x H
+    unsigned short* wqkv_b = nullptr;   // the same, stored bf16 (operand_dtype = 1)
     float* bqkv = nullptr;
     float* wvpe = nullptr;  // (H,4)
     float* bvpe = nullptr;  // (H)
@@ -70,6 +72,7 @@ struct GeoLayer {
     Ffn out, pos;
     float* wqkv = nullptr; float* bqkv = nullptr;  // self: [Wq;Wk;Wv]
     float* wpT = nullptr;                          // self: transpose(Wp)
+    unsigned short* wqkv_b = nullptr; unsigned short* wpT_b = nullptr;   // stored bf16 (operand_dtype = 1)
 };
 
 struct Arena {
@@ -112,6 +115,7 @@ struct Engine {
     hipStream_t side = nullptr;      // FPS chain runs here, beside the level-1 encoder work
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     std::string err;
+    hipStream_t fin_stream = nullptr;   // stream of the running finalize (weight conversions are queued on it)
     // ---- captured forwards (roitr_engine_forward_graph): one hipGraphExec per (sizes, io pointers) key
     struct GraphEntry {
         std::vector<long> key;
@@ -144,47 +148,74 @@ Lin lin(Engine& E, const std::string& prefix, int out, int in)
     l.w = P(E, prefix + ".weight", (long)out * in);
     l.b = P(E, prefix + ".bias", out);
     l.out = out; l.in = in;
+    if (E.cfg.operand_dtype == 1 && l.w) {   // bf16 operand storage: converted once, here
+        unsigned short* wb = E.warena.get<unsigned short>((size_t)out * in);
+        if (!E.warena.fail && roitr_f32_to_bf16((long)out * in, l.w, wb, E.fin_stream) == 0) l.wb = wb;
+    }
     return l;
 }
 
+// bf16 operand mode: `Wb` = the same weight stored bf16 (nullptr: fp32 layer).  The bf16 kernel is used whenever it takes the
+// shape (K % 64 == 0, 16-byte rows); `bf` = ROITR_BF16_A / ROITR_BF16_C says A is / C shall be STORED in bf16 -- only legal
+// when the bf16 kernel runs (callers check bf16_layer()), an fp32 fallback with such a request is an error.
+bool bf16_layer(const unsigned short* Wb, int K) { return Wb != nullptr && K % 64 == 0; }
+int use_bf16(RoitrGemm& g, const float* W, const unsigned short* Wb, int bf)
+{
+    if (Wb) {
+        g.W = reinterpret_cast<const float*>(Wb);
+        g.bf16 = ROITR_BF16_W | bf;
+        if (roitr_gemm_bf16_supported(&g)) return 0;
+        g.W = W; g.bf16 = 0;
+    }
+    if (bf) { roitr_set_error("engine: bf16-stored activation routed to an fp32 layer", __FILE__, __LINE__); return ROITR_ERR_ARG; }
+    return 0;
+}
 int gemm(hipStream_t st, int M, int N, int K, const float* A, int lda, const float* W, int ldw, const float* bias, float* C, int ldc,
-         bool relu = false, const int* a_idx = nullptr, const float* A2 = nullptr, float alpha = 1.0f)
+         bool relu = false, const int* a_idx = nullptr, const float* A2 = nullptr, float alpha = 1.0f, const unsigned short* Wb = nullptr,
+         int bf = 0)
 {
     RoitrGemm g;
     memset(&g, 0, sizeof(g));
     g.M = M; g.N = N; g.K = K; g.A = A; g.A2 = A2; g.lda = lda; g.a_idx = a_idx; g.W = W; g.ldw = ldw; g.bias = bias;
     g.alpha = alpha; g.relu = relu ? 1 : 0; g.C = C; g.ldc = ldc; g.batch = 1;
+    CHK(use_bf16(g, W, Wb, bf));
     return roitr_gemm(&g, st);
 }
-int gemm(hipStream_t st, int M, const float* A, const Lin& l, float* C, bool relu = false, const int* a_idx = nullptr, const float* A2 = nullptr)
+int gemm(hipStream_t st, int M, const float* A, const Lin& l, float* C, bool relu = false, const int* a_idx = nullptr, const float* A2 = nullptr,
+         int bf = 0)
 {
-    return gemm(st, M, l.out, l.in, A, l.in, l.w, l.in, l.b, C, l.out, relu, a_idx, A2);
+    return gemm(st, M, l.out, l.in, A, l.in, l.w, l.in, l.b, C, l.out, relu, a_idx, A2, 1.0f, l.wb, bf);
 }
 
 // nn.Linear followed by (+ residual) LayerNorm (+ post-add) (ReLU): one launch when the layer is 64 wide (the LayerNorm
 // runs in the GEMM epilogue, the (M, 64) intermediate never reaches HBM), the two-launch sequence otherwise.
 // `tmp` (M x l.out) is only touched by the two-launch form.
-int gemm_ln(hipStream_t st, int M, const float* A, const Lin& l, const float* res, const int* res_idx, const float* gamma,
-            const float* beta, const float* post, bool relu, float* tmp, float* out, int lda = 0, const float* W = nullptr, int ldw = 0,
-            const float* bias = nullptr, bool has_bias = true)
+bool ln_fuses(int N, int K, int lda, int ldw)
 {
     static const bool fuse = getenv("ROITR_NO_LN_FUSE") == nullptr;
-    const float* w = W ? W : l.w;
-    const float* b = W ? (has_bias ? bias : nullptr) : l.b;
-    const int K = l.in, N = l.out;
-    if (lda == 0) lda = K;
-    if (ldw == 0) ldw = K;
     static const int fuse_max = [] { const char* e = getenv("ROITR_LN_FUSE_MAX"); return e ? atoi(e) : 128; }();
+    return fuse && (N == 64 || N == 128 || N == 256) && N <= fuse_max && K % 32 == 0 && lda % 4 == 0 && ldw % 4 == 0;
+}
+// bf: ROITR_BF16_A (A stored bf16; lda in elements) and / or ROITR_BF16_C (out stored bf16: fused form only)
+int gemm_ln(hipStream_t st, int M, const float* A, const Lin& l, const float* res, const int* res_idx, const float* gamma,
+            const float* beta, const float* post, bool relu, float* tmp, float* out, int bf = 0)
+{
+    const float* w = l.w;
+    const float* b = l.b;
+    const int K = l.in, N = l.out;
+    const int lda = K, ldw = K;
     // measured per 128-pair forward: fusing the 64-wide layers -1.55 ms, + the 128-wide ones -0.4 ms, + the 256-wide ones
     // +1.0 ms (64 x 256 tiles leave the coarse levels with too few, too fat blocks) -> default limit 128
-    if (fuse && (N == 64 || N == 128 || N == 256) && N <= fuse_max && K % 32 == 0 && lda % 4 == 0 && ldw % 4 == 0) {
+    if (ln_fuses(N, K, lda, ldw)) {
         RoitrGemm g;
         memset(&g, 0, sizeof(g));
         g.M = M; g.N = N; g.K = K; g.A = A; g.lda = lda; g.W = w; g.ldw = ldw; g.bias = b; g.alpha = 1.0f; g.C = out; g.ldc = N; g.batch = 1;
         g.ln_gamma = gamma; g.ln_beta = beta; g.ln_res = res; g.ln_res_idx = res_idx; g.ln_post = post; g.ln_relu = relu ? 1 : 0; g.ln_eps = 1e-5f;
+        CHK(use_bf16(g, w, l.wb, bf));
         return roitr_gemm(&g, st);
     }
-    CHK(gemm(st, M, N, K, A, lda, w, ldw, b, tmp, N));
+    if (bf & ROITR_BF16_C) { roitr_set_error("engine: bf16 LayerNorm output needs the fused epilogue", __FILE__, __LINE__); return ROITR_ERR_ARG; }
+    CHK(gemm(st, M, N, K, A, lda, w, ldw, b, tmp, N, false, nullptr, nullptr, 1.0f, l.wb, bf));
     return roitr_add_layernorm(M, N, tmp, res, res_idx, gamma, beta, post, relu ? 1 : 0, 1e-5f, out, st);
 }
 
@@ -254,6 +285,11 @@ int fold_local(Engine& E, LocalT& L, hipStream_t st)
     CHK(gemm(st, 1, NQ, H, L.q.b, H, pfold, H, nullptr, L.bqkv + H, NQ));
     CHK(d2d(st, L.bqkv + H + NQ, L.k.b, sizeof(float) * H));
     CHK(d2d(st, L.bqkv + 2 * H + NQ, L.v.b, sizeof(float) * H));
+    if (E.cfg.operand_dtype == 1) {   // folded in fp32, stored once in bf16
+        L.wqkv_b = A.get<unsigned short>((size_t)R * H);
+        if (A.fail) return ROITR_ERR_ARG;
+        CHK(roitr_f32_to_bf16((long)R * H, L.wqkv, L.wqkv_b, st));
+    }
     return 0;
 }
 
@@ -294,14 +330,15 @@ int local_transformer(Engine& E, hipStream_t st, const LocalT& L, int N_in, cons
         const int R = 3 * H + NQ;
         float* qkv = A.get<float>((size_t)N_in * R);
         if (A.fail) return ROITR_ERR_ARG;
-        CHK(gemm(st, N_in, R, H, f, H, L.wqkv, H, L.bqkv, qkv, R));
+        CHK(gemm(st, N_in, R, H, f, H, L.wqkv, H, L.bqkv, qkv, R, false, nullptr, nullptr, 1.0f, L.wqkv_b));
         q = qkv; k = qkv + H + NQ; v = qkv + 2 * H + NQ; ldq = R; ldkv = R;
     } else {
         float* qe = A.get<float>((size_t)M * (H + NQ));
         float* kv = A.get<float>((size_t)N_in * 2 * H);
         if (A.fail) return ROITR_ERR_ARG;
-        CHK(gemm(st, M, H + NQ, H, f, H, L.wqkv, H, L.bqkv, qe, H + NQ, false, node_idx));
-        CHK(gemm(st, N_in, 2 * H, H, f, H, L.wqkv + (size_t)(H + NQ) * H, H, L.bqkv + H + NQ, kv, 2 * H));
+        CHK(gemm(st, M, H + NQ, H, f, H, L.wqkv, H, L.bqkv, qe, H + NQ, false, node_idx, nullptr, 1.0f, L.wqkv_b));
+        CHK(gemm(st, N_in, 2 * H, H, f, H, L.wqkv + (size_t)(H + NQ) * H, H, L.bqkv + H + NQ, kv, 2 * H, false, nullptr, nullptr, 1.0f,
+                 L.wqkv_b ? L.wqkv_b + (size_t)(H + NQ) * H : nullptr));
         q = qe; k = kv; v = kv + H; ldq = H + NQ; ldkv = 2 * H;
     }
     float* att = A.get<float>((size_t)M * H);
@@ -314,13 +351,15 @@ int local_transformer(Engine& E, hipStream_t st, const LocalT& L, int N_in, cons
     a.group_idx = group; a.ppf = ppf; a.wvpe = L.wvpe; a.bvpe = L.bvpe; a.scale = 1.0f / sqrtf((float)(H / HEADS));
     a.out = att; a.ldo = H; a.node_order = order;
     CHK(roitr_local_attention(&a, st));
-    CHK(gemm_ln(st, M, att, L.lin, f, node_idx, L.norm_w, L.norm_b, nullptr, false, hid, y));
+    // bf16 operand mode: `y` only feeds out_proj -> the LayerNorm epilogue stores it in bf16 (half the round trip)
+    const bool y_h = ln_fuses(H, H, H, H) && bf16_layer(L.lin.wb, H) && bf16_layer(L.out_proj.wb, H);
+    CHK(gemm_ln(st, M, att, L.lin, f, node_idx, L.norm_w, L.norm_b, nullptr, false, hid, y, y_h ? ROITR_BF16_C : 0));
     if (bn2_res) {
         float* t = A.get<float>((size_t)M * L.out_dim);
         if (A.fail) return ROITR_ERR_ARG;
-        CHK(gemm_ln(st, M, y, L.out_proj, nullptr, nullptr, L.bn2_w, L.bn2_b, bn2_res, true, t, out));
+        CHK(gemm_ln(st, M, y, L.out_proj, nullptr, nullptr, L.bn2_w, L.bn2_b, bn2_res, true, t, out, y_h ? ROITR_BF16_A : 0));
     } else {
-        CHK(gemm(st, M, y, L.out_proj, out));
+        CHK(gemm(st, M, y, L.out_proj, out, false, nullptr, nullptr, y_h ? ROITR_BF16_A : 0));
     }
     A.off = mark;
     return 0;
@@ -344,8 +383,10 @@ int ffn_apply(Engine& E, hipStream_t st, const Ffn& F, int M, int C, const float
     float* e = A.get<float>((size_t)M * 2 * C);
     float* s = A.get<float>((size_t)M * C);
     if (A.fail) return ROITR_ERR_ARG;
-    CHK(gemm(st, M, x, F.expand, e, true));
-    CHK(gemm_ln(st, M, e, F.squeeze, x, nullptr, F.n_w, F.n_b, nullptr, false, s, out));
+    // bf16 operand mode: the (M, 2C) hidden activation lives in bf16 between the two GEMMs
+    const bool e_h = bf16_layer(F.expand.wb, C) && bf16_layer(F.squeeze.wb, 2 * C);
+    CHK(gemm(st, M, x, F.expand, e, true, nullptr, nullptr, e_h ? ROITR_BF16_C : 0));
+    CHK(gemm_ln(st, M, e, F.squeeze, x, nullptr, F.n_w, F.n_b, nullptr, false, s, out, e_h ? ROITR_BF16_A : 0));
     A.off = mark;
     return 0;
 }
@@ -419,6 +460,18 @@ extern "C" int roitr_engine_finalize(void* h, hipStream_t st)
     E.graphs.clear();
     const int f = E.cfg.factor;
     const int C4 = 256 * f;
+    if (E.cfg.operand_dtype != 0 && E.cfg.operand_dtype != 1) { roitr_set_error("operand_dtype must be 0 (fp32) or 1 (bf16)", __FILE__, __LINE__); return ROITR_ERR_ARG; }
+    // ---- derived-weight arena (folded / concatenated weights, bf16 copies); the bf16 copies are made while the names resolve
+    {
+        const size_t want = ((size_t)96 << 20) * (f > 1 ? 2 : 1) + (E.cfg.operand_dtype == 1 ? ((size_t)48 << 20) * f * f : 0);
+        if (E.warena.cap < want) {
+            if (E.warena.base) { ROITR_HIP(hipStreamSynchronize(st)); ROITR_HIP(hipFree(E.warena.base)); E.warena.base = nullptr; }
+            E.warena.cap = want;
+            ROITR_HIP(hipMalloc((void**)&E.warena.base, E.warena.cap));
+        }
+        E.warena.off = 0; E.warena.fail = false;
+        E.fin_stream = st;
+    }
     // ---- resolve names (model/model.py:146-184 module tree)
     int in_planes = 1;
     for (int l = 0; l < 4; ++l) {
@@ -480,11 +533,6 @@ extern "C" int roitr_engine_finalize(void* h, hipStream_t st)
     if (!E.err.empty()) { roitr_set_error(E.err.c_str(), __FILE__, __LINE__); return ROITR_ERR_ARG; }
 
     // ---- derived weights
-    if (!E.warena.base) {
-        E.warena.cap = (size_t)96 << 20;
-        ROITR_HIP(hipMalloc((void**)&E.warena.base, E.warena.cap));
-    }
-    E.warena.off = 0; E.warena.fail = false;
     for (int l = 0; l < 4; ++l) {
         for (int b = 0; b < E.nblocks[l]; ++b) CHK(fold_local(E, E.enc[l][b], st));
         CHK(fold_local(E, E.dec[l], st));
@@ -501,6 +549,13 @@ extern "C" int roitr_engine_finalize(void* h, hipStream_t st)
             CHK(d2d(st, L.bqkv + (size_t)j * C4, qs[j]->b, sizeof(float) * C4));
         }
         CHK(roitr_transpose(C4, C4, L.p.w, C4, L.wpT, C4, st));
+        if (E.cfg.operand_dtype == 1) {
+            L.wqkv_b = E.warena.get<unsigned short>((size_t)3 * C4 * C4);
+            L.wpT_b = E.warena.get<unsigned short>((size_t)C4 * C4);
+            if (E.warena.fail) break;
+            CHK(roitr_f32_to_bf16((long)3 * C4 * C4, L.wqkv, L.wqkv_b, st));
+            CHK(roitr_f32_to_bf16((long)C4 * C4, L.wpT, L.wpT_b, st));
+        }
     }
     // SinusoidalPositionalEmbedding.div_term (positional_encoding.py:43-45): a buffer in the state_dict;
     // regenerate it in fp32 when the caller did not register it
@@ -718,7 +773,9 @@ extern "C" int roitr_engine_forward(void* h, const RoitrForwardIO* io, hipStream
         CHK(roitr_geo_indices(T4, p[3], D.off[3], D.cloud_of_node, D.eoff, 0.2f, 15.0f, 3, V.nmax[3], d_idx, a_idx, st));
         CHK(tap(E, st, "geo.d_idx", d_idx, sizeof(float) * etot));
         CHK(tap(E, st, "geo.a_idx", a_idx, sizeof(float) * etot * 3));
-        if (E.proj_d3)
+        if (E.cfg.operand_dtype == 1 && E.proj_d.wb && E.proj_a.wb)
+            CHK(roitr_geo_embed_bf16(etot, C4, 3, d_idx, a_idx, E.geo_div, E.proj_d.wb, E.proj_d.b, E.proj_a.wb, E.proj_a.b, Emb, st));
+        else if (E.proj_d3)
             CHK(roitr_geo_embed_split(etot, C4, 3, d_idx, a_idx, E.geo_div, E.proj_d3, E.proj_d.b, E.proj_a3, E.proj_a.b, Emb, st));
         else
             CHK(roitr_geo_embed(etot, C4, 3, d_idx, a_idx, E.geo_div, E.proj_d.w, E.proj_d.b, E.proj_a.w, E.proj_a.b, Emb, st));
@@ -741,11 +798,12 @@ extern "C" int roitr_engine_forward(void* h, const RoitrForwardIO* io, hipStream
         for (size_t li = 0; li < E.geo.size(); ++li) {
             const GeoLayer& L = E.geo[li];
             if (!L.cross) {
-                CHK(gemm(st, T4, 3 * C4, C4, fcur, C4, L.wqkv, C4, L.bqkv, qkv, 3 * C4));
+                CHK(gemm(st, T4, 3 * C4, C4, fcur, C4, L.wqkv, C4, L.bqkv, qkv, 3 * C4, false, nullptr, nullptr, 1.0f, L.wqkv_b));
                 {   // qt[(row,h), :] = Wp_h^T q_h   (batched over heads)
                     RoitrGemm gq; memset(&gq, 0, sizeof(gq));
                     gq.M = T4; gq.N = C4; gq.K = cpe; gq.A = qkv; gq.lda = 3 * C4; gq.W = L.wpT; gq.ldw = C4; gq.alpha = 1.f;
                     gq.C = qt; gq.ldc = HEADS * C4; gq.batch = HEADS; gq.sA = cpe; gq.sW = cpe; gq.sC = C4;
+                    CHK(use_bf16(gq, L.wpT, L.wpT_b, 0));
                     CHK(roitr_gemm(&gq, st));
                 }
                 RoitrMha m; memset(&m, 0, sizeof(m));
@@ -757,6 +815,7 @@ extern "C" int roitr_engine_forward(void* h, const RoitrForwardIO* io, hipStream
                     RoitrGemm gp; memset(&gp, 0, sizeof(gp));
                     gp.M = T4; gp.N = cpe; gp.K = C4; gp.A = ebar; gp.lda = HEADS * C4; gp.W = L.vp.w; gp.ldw = C4; gp.bias = L.vp.b; gp.alpha = 1.f;
                     gp.C = t2; gp.ldc = C4; gp.batch = HEADS; gp.sA = C4; gp.sW = (long)cpe * C4; gp.sC = cpe; gp.sBias = cpe;
+                    CHK(use_bf16(gp, L.vp.w, L.vp.wb, 0));
                     CHK(roitr_gemm(&gp, st));
                 }
                 // RPEAttentionLayer tail (geoattention.py:236-244) + AttentionOutput x2 (l.278-280)
@@ -774,9 +833,11 @@ extern "C" int roitr_engine_forward(void* h, const RoitrForwardIO* io, hipStream
                     float* qb_ = qkv;                          // (T4, C4) region reused: q rows at their own row index
                     float* kb_ = qkv + (size_t)T4 * C4;
                     float* vb_ = qkv + (size_t)2 * T4 * C4;
-                    CHK(gemm(st, qn, C4, C4, fcur + (size_t)q0 * C4, C4, L.q.w, C4, L.q.b, qb_ + (size_t)q0 * C4, C4, false, nullptr, pos + (size_t)q0 * C4));
-                    CHK(gemm(st, kn, C4, C4, fcur + (size_t)k0 * C4, C4, L.k.w, C4, L.k.b, kb_ + (size_t)k0 * C4, C4, false, nullptr, pos + (size_t)k0 * C4));
-                    CHK(gemm(st, kn, C4, C4, fcur + (size_t)k0 * C4, C4, L.v.w, C4, L.v.b, vb_ + (size_t)k0 * C4, C4));
+                    CHK(gemm(st, qn, C4, C4, fcur + (size_t)q0 * C4, C4, L.q.w, C4, L.q.b, qb_ + (size_t)q0 * C4, C4, false, nullptr, pos + (size_t)q0 * C4,
+                             1.0f, L.q.wb));
+                    CHK(gemm(st, kn, C4, C4, fcur + (size_t)k0 * C4, C4, L.k.w, C4, L.k.b, kb_ + (size_t)k0 * C4, C4, false, nullptr, pos + (size_t)k0 * C4,
+                             1.0f, L.k.wb));
+                    CHK(gemm(st, kn, C4, C4, fcur + (size_t)k0 * C4, C4, L.v.w, C4, L.v.b, vb_ + (size_t)k0 * C4, C4, false, nullptr, nullptr, 1.0f, L.v.wb));
                     RoitrMha m; memset(&m, 0, sizeof(m));
                     m.q_row0 = q0; m.q_rows = qn; m.C = C4; m.heads = HEADS; m.q = qb_; m.ldq = C4; m.k = kb_; m.ldk = C4; m.v = vb_; m.ldv = C4;
                     m.offset = D.off[3]; m.cloud_of_row = D.cloud_of_node; m.partner = D.partner; m.scale = scale; m.nk_max = V.nmax[3];
@@ -811,8 +872,8 @@ extern "C" int roitr_engine_forward(void* h, const RoitrForwardIO* io, hipStream
         if (A.fail) { roitr_set_error("arena exhausted (decoder)", __FILE__, __LINE__); return ROITR_ERR_ARG; }
         CHK(roitr_segment_mean(NC, pl, xe[3], D.off[3], mean, st));
         CHK(gemm(st, NC, mean, U.l2, tm, true));
-        CHK(gemm(st, NC, pl, pl, tm, pl, U.l1.w + pl, 2 * pl, U.l1.b, um, pl));
-        CHK(gemm(st, T4, pl, pl, xe[3], pl, U.l1.w, 2 * pl, nullptr, y, pl));
+        CHK(gemm(st, NC, pl, pl, tm, pl, U.l1.w + pl, 2 * pl, U.l1.b, um, pl, false, nullptr, nullptr, 1.0f, U.l1.wb ? U.l1.wb + pl : nullptr));
+        CHK(gemm(st, T4, pl, pl, xe[3], pl, U.l1.w, 2 * pl, nullptr, y, pl, false, nullptr, nullptr, 1.0f, U.l1.wb));
         CHK(roitr_add_layernorm(T4, pl, y, um, D.cloud_of_node, U.l1n_w, U.l1n_b, nullptr, 1, 1e-5f, x0, st));
         CHK(tap(E, st, "dec4.0", x0, sizeof(float) * (size_t)T4 * pl));
         CHK(block(E, st, E.dec[3], T4, x0, g_self[3], ppf_self[3], E.nsample[3], xd[3], order[3]));

@@ -214,6 +214,9 @@ __device__ __forceinline__ lds_ptr_t to_lds(const void* p) { return (lds_ptr_t)(
 // by DMA (global_load_lds_dwordx4: with the matrix time cut 2.7x the ds_write path of the fp32 kernel would be the
 // bottleneck), the generated A planes by ds_write_b128.  LDS rows are 4 chunks of 8 bf16, unpadded (the DMA writes
 // linearly); chunk c of row r lives at physical chunk c ^ ((r >> 2) & 3): conflict-free b128 fragment reads.
+// NP = 3: the split form above.  NP = 1: plain bf16 operands (one plane: the embedding and the weights rounded to bf16 once,
+// fp32 accumulate) -- the bf16 operand mode of the engine (BASELINE config 4), W3 then is the (C, C) bf16 weight.
+template <int NP>
 __global__ __launch_bounds__(256) void geo_embed_split_kernel(long rows, int C, int angle_k, const float* __restrict__ d_idx,
                                                               const float* __restrict__ a_idx, const float* __restrict__ div_term,
                                                               const unsigned short* __restrict__ Wd3, const float* __restrict__ bd,
@@ -221,8 +224,8 @@ __global__ __launch_bounds__(256) void geo_embed_split_kernel(long rows, int C, 
                                                               float* __restrict__ out)
 {
     constexpr int BNW = 128;
-    __shared__ __attribute__((aligned(1024))) uint4 Bs[2][3][BNW * 4];   // [stage][plane][row][chunk]
-    __shared__ __attribute__((aligned(16))) uint4 As[2][3][BM * 4];
+    __shared__ __attribute__((aligned(1024))) uint4 Bs[2][NP][BNW * 4];   // [stage][plane][row][chunk]
+    __shared__ __attribute__((aligned(16))) uint4 As[2][NP][BM * 4];
     __shared__ float divs[512];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const long m0 = (long)blockIdx.y * BM;
@@ -234,12 +237,13 @@ __global__ __launch_bounds__(256) void geo_embed_split_kernel(long rows, int C, 
     const int kg = lane >> 5, ml = lane & 31;
     const size_t plane = (size_t)C * C;
     const int a_wr = r * 4 + (ck ^ ((r >> 2) & 3));
-    // DMA assignment: 24 one-KB pieces per slab (3 planes x 8 groups of 16 rows), 6 per wave; lane -> row 16 u + lane / 4,
+    // DMA assignment: 8 NP one-KB pieces per slab (NP planes x 8 groups of 16 rows), 2 NP per wave; lane -> row 16 u + lane / 4,
     // physical chunk lane % 4
-    int dma_p[6], dma_lds[6]; size_t dma_src[6];
+    constexpr int PPW = 2 * NP;
+    int dma_p[PPW], dma_lds[PPW]; size_t dma_src[PPW];
 #pragma unroll
-    for (int t = 0; t < 6; ++t) {
-        const int idx = wave * 6 + t, p = idx >> 3, u = idx & 7;
+    for (int t = 0; t < PPW; ++t) {
+        const int idx = wave * PPW + t, p = idx >> 3, u = idx & 7;
         const int row = 16 * u + (lane >> 2);
         const int lc = (lane & 3) ^ ((row >> 2) & 3);
         dma_p[t] = p; dma_lds[t] = p * (BNW * 4) + u * 64;
@@ -258,7 +262,7 @@ __global__ __launch_bounds__(256) void geo_embed_split_kernel(long rows, int C, 
             for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
         auto dma = [&](int stage, int k0) {
 #pragma unroll
-            for (int t = 0; t < 6; ++t)
+            for (int t = 0; t < PPW; ++t)
                 __builtin_amdgcn_global_load_lds(W3 + dma_src[t] + k0, to_lds(&Bs[stage][0][0] + dma_lds[t]), 16, 0, 0);
         };
         auto gen = [&](int stage, int k0) {   // this thread's 8 consecutive k of the embedding row -> three bf16 planes
@@ -268,11 +272,14 @@ __global__ __launch_bounds__(256) void geo_embed_split_kernel(long rows, int C, 
             for (int i = 0; i < 4; ++i) {
                 float sn, cs;
                 sincos_cw(val * divs[f0 + i], sn, cs);
-                split3_pair(sn, cs, hh[i], mm[i], ll[i]);
+                if (NP == 3) split3_pair(sn, cs, hh[i], mm[i], ll[i]);
+                else { f32x2 v = {sn, cs}; hh[i] = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2)); }
             }
             As[stage][0][a_wr] = make_uint4(hh[0], hh[1], hh[2], hh[3]);
-            As[stage][1][a_wr] = make_uint4(mm[0], mm[1], mm[2], mm[3]);
-            As[stage][2][a_wr] = make_uint4(ll[0], ll[1], ll[2], ll[3]);
+            if (NP == 3) {
+                As[stage][NP - 2][a_wr] = make_uint4(mm[0], mm[1], mm[2], mm[3]);
+                As[stage][NP - 1][a_wr] = make_uint4(ll[0], ll[1], ll[2], ll[3]);
+            }
         };
         __syncthreads();   // the previous pass is done with both stages
         dma(0, 0);
@@ -286,9 +293,9 @@ __global__ __launch_bounds__(256) void geo_embed_split_kernel(long rows, int C, 
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {   // two k-steps of 16 per slab
                 const int ch = 2 * s2 + kg;
-                bf16x8 a[3][2], b[3];
+                bf16x8 a[NP][2], b[NP];
 #pragma unroll
-                for (int p = 0; p < 3; ++p) {
+                for (int p = 0; p < NP; ++p) {
                     a[p][0] = __builtin_bit_cast(bf16x8, As[stage][p][ml * 4 + (ch ^ ((ml >> 2) & 3))]);
                     a[p][1] = __builtin_bit_cast(bf16x8, As[stage][p][(32 + ml) * 4 + (ch ^ ((ml >> 2) & 3))]);
                     const int br = wave * 32 + ml;
@@ -296,11 +303,13 @@ __global__ __launch_bounds__(256) void geo_embed_split_kernel(long rows, int C, 
                 }
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {   // smallest terms first
-                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2][i], b[0], acc[i], 0, 0, 0);   // l h
-                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[2], acc[i], 0, 0, 0);   // h l
-                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][i], b[1], acc[i], 0, 0, 0);   // m m
-                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][i], b[0], acc[i], 0, 0, 0);   // m h
-                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[1], acc[i], 0, 0, 0);   // h m
+                    if (NP == 3) {
+                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[NP - 1][i], b[0], acc[i], 0, 0, 0);        // l h
+                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[NP - 1], acc[i], 0, 0, 0);        // h l
+                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[NP - 2][i], b[NP - 2], acc[i], 0, 0, 0);   // m m
+                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[NP - 2][i], b[0], acc[i], 0, 0, 0);        // m h
+                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[NP - 2], acc[i], 0, 0, 0);        // h m
+                    }
                     acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[0], acc[i], 0, 0, 0);   // h h
                 }
             }
@@ -373,7 +382,25 @@ extern "C" int roitr_geo_embed_split(long rows, int C, int angle_k, const float*
     const long mt = (rows + BM - 1) / BM;
     if (mt > 0x7fffffffL) return ROITR_ERR_UNSUPPORTED;
     roitr_prof_begin(ROITR_PROF_GEO_EMBED, 2.0 * rows * (1.0 + angle_k) * (double)C * C, stream);
-    geo_embed_split_kernel<<<dim3(C / 128, (unsigned)mt), 256, 0, stream>>>(rows, C, angle_k, d_idx, a_idx, div_term, Wd3, bd, Wa3, ba, out);
+    geo_embed_split_kernel<3><<<dim3(C / 128, (unsigned)mt), 256, 0, stream>>>(rows, C, angle_k, d_idx, a_idx, div_term, Wd3, bd, Wa3, ba, out);
+    roitr_prof_end(ROITR_PROF_GEO_EMBED, stream);
+    ROITR_LAUNCH_CHECK();
+    return ROITR_OK;
+}
+
+/* bf16 operand form of roitr_geo_embed (engine operand_dtype = bf16): Wd / Wa are the (C, C) weights stored in bf16
+ * (roitr_f32_to_bf16), the generated sinusoid is rounded to bf16 as it is written into the MFMA image, fp32 accumulate,
+ * fp32 max / add epilogue. */
+extern "C" int roitr_geo_embed_bf16(long rows, int C, int angle_k, const float* d_idx, const float* a_idx, const float* div_term,
+                                    const unsigned short* Wd, const float* bd, const unsigned short* Wa, const float* ba, float* out,
+                                    hipStream_t stream)
+{
+    if (rows <= 0) return ROITR_OK;
+    if (C % 128 || C > 1024 || angle_k < 1) return ROITR_ERR_UNSUPPORTED;
+    const long mt = (rows + BM - 1) / BM;
+    if (mt > 0x7fffffffL) return ROITR_ERR_UNSUPPORTED;
+    roitr_prof_begin(ROITR_PROF_GEO_EMBED, 2.0 * rows * (1.0 + angle_k) * (double)C * C, stream);
+    geo_embed_split_kernel<1><<<dim3(C / 128, (unsigned)mt), 256, 0, stream>>>(rows, C, angle_k, d_idx, a_idx, div_term, Wd, bd, Wa, ba, out);
     roitr_prof_end(ROITR_PROF_GEO_EMBED, stream);
     ROITR_LAUNCH_CHECK();
     return ROITR_OK;

@@ -152,33 +152,53 @@ class _Gemm(ctypes.Structure):
                 ("sBias", ctypes.c_long), ("sAidx", ctypes.c_long), ("sWidx", ctypes.c_long), ("seg_off", _P),
                 ("seg_a0", ctypes.c_int), ("seg_w0", ctypes.c_int),
                 ("ln_gamma", _P), ("ln_beta", _P), ("ln_res", _P), ("ln_res_idx", _P), ("ln_post", _P),
-                ("ln_relu", ctypes.c_int), ("ln_eps", ctypes.c_float)]
+                ("ln_relu", ctypes.c_int), ("ln_eps", ctypes.c_float), ("bf16", ctypes.c_int)]
 
 
-def linear(x, weight, bias=None, relu=False, alpha=1.0):
-    """act(alpha * x @ weight.T + bias) on the fp32 MFMA GEMM (the kernel behind every nn.Linear of the path)."""
-    x, weight = x.contiguous().float(), weight.contiguous().float()
+BF16_W, BF16_A, BF16_C = 1, 2, 4   # RoitrGemm::bf16 flags (include/roitr_engine.h)
+
+
+def _bf16_flags(bf16, x, weight, out_bf16):
+    """bf16 operand mode of the GEMM: the weight is stored bf16, x is rounded while staged unless it already is a bfloat16
+    tensor, the output is stored bf16 on request.  Returns (x, weight, flags)."""
+    if not bf16:
+        return x.contiguous().float(), weight.contiguous().float(), 0
+    flags = BF16_W | (BF16_C if out_bf16 else 0)
+    w = weight.contiguous().to(torch.bfloat16)
+    if x.dtype == torch.bfloat16:
+        return x.contiguous(), w, flags | BF16_A
+    return x.contiguous().float(), w, flags
+
+
+def linear(x, weight, bias=None, relu=False, alpha=1.0, bf16=False, out_bf16=False):
+    """act(alpha * x @ weight.T + bias): the kernel behind every nn.Linear of the path.  Default: the fp32 MFMA GEMM.
+    bf16=True: the bf16-operand kernel (csrc/gemm_bf16.hip; weights stored bf16, fp32 accumulate); x may be a bfloat16
+    tensor (stored-bf16 activation), out_bf16 stores the result in bf16."""
+    x, weight, flags = _bf16_flags(bf16, x, weight, out_bf16)
     M, K = x.shape
     N = weight.shape[0]
-    out = torch.empty((M, N), dtype=torch.float32, device=x.device)
+    out = torch.empty((M, N), dtype=torch.bfloat16 if flags & BF16_C else torch.float32, device=x.device)
     b = bias.contiguous().float() if bias is not None else None
     g = _Gemm(M, N, K, L.ptr(x), L.ptr(None), K, L.ptr(None), 0, L.ptr(weight), K, L.ptr(None), 0, L.ptr(b), float(alpha), int(relu),
               L.ptr(out), N, 1, 0, 0, 0, 0, 0, 0, L.ptr(None), 0, 0)
+    g.bf16 = flags
     L.check(L.lib().roitr_gemm(ctypes.byref(g), L.stream_ptr()), "gemm")
     return out
 
 
-def linear_layernorm(x, weight, bias, gamma, beta, res=None, res_idx=None, post=None, relu=False, eps=1e-5):
-    """[relu](LayerNorm(x @ weight.T + bias + res[res_idx]) * gamma + beta + post) in ONE launch (64 output channels):
-    the nn.Linear -> (+ residual) -> nn.LayerNorm call sites of attention.py:319, model/model.py:89-97,138-140."""
-    x, weight = x.contiguous().float(), weight.contiguous().float()
+def linear_layernorm(x, weight, bias, gamma, beta, res=None, res_idx=None, post=None, relu=False, eps=1e-5, bf16=False, out_bf16=False):
+    """[relu](LayerNorm(x @ weight.T + bias + res[res_idx]) * gamma + beta + post) in ONE launch (64 / 128 / 256 output
+    channels): the nn.Linear -> (+ residual) -> nn.LayerNorm call sites of attention.py:319, model/model.py:89-97,138-140.
+    bf16 / out_bf16 as in linear()."""
+    x, weight, flags = _bf16_flags(bf16, x, weight, out_bf16)
     M, K = x.shape
     N = weight.shape[0]
-    out = torch.empty((M, N), dtype=torch.float32, device=x.device)
+    out = torch.empty((M, N), dtype=torch.bfloat16 if flags & BF16_C else torch.float32, device=x.device)
     c = lambda t, dt=torch.float32: None if t is None else t.contiguous().to(dt)
     b, gm, bt, rs, ri, po = c(bias), c(gamma), c(beta), c(res), c(res_idx, torch.int32), c(post)
     g = _Gemm(M, N, K, L.ptr(x), L.ptr(None), K, L.ptr(None), 0, L.ptr(weight), K, L.ptr(None), 0, L.ptr(b), 1.0, 0,
               L.ptr(out), N, 1, 0, 0, 0, 0, 0, 0, L.ptr(None), 0, 0, L.ptr(gm), L.ptr(bt), L.ptr(rs), L.ptr(ri), L.ptr(po), int(relu), float(eps))
+    g.bf16 = flags
     L.check(L.lib().roitr_gemm(ctypes.byref(g), L.stream_ptr()), "gemm+layernorm")
     return out
 
@@ -209,15 +229,21 @@ def adaptive_superpoint_matching(src_feats, tgt_feats, src_masks, tgt_masks, min
     return ia[:n].long(), ib[:n].long(), sc[:n]
 
 
-def geo_embed(d_idx, a_idx, div_term, w_d, b_d, w_a, b_a, split=False):
+def geo_embed(d_idx, a_idx, div_term, w_d, b_d, w_a, b_a, split=False, bf16=False):
     """positional_encoding.py:139-154 fused: proj_d(sinusoid(d_idx)) + max_k proj_a(sinusoid(a_idx[:, k])) for `rows` index
-    rows.  split=True: the opt-in three-way bf16 split on the bf16 matrix cores (fp32-level accuracy)."""
+    rows.  split=True: the opt-in three-way bf16 split on the bf16 matrix cores (fp32-level accuracy); bf16=True: plain bf16
+    operands (weights stored bf16, the sinusoid rounded to bf16, fp32 accumulate) -- the engine's bf16 operand mode."""
     rows, k = int(a_idx.shape[0]), int(a_idx.shape[1])
     C = int(w_d.shape[0])
     f = lambda t: t.contiguous().float()
     d_idx, a_idx, div_term, w_d, b_d, w_a, b_a = map(f, (d_idx, a_idx, div_term, w_d, b_d, w_a, b_a))
     out = torch.empty((rows, C), dtype=torch.float32, device=d_idx.device)
     lib = L.lib()
+    if bf16:
+        wdh, wah = w_d.to(torch.bfloat16).contiguous(), w_a.to(torch.bfloat16).contiguous()
+        L.check(lib.roitr_geo_embed_bf16(ctypes.c_long(rows), C, k, L.ptr(d_idx), L.ptr(a_idx), L.ptr(div_term), L.ptr(wdh), L.ptr(b_d),
+                                         L.ptr(wah), L.ptr(b_a), L.ptr(out), L.stream_ptr()), "geo_embed_bf16")
+        return out
     if split:
         wd3 = torch.empty((3, C, C), dtype=torch.int16, device=out.device)
         wa3 = torch.empty((3, C, C), dtype=torch.int16, device=out.device)

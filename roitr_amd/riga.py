@@ -127,7 +127,8 @@ class _CConfig(ctypes.Structure):
     _fields_ = [("factor", ctypes.c_int), ("num_corr", ctypes.c_int), ("point_limit", ctypes.c_int),
                 ("fine_topk", ctypes.c_int), ("fine_mutual", ctypes.c_int), ("fine_use_global_score", ctypes.c_int),
                 ("fine_conf", ctypes.c_float), ("n_geo_layers", ctypes.c_int), ("geo_is_cross", ctypes.c_int * 16),
-                ("matching_radius", ctypes.c_float), ("adaptive_coarse", ctypes.c_int), ("occlusion_radius", ctypes.c_float)]
+                ("matching_radius", ctypes.c_float), ("adaptive_coarse", ctypes.c_int), ("occlusion_radius", ctypes.c_float),
+                ("operand_dtype", ctypes.c_int)]
 
 
 _P = ctypes.c_void_p
@@ -190,6 +191,10 @@ class RIGA_v2(nn.Module):
         self.fine_conf = float(_cfg_get(config, "fine_matching_confidence_threshold", 0.05))
         self.fine_use_dustbin = bool(_cfg_get(config, "fine_matching_use_dustbin", False))
         self.fine_use_global_score = bool(_cfg_get(config, "fine_matching_use_global_score", False))
+        # not a reference key: 'f32' (default, the reference's arithmetic) or 'bf16' (bf16 operand storage of the dense layers)
+        self.operand_dtype = str(_cfg_get(config, "operand_dtype", "f32"))
+        if self.operand_dtype not in ("f32", "bf16"):
+            raise ValueError(f"operand_dtype must be 'f32' or 'bf16', got {self.operand_dtype!r}")
         if self.fine_use_dustbin:
             raise NotImplementedError("fine_matching_use_dustbin=True is not on the reference's test configs")
         for key, shape, kind in state_dict_layout(self.factor, self.architecture):
@@ -222,6 +227,7 @@ class RIGA_v2(nn.Module):
         cfg.matching_radius = self.matching_radius
         cfg.adaptive_coarse = 0 if self.factor == 1 else 1
         cfg.occlusion_radius = 0.0375
+        cfg.operand_dtype = 1 if self.operand_dtype == "bf16" else 0
         lib.roitr_engine_create.restype = ctypes.c_void_p
         h = lib.roitr_engine_create(ctypes.byref(cfg))
         if not h:

@@ -1,0 +1,154 @@
+"""GPU: the bf16 operand mode (BASELINE.json configs[3]: 4DMatch, ~8000 pts/cloud, bf16).
+
+Kernel level: csrc/gemm_bf16.hip against a float64 product of the SAME bf16-rounded operands -- with identical inputs the only
+difference is the fp32 accumulation order, so the bound is fp32-rounding tight (2e-5 relative to the row's |a|.|w| mass) and a
+wrong lane / k mapping cannot hide.  Engine level: the 4DMatch forward at N = 8000 in bf16 mode against the fp32 CPU oracle:
+everything that does not pass through a dense layer (FPS nodes, point-to-node partition) is bit-identical, descriptors are
+within the STATED bf16 tolerance, coarse correspondences overlap.
+
+Stated tolerances (bf16 has 8 mantissa bits: 2^-9 = 2e-3 relative rounding per operand; the network is ~40 layers deep with
+LayerNorm re-normalising every block): L2-normalised node descriptors: max abs error 4e-2 and cosine similarity >= 0.995 per
+node; point descriptors (LayerNorm-scale activations, |x| ~ 1): max abs error 1.5e-1, mean abs error 1e-2; coarse matching:
+>= 80 % of the fp32 oracle's node correspondences selected.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from gpu_util import build_model, pair_to_device  # noqa: E402
+
+CORES = len(os.sched_getaffinity(0))
+
+
+def bf16_round(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(torch.bfloat16).to(torch.float64).numpy()
+
+
+def ref_linear(x, w, b=None, relu=False, alpha=1.0, x_is_bf16=False):
+    y = alpha * (bf16_round(x) @ bf16_round(w).T)
+    if b is not None:
+        y = y + b.astype(np.float64)
+    return np.maximum(y, 0) if relu else y
+
+
+def mass(x, w):
+    return np.abs(bf16_round(x)) @ np.abs(bf16_round(w)).T + 1e-6
+
+
+@pytest.mark.parametrize("M,N,K", [(64, 64, 64), (1000, 404, 128), (257, 128, 256), (4096, 512, 512), (130, 1024, 512), (77, 65, 1024), (1, 512, 64)])
+@pytest.mark.parametrize("relu", [False, True])
+def test_gemm_bf16_matches_bf16_rounded_float64(M, N, K, relu):
+    from roitr_amd import ops
+    rng = np.random.default_rng(M * 7 + N * 3 + K)
+    x = rng.standard_normal((M, K)).astype(np.float32)
+    w = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+    b = rng.standard_normal(N).astype(np.float32)
+    xd, wd, bd = (torch.from_numpy(t).cuda() for t in (x, w, b))
+    ref = ref_linear(x, w, b, relu, 0.75)
+    tol = 4e-5 * 0.75 * mass(x, w) + 1e-6
+    got = ops.linear(xd, wd, bd, relu=relu, alpha=0.75, bf16=True).cpu().numpy()
+    assert (np.abs(got - ref) <= tol).all(), float((np.abs(got - ref) / tol).max())
+    # stored-bf16 activation in, stored-bf16 result out (the GEMM -> GEMM intermediates of the engine)
+    got_h = ops.linear(xd.to(torch.bfloat16), wd, bd, relu=relu, alpha=0.75, bf16=True, out_bf16=True)
+    assert got_h.dtype == torch.bfloat16
+    gh = got_h.float().cpu().numpy()
+    assert (np.abs(gh - ref) <= tol + 2.0 ** -8 * np.abs(ref)).all()      # + one bf16 rounding of the result
+
+
+@pytest.mark.parametrize("N", [64, 128, 256])
+def test_gemm_bf16_layernorm_epilogue(N):
+    from roitr_amd import ops
+    rng = np.random.default_rng(N)
+    M, K = 333, 2 * N
+    x = rng.standard_normal((M, K)).astype(np.float32)
+    w = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+    b, gm, bt = (rng.standard_normal(N).astype(np.float32) for _ in range(3))
+    res = rng.standard_normal((500, N)).astype(np.float32)
+    ridx = rng.integers(0, 500, M).astype(np.int32)
+    post = rng.standard_normal((M, N)).astype(np.float32)
+    t = ref_linear(x, w, b) + res[ridx]
+    mu = t.mean(1, keepdims=True)
+    ref = np.maximum((t - mu) / np.sqrt(((t - mu) ** 2).mean(1, keepdims=True) + 1e-5) * gm + bt + post, 0)
+    d = lambda a: torch.from_numpy(a).cuda()
+    got = ops.linear_layernorm(d(x), d(w), d(b), d(gm), d(bt), res=d(res), res_idx=d(ridx), post=d(post), relu=True, bf16=True)
+    np.testing.assert_allclose(got.cpu().numpy(), ref, rtol=0, atol=2e-4)
+    got_h = ops.linear_layernorm(d(x).to(torch.bfloat16), d(w), d(b), d(gm), d(bt), res=d(res), res_idx=d(ridx), post=d(post), relu=True,
+                                 bf16=True, out_bf16=True)
+    np.testing.assert_allclose(got_h.float().cpu().numpy(), ref, rtol=2.0 ** -8, atol=2e-4)
+
+
+def test_gemm_bf16_rejects_unsupported_shapes():
+    from roitr_amd import _lib as L
+    from roitr_amd import ops
+    x = torch.randn(10, 48, device="cuda")
+    w = torch.randn(16, 48, device="cuda")
+    with pytest.raises(L.RoitrError):
+        ops.linear(x, w, bf16=True)          # K % 64 != 0: no silent fp32 fallback behind the operator
+
+
+def test_geo_embed_bf16_against_float64():
+    from roitr_amd import ops
+    rng = np.random.default_rng(9)
+    rows, C, k = 3000, 512, 3
+    d_idx = (rng.random(rows) * 15).astype(np.float32)
+    a_idx = (rng.random((rows, k)) * 12).astype(np.float32)
+    div = np.exp(np.arange(0, C, 2, dtype=np.float32) * np.float32(-np.log(10000.0) / C)).astype(np.float32)
+    wd, wa = ((rng.standard_normal((C, C)) / np.sqrt(C)).astype(np.float32) for _ in range(2))
+    bd, ba = (rng.standard_normal(C).astype(np.float32) for _ in range(2))
+
+    def emb(v):
+        om = v.astype(np.float64)[..., None] * div.astype(np.float64)
+        return np.stack([np.sin(om), np.cos(om)], -1).reshape(*v.shape, C)
+
+    ref = emb(d_idx) @ wd.T.astype(np.float64) + bd + (emb(a_idx) @ wa.T.astype(np.float64) + ba).max(1)
+    d = lambda a: torch.from_numpy(a).cuda()
+    got = ops.geo_embed(d(d_idx), d(a_idx), d(div), d(wd), d(bd), d(wa), d(ba), bf16=True).cpu().numpy()
+    err = np.abs(got - ref)
+    # bf16 operands: 2^-9 relative per factor, ~sqrt(C) accumulation of independent roundings on O(1) outputs
+    assert err.max() < 2e-2 and err.mean() < 3e-3, (err.max(), err.mean())
+
+
+@pytest.fixture(scope="module")
+def fd8000():
+    from oracle import roitr_ref as R  # checker only
+    from roitr_amd.synthetic import make_pair
+    pair = make_pair(8000, config=4, pair_index=2)
+    ref = R.forward(R.closed_form_state(2), pair, cfg=dict(R.FDMATCH_CFG), threads=CORES)
+    model = build_model("4DMatch", operand_dtype="bf16")
+    with torch.no_grad():
+        out = model.forward(**pair_to_device(pair))
+    return out, ref
+
+
+def test_bf16_forward_indices_identical_to_fp32_oracle(fd8000):
+    out, ref = fd8000
+    for k in ("src_nodes", "tgt_nodes"):                     # FPS chain: fp32, untouched by the operand dtype
+        assert np.array_equal(out[k].cpu().numpy(), ref[k]), k
+    for side in ("src", "tgt"):                              # partition: fp32 geometry only
+        assert np.array_equal(out[f"_{side}_node_knn_indices"].cpu().numpy(), ref[f"_{side}_node_knn_indices"])
+        assert np.array_equal(out[f"_{side}_node_masks"].cpu().numpy(), ref[f"_{side}_node_masks"])
+
+
+def test_bf16_forward_descriptors_within_stated_tolerance(fd8000):
+    out, ref = fd8000
+    for k in ("src_node_feats", "tgt_node_feats"):
+        a, b = out[k].cpu().numpy(), ref[k]
+        assert np.abs(a - b).max() < 4e-2, (k, float(np.abs(a - b).max()))
+        cos = (a * b).sum(1) / (np.linalg.norm(a, axis=1) * np.linalg.norm(b, axis=1))
+        assert cos.min() > 0.995, (k, float(cos.min()))
+    for k in ("src_point_feats", "tgt_point_feats"):
+        e = np.abs(out[k].cpu().numpy() - ref[k])
+        assert e.max() < 1.5e-1 and e.mean() < 1e-2, (k, float(e.max()), float(e.mean()))
+
+
+def test_bf16_forward_coarse_overlap(fd8000):
+    out, ref = fd8000
+    got = set(zip(out["tgt_node_corr_indices"].tolist(), out["src_node_corr_indices"].tolist()))
+    want = set(zip(ref["tgt_node_corr_indices"].tolist(), ref["src_node_corr_indices"].tolist()))
+    assert len(got & want) >= 0.8 * len(want), (len(got & want), len(want), len(got))
+    sc = out["corr_scores"].cpu().numpy()
+    assert (sc > 0.05).all()
