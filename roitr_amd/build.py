@@ -54,6 +54,11 @@ def build(force=False, verbose=False):
         if r.returncode != 0:
             sys.stderr.write(r.stdout + r.stderr)
             raise RuntimeError("link failed")
+        # -shared links happily with undefined symbols (a kernel whose host stub was not emitted): load it now, in a child
+        chk = subprocess.run([sys.executable, "-c", f"import ctypes; ctypes.CDLL({LIB!r})"], capture_output=True, text=True)
+        if chk.returncode != 0:
+            os.remove(LIB)
+            raise RuntimeError("libroitr_hip.so does not load: " + chk.stderr.strip().splitlines()[-1])
     return LIB
 
 

@@ -216,12 +216,14 @@ __device__ __forceinline__ lds_ptr_t to_lds(const void* p) { return (lds_ptr_t)(
 // linearly); chunk c of row r lives at physical chunk c ^ ((r >> 2) & 3): conflict-free b128 fragment reads.
 // NP = 3: the split form above.  NP = 1: plain bf16 operands (one plane: the embedding and the weights rounded to bf16 once,
 // fp32 accumulate) -- the bf16 operand mode of the engine (BASELINE config 4), W3 then is the (C, C) bf16 weight.
+// (A device-function template behind two plain kernels: hipcc 7.2 silently emits no host stub for this body as a __global__
+// template.)
 template <int NP>
-__global__ __launch_bounds__(256) void geo_embed_split_kernel(long rows, int C, int angle_k, const float* __restrict__ d_idx,
-                                                              const float* __restrict__ a_idx, const float* __restrict__ div_term,
-                                                              const unsigned short* __restrict__ Wd3, const float* __restrict__ bd,
-                                                              const unsigned short* __restrict__ Wa3, const float* __restrict__ ba,
-                                                              float* __restrict__ out)
+__device__ __forceinline__ void geo_embed_split_body(long rows, int C, int angle_k, const float* __restrict__ d_idx,
+                                                     const float* __restrict__ a_idx, const float* __restrict__ div_term,
+                                                     const unsigned short* __restrict__ Wd3, const float* __restrict__ bd,
+                                                     const unsigned short* __restrict__ Wa3, const float* __restrict__ ba,
+                                                     float* __restrict__ out)
 {
     constexpr int BNW = 128;
     __shared__ __attribute__((aligned(1024))) uint4 Bs[2][NP][BNW * 4];   // [stage][plane][row][chunk]
@@ -272,13 +274,13 @@ __global__ __launch_bounds__(256) void geo_embed_split_kernel(long rows, int C, 
             for (int i = 0; i < 4; ++i) {
                 float sn, cs;
                 sincos_cw(val * divs[f0 + i], sn, cs);
-                if (NP == 3) split3_pair(sn, cs, hh[i], mm[i], ll[i]);
+                if constexpr (NP == 3) split3_pair(sn, cs, hh[i], mm[i], ll[i]);
                 else { f32x2 v = {sn, cs}; hh[i] = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2)); }
             }
             As[stage][0][a_wr] = make_uint4(hh[0], hh[1], hh[2], hh[3]);
-            if (NP == 3) {
-                As[stage][NP - 2][a_wr] = make_uint4(mm[0], mm[1], mm[2], mm[3]);
-                As[stage][NP - 1][a_wr] = make_uint4(ll[0], ll[1], ll[2], ll[3]);
+            if constexpr (NP == 3) {
+                As[stage][1][a_wr] = make_uint4(mm[0], mm[1], mm[2], mm[3]);
+                As[stage][2][a_wr] = make_uint4(ll[0], ll[1], ll[2], ll[3]);
             }
         };
         __syncthreads();   // the previous pass is done with both stages
@@ -303,12 +305,12 @@ __global__ __launch_bounds__(256) void geo_embed_split_kernel(long rows, int C, 
                 }
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {   // smallest terms first
-                    if (NP == 3) {
-                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[NP - 1][i], b[0], acc[i], 0, 0, 0);        // l h
-                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[NP - 1], acc[i], 0, 0, 0);        // h l
-                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[NP - 2][i], b[NP - 2], acc[i], 0, 0, 0);   // m m
-                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[NP - 2][i], b[0], acc[i], 0, 0, 0);        // m h
-                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[NP - 2], acc[i], 0, 0, 0);        // h m
+                    if constexpr (NP == 3) {
+                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2][i], b[0], acc[i], 0, 0, 0);   // l h
+                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[2], acc[i], 0, 0, 0);   // h l
+                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][i], b[1], acc[i], 0, 0, 0);   // m m
+                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][i], b[0], acc[i], 0, 0, 0);   // m h
+                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[1], acc[i], 0, 0, 0);   // h m
                     }
                     acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[0], acc[i], 0, 0, 0);   // h h
                 }
@@ -334,6 +336,23 @@ __global__ __launch_bounds__(256) void geo_embed_split_kernel(long rows, int C, 
             const long row = m0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
             if (row < rows) out[(size_t)row * C + col] = (acc[i][e] + bdv) + (amax[i][e] + bav);
         }
+}
+
+__global__ __launch_bounds__(256) void geo_embed_split_kernel(long rows, int C, int angle_k, const float* __restrict__ d_idx,
+                                                              const float* __restrict__ a_idx, const float* __restrict__ div_term,
+                                                              const unsigned short* __restrict__ Wd3, const float* __restrict__ bd,
+                                                              const unsigned short* __restrict__ Wa3, const float* __restrict__ ba,
+                                                              float* __restrict__ out)
+{
+    geo_embed_split_body<3>(rows, C, angle_k, d_idx, a_idx, div_term, Wd3, bd, Wa3, ba, out);
+}
+__global__ __launch_bounds__(256) void geo_embed_bf16_kernel(long rows, int C, int angle_k, const float* __restrict__ d_idx,
+                                                             const float* __restrict__ a_idx, const float* __restrict__ div_term,
+                                                             const unsigned short* __restrict__ Wd, const float* __restrict__ bd,
+                                                             const unsigned short* __restrict__ Wa, const float* __restrict__ ba,
+                                                             float* __restrict__ out)
+{
+    geo_embed_split_body<1>(rows, C, angle_k, d_idx, a_idx, div_term, Wd, bd, Wa, ba, out);
 }
 
 }  // namespace
@@ -382,7 +401,7 @@ extern "C" int roitr_geo_embed_split(long rows, int C, int angle_k, const float*
     const long mt = (rows + BM - 1) / BM;
     if (mt > 0x7fffffffL) return ROITR_ERR_UNSUPPORTED;
     roitr_prof_begin(ROITR_PROF_GEO_EMBED, 2.0 * rows * (1.0 + angle_k) * (double)C * C, stream);
-    geo_embed_split_kernel<3><<<dim3(C / 128, (unsigned)mt), 256, 0, stream>>>(rows, C, angle_k, d_idx, a_idx, div_term, Wd3, bd, Wa3, ba, out);
+    geo_embed_split_kernel<<<dim3(C / 128, (unsigned)mt), 256, 0, stream>>>(rows, C, angle_k, d_idx, a_idx, div_term, Wd3, bd, Wa3, ba, out);
     roitr_prof_end(ROITR_PROF_GEO_EMBED, stream);
     ROITR_LAUNCH_CHECK();
     return ROITR_OK;
@@ -400,7 +419,7 @@ extern "C" int roitr_geo_embed_bf16(long rows, int C, int angle_k, const float* 
     const long mt = (rows + BM - 1) / BM;
     if (mt > 0x7fffffffL) return ROITR_ERR_UNSUPPORTED;
     roitr_prof_begin(ROITR_PROF_GEO_EMBED, 2.0 * rows * (1.0 + angle_k) * (double)C * C, stream);
-    geo_embed_split_kernel<1><<<dim3(C / 128, (unsigned)mt), 256, 0, stream>>>(rows, C, angle_k, d_idx, a_idx, div_term, Wd, bd, Wa, ba, out);
+    geo_embed_bf16_kernel<<<dim3(C / 128, (unsigned)mt), 256, 0, stream>>>(rows, C, angle_k, d_idx, a_idx, div_term, Wd, bd, Wa, ba, out);
     roitr_prof_end(ROITR_PROF_GEO_EMBED, stream);
     ROITR_LAUNCH_CHECK();
     return ROITR_OK;
