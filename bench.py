@@ -126,10 +126,17 @@ def main():
         n_corr = 0
         handle = model.launch_batch(batch(first), want_gt=True)
         recs = None
+        trace = os.environ.get("ROITR_BENCH_TRACE")
+        t_prev = time.perf_counter()
         for s in range(steps):
             nxt = model.launch_batch(batch(first + s + 1), want_gt=True) if s + 1 < steps else None
+            t_l = time.perf_counter()
             res = model.finish_batch(handle)
             n_corr += sum(int(r["corr_scores"].shape[0]) for r in res)
+            if trace:
+                t_now = time.perf_counter()
+                print(f"[bench trace] step {s}: launch {1e3 * (t_l - t_prev):.1f} ms, finish {1e3 * (t_now - t_l):.1f} ms", file=sys.stderr)
+                t_prev = t_now
             if gather and s + 1 == steps:
                 # unique slot ids for the record block: global pair id of the pool entry, made unique per slot of the step
                 rec_ids = [rank + world * j for j in range(B)]
@@ -235,9 +242,16 @@ def main():
             out["single_pair_mode"] = single
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(N, args.cpu_baseline_seconds, wl["benchmark"], wl["seed_config"])
-        print(json.dumps(out), flush=True)
     if dist.is_available() and dist.is_initialized():
         dist.destroy_process_group()
+    if rank == 0:
+        # the JSON line goes out LAST: librccl prints its version banner through C stdio, which is flushed here first
+        import ctypes
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        print(json.dumps(out), flush=True)
 
 
 def rooflines(prof, steps, dtype):

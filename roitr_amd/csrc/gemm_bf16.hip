@@ -294,7 +294,6 @@ extern "C" int roitr_gemm_bf16_supported(const RoitrGemm* g)
     if (g->K <= 0 || g->K % BK) return 0;
     if (g->lda % a_al || g->ldw % 8 || g->sA % a_al || g->sW % 8) return 0;
     if (((uintptr_t)g->A & 15) || ((uintptr_t)g->W & 15) || (g->A2 && (((uintptr_t)g->A2 & 15) || a_h))) return 0;
-    if ((g->bf16 & ROITR_BF16_C) && ((g->ldc & 1) || (g->sC & 1))) return 0;
     if (g->seg_off && (g->lda % a_al || g->ldw % 8)) return 0;
     if (g->ln_gamma) {
         const int tn = g->N / BN;

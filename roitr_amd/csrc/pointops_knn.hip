@@ -25,6 +25,7 @@
 #include "common.h"
 #include "prof.h"
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 
 #define KNN_FILL 1e10f  // knnquery_cuda_kernel.cu:89
@@ -493,10 +494,12 @@ __device__ __forceinline__ void wave_sort128(WaveList<2>& L, int lane)
     sort128_stage<2>(L, lane); sort128_stage<4>(L, lane); sort128_stage<8>(L, lane); sort128_stage<16>(L, lane);
     sort128_stage<32>(L, lane); sort128_stage<64>(L, lane); sort128_stage<128>(L, lane);
 }
+// qlist != nullptr: the queries are qlist[0 .. *qcount) (the ones knn_cell_kernel handed over), walked with a grid stride.
 __global__ __launch_bounds__(256) void knn_gridsel_kernel(int m, int nsample, const float* __restrict__ xyz,
                                                           const float* __restrict__ new_xyz, const int* __restrict__ offset,
                                                           const int* __restrict__ new_offset, const RoitrGrid* __restrict__ grids,
-                                                          const int* __restrict__ cell_start, const float4* __restrict__ sorted, KnnOut o)
+                                                          const int* __restrict__ cell_start, const float4* __restrict__ sorted, KnnOut o,
+                                                          const int* __restrict__ qlist, const int* __restrict__ qcount)
 {
     __shared__ float bd_[4][SEL_CAP];
     __shared__ int bi_[4][SEL_CAP];
@@ -504,8 +507,9 @@ __global__ __launch_bounds__(256) void knn_gridsel_kernel(int m, int nsample, co
     __shared__ int li_[4][128];
     __shared__ int hist_[4][64];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int q = blockIdx.x * 4 + w;
-    if (q >= m) return;
+    const int n_q = qlist ? *qcount : m;
+    for (int t_ = blockIdx.x * 4 + w; t_ < n_q; t_ += gridDim.x * 4) {
+    const int q = qlist ? qlist[t_] : t_;
     float* bd = bd_[w]; int* bi = bi_[w]; float* ld = ld_[w]; int* li = li_[w]; int* hist = hist_[w];
     int start, end, seg;
     find_segment(q, offset, new_offset, start, end, seg);
@@ -633,9 +637,252 @@ __global__ __launch_bounds__(256) void knn_gridsel_kernel(int m, int nsample, co
     if (!overflow && !sorted_ok) reduce();   // fewer than nsample+1 candidates in the whole cloud, or a trailing append
     if (overflow) {   // rare: hand the query to the exact replay
         if (lane == 0) { const int slot = atomicAdd(o.tie_count, 1); o.tie_list[slot] = q; }
-        return;
+        continue;
     }
     finish_query<2>(L, o, q, nsample, lane, xyz, Q);
+    }
+}
+
+// ---------------------------------------------------------------- cell kernel: large k, self queries (BASELINE config 5)
+// One WORKGROUP PER GRID CELL.  The 3 x 3 x 3 cell neighbourhood of the cell (9 contiguous runs of the counting-sorted
+// array) is staged ONCE into LDS and shared by all queries of the cell; a wave takes one query at a time:
+//   A. distances to every staged candidate (conflict-free ds_read_b128, 64 per step); only candidates inside the
+//      GUARANTEE radius (everything unseen is farther than the distance dm to the faces of the 3 x 3 x 3 box) can belong
+//      to the answer -- those (~20 %) are ballot-compacted into a per-wave LDS list;
+//   B. exact selection of the S = nsample - 1 nearest OTHER points (the query itself is position 0 of its row): a 64-bin
+//      histogram over [0, dm^2) finds the bin that holds rank S, the few elements of that bin are ranked against each
+//      other, which gives the exact threshold tau and tells whether the cut falls between two EQUAL distances;
+//   C. the S elements <= tau are compacted one per lane and ordered by a 64-lane bitonic network (21 steps, DPP inside
+//      the 16-lane rows), neighbour coordinates for the fused PPF come from the staged LDS copy.
+// No per-candidate list insertion anywhere (the old kernels spend ~2.8 k VALU instructions per query on it at k = 64).
+// Exactness: same fp32 distance form (sqdist3); a tie anywhere among the best nsample + 1 (equal neighbours after the
+// sort, a second point at distance 0, a tie at the cut) sends the query to the replay kernel like every other kernel;
+// anything this kernel cannot decide from its staged data (guarantee radius not reached, neighbourhood larger than the
+// LDS budget, cloud smaller than nsample) is handed to knn_gridsel_kernel through a retry list.
+constexpr int CELL_CAP = 1024;    // staged candidates per cell (16 KB)
+constexpr int CELL_NEAR = 256;    // candidates inside the guarantee radius kept per query (4 per lane)
+
+template <int K, int J>
+__device__ __forceinline__ void sort64_step(float& d, int& j, int lane)
+{
+    const float pd = __int_as_float(lane_xor<J>(__float_as_int(d), lane));
+    const int pj = lane_xor<J>(j, lane);
+    const bool up = (lane & K) == 0;       // ascending block (K = 64: the whole wave)
+    const bool lower = (lane & J) == 0;    // this lane holds the lower position of the pair
+    const bool take = (lower == up) ? (d > pd) : (d < pd);   // strict on both sides: equal keys never move (no duplication)
+    d = take ? pd : d;
+    j = take ? pj : j;
+}
+template <int K>
+__device__ __forceinline__ void sort64_stage(float& d, int& j, int lane)
+{
+    if (K >= 64) sort64_step<K, 32>(d, j, lane);
+    if (K >= 32) sort64_step<K, 16>(d, j, lane);
+    if (K >= 16) sort64_step<K, 8>(d, j, lane);
+    if (K >= 8) sort64_step<K, 4>(d, j, lane);
+    if (K >= 4) sort64_step<K, 2>(d, j, lane);
+    sort64_step<K, 1>(d, j, lane);
+}
+__device__ __forceinline__ void wave_sort64(float& d, int& j, int lane)
+{
+    sort64_stage<2>(d, j, lane); sort64_stage<4>(d, j, lane); sort64_stage<8>(d, j, lane);
+    sort64_stage<16>(d, j, lane); sort64_stage<32>(d, j, lane); sort64_stage<64>(d, j, lane);
+}
+__device__ __forceinline__ int wave_incl_scan(int v, int lane)
+{
+#pragma unroll
+    for (int s_ = 1; s_ < 64; s_ <<= 1) { const int t = __shfl_up(v, s_, 64); if (lane >= s_) v += t; }
+    return v;
+}
+
+__global__ __launch_bounds__(256) void knn_cell_kernel(int nsample, const float* __restrict__ xyz, const int* __restrict__ offset,
+                                                       const RoitrGrid* __restrict__ grids, const int* __restrict__ cell_start,
+                                                       const float4* __restrict__ sorted, KnnOut o, int* __restrict__ retry_count,
+                                                       int* __restrict__ retry_list)
+{
+    __shared__ float4 cand[CELL_CAP];
+    __shared__ float nd_[4][CELL_NEAR];
+    __shared__ int nj_[4][CELL_NEAR];
+    __shared__ int hist_[4][64];
+    __shared__ float sd_[4][64];
+    __shared__ int sj_[4][64];
+    __shared__ int run_s[9], run_off[10];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int seg = blockIdx.y;
+    const RoitrGrid g = grids[seg];
+    const int* cs = cell_start + (size_t)seg * (GRID_MAX_CELLS + 1);
+    const int ncell = g.nx * g.ny * g.nz;
+    const int S = nsample - 1;                 // neighbours other than the query itself (<= 64)
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    float* nd = nd_[w]; int* nj = nj_[w]; int* hist = hist_[w]; float* sd = sd_[w]; int* sj = sj_[w];
+    const float margin = 2e-4f * g.h;
+    auto retry = [&](int q) { if (lane == 0) { const int slot = atomicAdd(retry_count, 1); retry_list[slot] = q; } };
+    auto tie = [&](int q) { if (lane == 0) { const int slot = atomicAdd(o.tie_count, 1); o.tie_list[slot] = q; } };
+
+    for (int cell = blockIdx.x; cell < ncell; cell += gridDim.x) {
+        const int qs = cs[cell], qe = cs[cell + 1];
+        if (qe == qs) continue;                 // block-uniform
+        const int cx = cell % g.nx, cy = (cell / g.nx) % g.ny, cz = cell / (g.nx * g.ny);
+        const int x0 = max(cx - 1, 0), x1 = min(cx + 1, g.nx - 1);
+        const int y0 = max(cy - 1, 0), y1 = min(cy + 1, g.ny - 1);
+        const int z0 = max(cz - 1, 0), z1 = min(cz + 1, g.nz - 1);
+        __syncthreads();                        // the previous cell's queries are done with cand / run tables
+        if (tid == 0) {
+            int acc = 0;
+            for (int rz = 0; rz < 3; ++rz)
+                for (int ry = 0; ry < 3; ++ry) {
+                    const int yy = cy - 1 + ry, zz = cz - 1 + rz;
+                    int a = 0, b = 0;
+                    if (yy >= 0 && yy < g.ny && zz >= 0 && zz < g.nz) {
+                        const int rowbase = (zz * g.ny + yy) * g.nx;
+                        a = cs[rowbase + x0]; b = cs[rowbase + x1 + 1];
+                    }
+                    run_s[rz * 3 + ry] = a; run_off[rz * 3 + ry] = acc; acc += b - a;
+                }
+            run_off[9] = acc;
+        }
+        __syncthreads();
+        const int C = run_off[9];
+        if (C > CELL_CAP) {                     // neighbourhood does not fit: all queries of the cell take the general path
+            for (int p = qs + tid; p < qe; p += 256) { const int slot = atomicAdd(retry_count, 1); retry_list[slot] = __float_as_int(sorted[p].w); }
+            continue;
+        }
+        for (int e = tid; e < C; e += 256) {
+            int r = 0;
+#pragma unroll
+            for (int u = 1; u < 9; ++u) r += (e >= run_off[u]) ? 1 : 0;
+            cand[e] = sorted[run_s[r] + (e - run_off[r])];
+        }
+        __syncthreads();
+        const int centre0 = run_off[4] - run_s[4];   // slot of sorted[p] (p in the centre row run) = p + centre0
+        const int T = (C + 63) >> 6;
+
+        for (int p = qs + w; p < qe; p += 4) {
+            const int qslot = p + centre0;
+            const float4 Qp = cand[qslot];
+            const int q = __float_as_int(Qp.w);
+            // guarantee radius: distance to the nearest face of the searched box that has unseen cells behind it
+            float dmin = INFINITY;
+            if (x0 > 0) dmin = fminf(dmin, Qp.x - __fmaf_rn((float)x0, g.h, g.ox));
+            if (x1 < g.nx - 1) dmin = fminf(dmin, __fmaf_rn((float)(x1 + 1), g.h, g.ox) - Qp.x);
+            if (y0 > 0) dmin = fminf(dmin, Qp.y - __fmaf_rn((float)y0, g.h, g.oy));
+            if (y1 < g.ny - 1) dmin = fminf(dmin, __fmaf_rn((float)(y1 + 1), g.h, g.oy) - Qp.y);
+            if (z0 > 0) dmin = fminf(dmin, Qp.z - __fmaf_rn((float)z0, g.h, g.oz));
+            if (z1 < g.nz - 1) dmin = fminf(dmin, __fmaf_rn((float)(z1 + 1), g.h, g.oz) - Qp.z);
+            const bool covered = dmin == INFINITY;          // the box is the whole grid
+            const float dm = dmin - margin;
+            if (!covered && !(dm > 0.f)) { retry(q); continue; }
+            const float lim = covered ? INFINITY : dm * dm;
+
+            // ---- A: distances, compaction of the candidates inside the guarantee radius
+            int cnt = 0;
+            for (int t = 0; t < T; ++t) {
+                const int j = t * 64 + lane;
+                const float4 c = cand[min(j, C - 1)];
+                const float d = sqdist3(Qp.x, Qp.y, Qp.z, c.x, c.y, c.z);
+                const bool near = j < C && j != qslot && d < lim;
+                const unsigned long long mk = __ballot(near);
+                const int pos = cnt + __popcll(mk & lt_mask);
+                if (near && pos < CELL_NEAR) { nd[pos] = d; nj[pos] = j; }
+                cnt += __popcll(mk);
+            }
+            if (cnt > CELL_NEAR || cnt < S) { retry(q); continue; }   // too dense for the list / guarantee radius not reached
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            float e[4]; int ej[4];
+            float emax = 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int k = lane + 64 * r;
+                const bool v = k < cnt;
+                e[r] = v ? nd[k] : INFINITY;
+                ej[r] = v ? nj[k] : 0;
+                emax = v ? fmaxf(emax, e[r]) : emax;
+            }
+            // ---- B: exact threshold of rank S
+            const float hi = covered ? wave_max(emax) * 1.0001f + 1e-30f : lim;
+            const float scale = 64.0f / hi;
+            hist[lane] = 0;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            int bin[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                bin[r] = min(63, (int)(e[r] * scale));       // monotone in the distance; INF (idle slots) -> 63, not counted
+                if (lane + 64 * r < cnt) atomicAdd(&hist[bin[r]], 1);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const int h = hist[lane];
+            const int incl = wave_incl_scan(h, lane);
+            const unsigned long long ge = __ballot(incl >= S);   // != 0: cnt >= S
+            const int B = __ffsll((long long)ge) - 1;
+            const int nB = rl_i(h, B);
+            const int r_need = S - (rl_i(incl, B) - nB);          // 1 .. nB elements of bin B belong to the answer
+            float tau;
+            {
+                // the elements of bin B, compacted to lanes 0 .. nB-1 (nB is small: ~2 on uniform clouds)
+                int base = 0;
+                bool too_many = false;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const bool inb = (lane + 64 * r < cnt) && bin[r] == B;
+                    const unsigned long long mk = __ballot(inb);
+                    const int pos = base + __popcll(mk & lt_mask);
+                    if (inb && pos < 64) sd[pos] = e[r];
+                    base += __popcll(mk);
+                }
+                too_many = base > 64;
+                if (too_many) { retry(q); continue; }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                const float v = lane < nB ? sd[lane] : INFINITY;
+                int rank = 0;
+                for (int u = 0; u < nB; ++u) rank += (rl_f(v, u) < v) ? 1 : 0;
+                // tau = the r_need-th smallest of bin B; equal values share a rank, so "<= tau" may select more than r_need
+                const float tv = (lane < nB && rank < r_need) ? v : -1.0f;
+                tau = wave_max(tv);
+                const int n_le = __popcll(__ballot(lane < nB && v <= tau));
+                if (n_le != r_need) { tie(q); continue; }         // the cut falls between equal distances
+            }
+            // ---- C: the S selected elements, one per lane, sorted
+            {
+                int base = 0;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const bool sel = (lane + 64 * r < cnt) && e[r] <= tau;
+                    const unsigned long long mk = __ballot(sel);
+                    const int pos = base + __popcll(mk & lt_mask);
+                    if (sel && pos < 64) { sd[pos] = e[r]; sj[pos] = ej[r]; }
+                    base += __popcll(mk);
+                }
+                if (base != S) { retry(q); continue; }            // cannot happen (kept as a guard)
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            float d = lane < S ? sd[lane] : INFINITY;
+            int j = lane < S ? sj[lane] : 0;
+            wave_sort64(d, j, lane);
+            {
+                const float nxd = __shfl_down(d, 1, 64);
+                const bool t = (lane + 1 < S && d == nxd) || (lane == 0 && d == 0.f);   // equal neighbours / a twin of the query
+                if (__ballot(t) != 0ull) { tie(q); continue; }
+            }
+            // ---- output: row = [query itself (distance 0), the S neighbours]
+            const float4 nb = cand[j];
+            const int ni = __float_as_int(nb.w);
+            if (lane == 0) {
+                if (o.idx) o.idx[(size_t)q * nsample] = q;
+                if (o.dist2) o.dist2[(size_t)q * nsample] = 0.f;
+            }
+            if (lane < S) {
+                if (o.idx) o.idx[(size_t)q * nsample + lane + 1] = ni;
+                if (o.dist2) o.dist2[(size_t)q * nsample + lane + 1] = d;
+                if (o.group_idx) o.group_idx[(size_t)q * S + lane] = ni;
+                if (o.ppf) {
+                    const float* pn = o.ref_normals + (size_t)ni * 3;
+                    const float* qn = o.query_normals + (size_t)q * 3;
+                    reinterpret_cast<float4*>(o.ppf)[(size_t)q * S + lane] =
+                        ppf4(Qp.x, Qp.y, Qp.z, qn[0], qn[1], qn[2], nb.x, nb.y, nb.z, pn[0], pn[1], pn[2]);
+                }
+            }
+        }
+    }
 }
 
 // Queries that are not the reference points themselves: counting-sort their indices by the cell of the REFERENCE grid
@@ -973,11 +1220,12 @@ size_t g_legacy_ws_ints = 0;
 
 }  // namespace
 
-// Workspace layout (ints): [0] tie counter, [1 .. m] tie list, then (grid path)
-// grids (b * 8 words), cell_start (b * (GRID_MAX_CELLS+1)), sorted float4 (n * 4 words, 16-B aligned).
+// Workspace layout (ints): [0] tie counter, [1] retry counter (cell kernel -> general kernel), [4 .. 4 + m) tie list, then (grid
+// path) grids (b * 8 words), cell_start (b * (GRID_MAX_CELLS+1)), sorted float4 (n * 4 words, 16-B aligned), then m ints: the
+// query order of non-self lane queries / the retry list of self queries (never both in one call).
 extern "C" size_t roitr_knn_workspace_bytes(int b, int n, int m)
 {
-    size_t ints = 1 + (size_t)m;
+    size_t ints = 4 + (size_t)m;
     ints = (ints + 3) & ~(size_t)3;
     ints += (size_t)b * 8 + (size_t)b * (GRID_MAX_CELLS + 1);
     ints = (ints + 3) & ~(size_t)3;
@@ -995,8 +1243,8 @@ WsView carve(void* ws, int b, int n, int m)
     uintptr_t base = ((uintptr_t)ws + 15) & ~(uintptr_t)15;
     int* p = (int*)base;
     WsView v;
-    v.tie_count = p; v.tie_list = p + 1;
-    size_t ints = 1 + (size_t)m; ints = (ints + 3) & ~(size_t)3;
+    v.tie_count = p; v.tie_list = p + 4;
+    size_t ints = 4 + (size_t)m; ints = (ints + 3) & ~(size_t)3;
     v.grids = (RoitrGrid*)(p + ints); ints += (size_t)b * 8;
     v.cell_start = p + ints; ints += (size_t)b * (GRID_MAX_CELLS + 1);
     ints = (ints + 3) & ~(size_t)3;
@@ -1051,7 +1299,7 @@ extern "C" int roitr_knnquery_ex(int b, int n, int m, int nsample, const float* 
     if (ppf && (!ref_normals || !query_normals)) return ROITR_ERR_ARG;
     WsView v = carve(ws, b, n, m_capacity);
     KnnOut o = {idx, dist2, group_idx, ppf, ref_normals, query_normals, v.tie_count, v.tie_list};
-    ROITR_HIP(hipMemsetAsync(v.tie_count, 0, sizeof(int), stream));
+    ROITR_HIP(hipMemsetAsync(v.tie_count, 0, 2 * sizeof(int), stream));   // tie counter + retry counter
     const int blocks = div_up(m, 4);
     // algorithmic bytes: refs xyz(+normals) once, queries when distinct, idx + dist2/ppf rows out
     {
@@ -1063,6 +1311,7 @@ extern "C" int roitr_knnquery_ex(int b, int n, int m, int nsample, const float* 
     static const int lane_min = [] { const char* e = getenv("ROITR_KNN_LANE_MIN"); return e ? atoi(e) : 8192; }();
     static const bool lane_brute = getenv("ROITR_KNN_NO_LANE_BRUTE") == nullptr;
     static const bool gridsel = getenv("ROITR_KNN_NO_GRIDSEL") == nullptr;
+    static const bool cellk = getenv("ROITR_KNN_NO_CELL") == nullptr;
     const bool lane_ok = use_grid && m >= lane_min && (!ppf || group_idx) && b > 0;
     const int self_sorted = (new_xyz == xyz && new_offset == offset && m == n) ? 1 : 0;
     // non-self queries: walk them in reference-cell order; the order array reuses the tie list's tail
@@ -1081,8 +1330,16 @@ extern "C" int roitr_knnquery_ex(int b, int n, int m, int nsample, const float* 
         const int need = nsample + 1;
         if (need <= 2) LANE_CASE(2); else if (need <= 4) LANE_CASE(4); else if (need <= 10) LANE_CASE(10);
         else if (need <= 18) LANE_CASE(18); else LANE_CASE(34);
+    } else if (use_grid && cellk && self_sorted && b > 0 && v.qorder && nsample - 1 <= 64) {
+        // large k, self queries: workgroup per cell over the LDS-staged neighbourhood; what it cannot decide goes through the
+        // retry list to the general selection kernel
+        int* retry_count = v.tie_count + 1;
+        knn_cell_kernel<<<dim3(1024, b), 256, 0, stream>>>(nsample, xyz, offset, v.grids, v.cell_start, v.sorted, o, retry_count, v.qorder);
+        knn_gridsel_kernel<<<1024, 256, 0, stream>>>(m, nsample, xyz, new_xyz, offset, new_offset, v.grids, v.cell_start, v.sorted, o, v.qorder,
+                                                      retry_count);
     } else if (use_grid && gridsel && nsample + 1 <= 128) {
-        knn_gridsel_kernel<<<blocks, 256, 0, stream>>>(m, nsample, xyz, new_xyz, offset, new_offset, v.grids, v.cell_start, v.sorted, o);
+        knn_gridsel_kernel<<<min(blocks, 65536), 256, 0, stream>>>(m, nsample, xyz, new_xyz, offset, new_offset, v.grids, v.cell_start, v.sorted, o,
+                                                                    nullptr, nullptr);
     } else if (lane_ok && m >= 4 * lane_min) {
         if (nsample + 1 <= 66) LANE_CASE(66); else LANE_CASE(101);
     } else
@@ -1110,6 +1367,19 @@ extern "C" int roitr_knnquery_ex(int b, int n, int m, int nsample, const float* 
     knn_replay_kernel<<<min(m, 128), 64, 0, stream>>>(nsample, xyz, new_xyz, offset, new_offset, o);
     roitr_prof_end(ROITR_PROF_REPLAY, stream);
     ROITR_LAUNCH_CHECK();
+    {   // debug (ROITR_KNN_STATS=1, synchronous): queries that went to the exact replay / from the cell kernel to the general one
+        struct Stats {
+            bool on = getenv("ROITR_KNN_STATS") != nullptr; long q = 0, ties = 0, retries = 0, calls = 0;
+            ~Stats() { if (on) fprintf(stderr, "KNNSTATS calls %ld queries %ld replayed %ld cell->general %ld\n", calls, q, ties, retries); }
+        };
+        static Stats st;
+        if (st.on) {
+            int h[2] = {0, 0};
+            ROITR_HIP(hipMemcpyAsync(h, v.tie_count, sizeof(h), hipMemcpyDeviceToHost, stream));
+            ROITR_HIP(hipStreamSynchronize(stream));
+            st.calls++; st.q += m; st.ties += h[0]; st.retries += h[1];
+        }
+    }
     return ROITR_OK;
 }
 
@@ -1120,7 +1390,7 @@ extern "C" void knnquery_cuda_launcher(int m, int nsample, const float* xyz, con
                                        const int* new_offset, int* idx, float* dist2)
 {
     if (m <= 0) return;
-    const size_t need = (size_t)m + 8;
+    const size_t need = (size_t)m + 16;   // counters (4 ints) + tie list + alignment slack
     if (need > g_legacy_ws_ints) {
         if (g_legacy_ws) (void)hipFree(g_legacy_ws);
         g_legacy_ws_ints = need * 2;
