@@ -727,19 +727,18 @@ __global__ __launch_bounds__(256) void knn_cell_kernel(int nsample, const float*
         const int y0 = max(cy - 1, 0), y1 = min(cy + 1, g.ny - 1);
         const int z0 = max(cz - 1, 0), z1 = min(cz + 1, g.nz - 1);
         __syncthreads();                        // the previous cell's queries are done with cand / run tables
-        if (tid == 0) {
-            int acc = 0;
-            for (int rz = 0; rz < 3; ++rz)
-                for (int ry = 0; ry < 3; ++ry) {
-                    const int yy = cy - 1 + ry, zz = cz - 1 + rz;
-                    int a = 0, b = 0;
-                    if (yy >= 0 && yy < g.ny && zz >= 0 && zz < g.nz) {
-                        const int rowbase = (zz * g.ny + yy) * g.nx;
-                        a = cs[rowbase + x0]; b = cs[rowbase + x1 + 1];
-                    }
-                    run_s[rz * 3 + ry] = a; run_off[rz * 3 + ry] = acc; acc += b - a;
+        if (tid < 64) {   // lanes 0..8: one (z, y) row of the neighbourhood each; exclusive prefix of the run lengths across them
+            int a = 0, b = 0;
+            if (tid < 9) {
+                const int yy = cy - 1 + tid % 3, zz = cz - 1 + tid / 3;
+                if (yy >= 0 && yy < g.ny && zz >= 0 && zz < g.nz) {
+                    const int rowbase = (zz * g.ny + yy) * g.nx;
+                    a = cs[rowbase + x0]; b = cs[rowbase + x1 + 1];
                 }
-            run_off[9] = acc;
+            }
+            const int incl = wave_incl_scan(b - a, lane);
+            if (tid < 9) { run_s[tid] = a; run_off[tid] = incl - (b - a); }
+            if (tid == 8) run_off[9] = incl;
         }
         __syncthreads();
         const int C = run_off[9];
@@ -1159,34 +1158,47 @@ __global__ __launch_bounds__(64) void knn_replay_kernel(int nsample, const float
         Query Q = {new_xyz[(size_t)q * 3], new_xyz[(size_t)q * 3 + 1], new_xyz[(size_t)q * 3 + 2]};
         for (int p = lane; p < nsample; p += 64) { hd[p] = KNN_FILL; hi[p] = start; }
         __syncthreads();
-        for (int base = start; base < end; base += 64) {
-            const int k = base + lane;
-            float cd = INFINITY;
-            if (k < end) {
-                const float* p = xyz + (size_t)k * 3;
-                cd = sqdist3(Q.x, Q.y, Q.z, p[0], p[1], p[2]);
+        // the scan is one wave walking the whole cloud: NB batches of 64 distances are loaded together (the admission order
+        // below is still strictly the index order), otherwise every step is a dependent HBM / L2 round trip
+        constexpr int NB = 8;
+        for (int base0 = start; base0 < end; base0 += 64 * NB) {
+            float cdv[NB];
+#pragma unroll
+            for (int u = 0; u < NB; ++u) {
+                const int k = base0 + 64 * u + lane;
+                cdv[u] = INFINITY;
+                if (k < end) {
+                    const float* p = xyz + (size_t)k * 3;
+                    cdv[u] = sqdist3(Q.x, Q.y, Q.z, p[0], p[1], p[2]);
+                }
             }
-            float root = hd[0];
-            unsigned long long mk = __ballot(cd < root);
-            while (mk) {
-                const int l = __ffsll((long long)mk) - 1;
-                mk &= mk - 1;
-                const float nd = rl_f(cd, l);
-                if (nd < root) {
-                    __syncthreads();
-                    if (lane == 0) {
-                        hd[0] = nd; hi[0] = base + l;
-                        int rt = 0, child = 1;  // reheap, l.21-36
-                        while (child < nsample) {
-                            if (child + 1 < nsample && hd[child + 1] > hd[child]) child++;
-                            if (hd[rt] > hd[child]) break;
-                            const float td = hd[rt]; hd[rt] = hd[child]; hd[child] = td;
-                            const int ti = hi[rt]; hi[rt] = hi[child]; hi[child] = ti;
-                            rt = child; child = rt * 2 + 1;
+#pragma unroll
+            for (int u = 0; u < NB; ++u) {
+                const int base = base0 + 64 * u;
+                if (base >= end) break;   // wave-uniform
+                const float cd = cdv[u];
+                float root = hd[0];
+                unsigned long long mk = __ballot(cd < root);
+                while (mk) {
+                    const int l = __ffsll((long long)mk) - 1;
+                    mk &= mk - 1;
+                    const float nd = rl_f(cd, l);
+                    if (nd < root) {
+                        __syncthreads();
+                        if (lane == 0) {
+                            hd[0] = nd; hi[0] = base + l;
+                            int rt = 0, child = 1;  // reheap, l.21-36
+                            while (child < nsample) {
+                                if (child + 1 < nsample && hd[child + 1] > hd[child]) child++;
+                                if (hd[rt] > hd[child]) break;
+                                const float td = hd[rt]; hd[rt] = hd[child]; hd[child] = td;
+                                const int ti = hi[rt]; hi[rt] = hi[child]; hi[child] = ti;
+                                rt = child; child = rt * 2 + 1;
+                            }
                         }
+                        __syncthreads();
+                        root = hd[0];
                     }
-                    __syncthreads();
-                    root = hd[0];
                 }
             }
         }
