@@ -69,7 +69,10 @@ def _knn(nsample, xyz, new_xyz, offset, new_offset, want_idx=True, want_dist=Tru
     ws = torch.empty(lib.roitr_knn_workspace_bytes(b, n, m), dtype=torch.uint8, device=dev)
     st = L.stream_ptr()
     if use_grid:
-        rho = ctypes.c_float(max(6.0, (nsample + 1) / 3.0))  # ring-1 neighbourhood should hold the k+1 neighbours
+        # ring-1 neighbourhood (27 cells) should hold the k+1 neighbours with room for the guarantee radius; the
+        # workgroup-per-cell kernel (k + 2 >= 35, self queries) measured best at 0.4 (k + 2) points per cell
+        need = nsample + 1
+        rho = ctypes.c_float(max(6.0, need * 0.4 if need >= 35 else need / 3.0))
         L.check(lib.roitr_knn_build_grid_ex(b, n, m, L.ptr(xyz), L.ptr(offset), L.ptr(ws), rho, st), "knn_build_grid")
     L.check(lib.roitr_knnquery_ex(b, n, m, int(nsample), L.ptr(xyz), L.ptr(new_xyz), L.ptr(offset), L.ptr(new_offset),
                                   L.ptr(idx), L.ptr(d2), L.ptr(grp), L.ptr(ppf), L.ptr(ref_normals), L.ptr(query_normals),
