@@ -106,6 +106,8 @@ typedef struct RoitrLocalAttn {
     float scale;
     float* out; int ldo;
     const void* node_order;   /* optional float4[M] (x,y,z,index-as-bits): visiting order, e.g. roitr_knn_sorted_points() */
+    int bf16;                 /* 0: fp32 rows; 3: q / k / v rows AND the output row are stored in bf16 (uint16; ld* in elements) --
+                                 the engine's bf16 operand mode, where the q|k|v tensor is written bf16 by its GEMM */
 } RoitrLocalAttn;
 int roitr_local_attention(const RoitrLocalAttn* a, roitr_stream_t stream);
 int roitr_build_pfold(int H, int heads, const float* wpe, const float* bpe, float* pfold, roitr_stream_t stream);

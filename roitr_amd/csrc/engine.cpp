@@ -190,11 +190,16 @@ int gemm(hipStream_t st, int M, const float* A, const Lin& l, float* C, bool rel
 // nn.Linear followed by (+ residual) LayerNorm (+ post-add) (ReLU): one launch when the layer is 64 wide (the LayerNorm
 // runs in the GEMM epilogue, the (M, 64) intermediate never reaches HBM), the two-launch sequence otherwise.
 // `tmp` (M x l.out) is only touched by the two-launch form.
-bool ln_fuses(int N, int K, int lda, int ldw)
+// The fused form is bitwise the two-launch result, so the choice may depend on the row count without breaking batch invariance:
+// 256-wide rows fuse only for small M (64 x 256 tiles leave big batches with too few, too fat blocks: +1.0 ms per 128-pair
+// forward), where the saved launch is what counts (41 add_layernorm launches per forward at one pair per call).
+bool ln_fuses(int N, int K, int lda, int ldw, int M = 1 << 30)
 {
     static const bool fuse = getenv("ROITR_NO_LN_FUSE") == nullptr;
     static const int fuse_max = [] { const char* e = getenv("ROITR_LN_FUSE_MAX"); return e ? atoi(e) : 128; }();
-    return fuse && (N == 64 || N == 128 || N == 256) && N <= fuse_max && K % 32 == 0 && lda % 4 == 0 && ldw % 4 == 0;
+    static const int small_m = [] { const char* e = getenv("ROITR_LN_FUSE_SMALL_M"); return e ? atoi(e) : 8192; }();
+    const int lim = M <= small_m ? 256 : fuse_max;
+    return fuse && (N == 64 || N == 128 || N == 256) && N <= lim && K % 32 == 0 && lda % 4 == 0 && ldw % 4 == 0;
 }
 // bf: ROITR_BF16_A (A stored bf16; lda in elements) and / or ROITR_BF16_C (out stored bf16: fused form only)
 int gemm_ln(hipStream_t st, int M, const float* A, const Lin& l, const float* res, const int* res_idx, const float* gamma,
@@ -206,7 +211,7 @@ int gemm_ln(hipStream_t st, int M, const float* A, const Lin& l, const float* re
     const int lda = K, ldw = K;
     // measured per 128-pair forward: fusing the 64-wide layers -1.55 ms, + the 128-wide ones -0.4 ms, + the 256-wide ones
     // +1.0 ms (64 x 256 tiles leave the coarse levels with too few, too fat blocks) -> default limit 128
-    if (ln_fuses(N, K, lda, ldw)) {
+    if (ln_fuses(N, K, lda, ldw, M)) {
         RoitrGemm g;
         memset(&g, 0, sizeof(g));
         g.M = M; g.N = N; g.K = K; g.A = A; g.lda = lda; g.W = w; g.ldw = ldw; g.bias = b; g.alpha = 1.0f; g.C = out; g.ldc = N; g.batch = 1;
@@ -325,21 +330,27 @@ int local_transformer(Engine& E, hipStream_t st, const LocalT& L, int N_in, cons
     const int H = L.H, NQ = 5 * HEADS;
     float* f = A.get<float>((size_t)N_in * H);
     CHK(gemm(st, N_in, x, L.in_proj, f));
+    // bf16 operand mode: the q | k | v tensor (operands of the attention products) and the attention output (operand of
+    // `linear`) are stored bf16 by their producers -- half the bytes of the gather-bound attention kernel
+    const bool hb = bf16_layer(L.wqkv_b, H) && bf16_layer(L.lin.wb, H);
+    const int cq = hb ? ROITR_BF16_C : 0;
+    const size_t esz = hb ? 2 : 4;
     const float *q, *k, *v; int ldq, ldkv;
     if (!node_idx) {
         const int R = 3 * H + NQ;
         float* qkv = A.get<float>((size_t)N_in * R);
         if (A.fail) return ROITR_ERR_ARG;
-        CHK(gemm(st, N_in, R, H, f, H, L.wqkv, H, L.bqkv, qkv, R, false, nullptr, nullptr, 1.0f, L.wqkv_b));
-        q = qkv; k = qkv + H + NQ; v = qkv + 2 * H + NQ; ldq = R; ldkv = R;
+        CHK(gemm(st, N_in, R, H, f, H, L.wqkv, H, L.bqkv, qkv, R, false, nullptr, nullptr, 1.0f, L.wqkv_b, cq));
+        const char* b0 = (const char*)qkv;
+        q = qkv; k = (const float*)(b0 + (size_t)(H + NQ) * esz); v = (const float*)(b0 + (size_t)(2 * H + NQ) * esz); ldq = R; ldkv = R;
     } else {
         float* qe = A.get<float>((size_t)M * (H + NQ));
         float* kv = A.get<float>((size_t)N_in * 2 * H);
         if (A.fail) return ROITR_ERR_ARG;
-        CHK(gemm(st, M, H + NQ, H, f, H, L.wqkv, H, L.bqkv, qe, H + NQ, false, node_idx, nullptr, 1.0f, L.wqkv_b));
+        CHK(gemm(st, M, H + NQ, H, f, H, L.wqkv, H, L.bqkv, qe, H + NQ, false, node_idx, nullptr, 1.0f, L.wqkv_b, cq));
         CHK(gemm(st, N_in, 2 * H, H, f, H, L.wqkv + (size_t)(H + NQ) * H, H, L.bqkv + H + NQ, kv, 2 * H, false, nullptr, nullptr, 1.0f,
-                 L.wqkv_b ? L.wqkv_b + (size_t)(H + NQ) * H : nullptr));
-        q = qe; k = kv; v = kv + H; ldq = H + NQ; ldkv = 2 * H;
+                 L.wqkv_b ? L.wqkv_b + (size_t)(H + NQ) * H : nullptr, cq));
+        q = qe; k = kv; v = (const float*)((const char*)kv + (size_t)H * esz); ldq = H + NQ; ldkv = 2 * H;
     }
     float* att = A.get<float>((size_t)M * H);
     float* hid = A.get<float>((size_t)M * H);
@@ -349,11 +360,11 @@ int local_transformer(Engine& E, hipStream_t st, const LocalT& L, int N_in, cons
     memset(&a, 0, sizeof(a));
     a.M = M; a.K = K; a.H = H; a.heads = HEADS; a.q = q; a.ldq = ldq; a.k = k; a.ldk = ldkv; a.v = v; a.ldv = ldkv;
     a.group_idx = group; a.ppf = ppf; a.wvpe = L.wvpe; a.bvpe = L.bvpe; a.scale = 1.0f / sqrtf((float)(H / HEADS));
-    a.out = att; a.ldo = H; a.node_order = order;
+    a.out = att; a.ldo = H; a.node_order = order; a.bf16 = hb ? 3 : 0;
     CHK(roitr_local_attention(&a, st));
     // bf16 operand mode: `y` only feeds out_proj -> the LayerNorm epilogue stores it in bf16 (half the round trip)
-    const bool y_h = ln_fuses(H, H, H, H) && bf16_layer(L.lin.wb, H) && bf16_layer(L.out_proj.wb, H);
-    CHK(gemm_ln(st, M, att, L.lin, f, node_idx, L.norm_w, L.norm_b, nullptr, false, hid, y, y_h ? ROITR_BF16_C : 0));
+    const bool y_h = ln_fuses(H, H, H, H) && bf16_layer(L.lin.wb, H) && bf16_layer(L.out_proj.wb, H);   // independent of M: batch-invariant storage
+    CHK(gemm_ln(st, M, att, L.lin, f, node_idx, L.norm_w, L.norm_b, nullptr, false, hid, y, (y_h ? ROITR_BF16_C : 0) | (hb ? ROITR_BF16_A : 0)));
     if (bn2_res) {
         float* t = A.get<float>((size_t)M * L.out_dim);
         if (A.fail) return ROITR_ERR_ARG;

@@ -35,10 +35,41 @@ template <> struct VecLoad<4> { static __device__ __forceinline__ void ld(const 
 template <> struct VecLoad<8> { static __device__ __forceinline__ void ld(const float* p, float* d) { VecLoad<4>::ld(p, d); VecLoad<4>::ld(p + 4, d + 4); }
                                 static __device__ __forceinline__ void st(float* p, const float* d) { VecLoad<4>::st(p, d); VecLoad<4>::st(p + 4, d + 4); } };
 
+// bf16-stored rows (engine operand_dtype = bf16): HV consecutive bf16 -> fp32 (exact widening), fp32 -> bf16 (RNE) on store
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pack2(float x, float y)
+{
+    f32x2_t v = {x, y};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+}
+__device__ __forceinline__ void unpack2(unsigned u, float& a, float& b) { a = __uint_as_float(u << 16); b = __uint_as_float(u & 0xffff0000u); }
+template <int HV> struct VecLoadH;
+template <> struct VecLoadH<1> { static __device__ __forceinline__ void ld(const unsigned short* p, float* d) { d[0] = __uint_as_float((unsigned)*p << 16); }
+                                 static __device__ __forceinline__ void st(unsigned short* p, const float* d) { *p = (unsigned short)(pack2(d[0], 0.f) & 0xffffu); } };
+template <> struct VecLoadH<2> { static __device__ __forceinline__ void ld(const unsigned short* p, float* d) { unpack2(*reinterpret_cast<const unsigned*>(p), d[0], d[1]); }
+                                 static __device__ __forceinline__ void st(unsigned short* p, const float* d) { *reinterpret_cast<unsigned*>(p) = pack2(d[0], d[1]); } };
+template <> struct VecLoadH<4> { static __device__ __forceinline__ void ld(const unsigned short* p, float* d) { const uint2 t = *reinterpret_cast<const uint2*>(p); unpack2(t.x, d[0], d[1]); unpack2(t.y, d[2], d[3]); }
+                                 static __device__ __forceinline__ void st(unsigned short* p, const float* d) { *reinterpret_cast<uint2*>(p) = make_uint2(pack2(d[0], d[1]), pack2(d[2], d[3])); } };
+template <> struct VecLoadH<8> { static __device__ __forceinline__ void ld(const unsigned short* p, float* d) { VecLoadH<4>::ld(p, d); VecLoadH<4>::ld(p + 4, d + 4); }
+                                 static __device__ __forceinline__ void st(unsigned short* p, const float* d) { VecLoadH<4>::st(p, d); VecLoadH<4>::st(p + 4, d + 4); } };
+// row access in either storage type: `p` is the array base as the struct carries it (const float*), offsets in ELEMENTS
+template <bool HALF, int HV> __device__ __forceinline__ void row_ld(const float* base, size_t off, float* d)
+{
+    if (HALF) VecLoadH<HV>::ld(reinterpret_cast<const unsigned short*>(base) + off, d);
+    else VecLoad<HV>::ld(base + off, d);
+}
+template <bool HALF> __device__ __forceinline__ float elem_ld(const float* base, size_t off)
+{
+    if (HALF) return __uint_as_float((unsigned)reinterpret_cast<const unsigned short*>(base)[off] << 16);
+    return base[off];
+}
+
 __device__ __forceinline__ void lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
-// K = neighbours per node (8 / 16), HV = H / 64 (channels per lane); heads == 4.
-template <int K, int HV>
+// K = neighbours per node (8 / 16), HV = H / 64 (channels per lane); heads == 4.  HALF: q / k / v rows and the output row are
+// stored in bf16 (RoitrLocalAttn::bf16); all arithmetic stays fp32.
+template <int K, int HV, bool HALF>
 __global__ __launch_bounds__(256) void local_attn_kernel(RoitrLocalAttn a)
 {
     __shared__ __attribute__((aligned(16))) float xch[4][80];   // per wave: probs [head][16] | pbar [head][4]
@@ -57,10 +88,10 @@ __global__ __launch_bounds__(256) void local_attn_kernel(RoitrLocalAttn a)
 
     // ---- round trip 1: everything addressed by the node id
     const int g = a.group_idx[(size_t)node * K + (lane < K ? lane : 0)];
-    const float* qrow = a.q + (size_t)node * a.ldq;
+    const size_t qoff = (size_t)node * a.ldq;
     float qv[HV];
-    VecLoad<HV>::ld(qrow + lane * HV, qv);
-    float ec = t < 5 ? qrow[H + h * 5 + t] : 0.f;   // qp[h][0..3] (PPF coefficients), qp[h][4] (q_h . bpe_h)
+    row_ld<HALF, HV>(a.q, qoff + lane * HV, qv);
+    float ec = t < 5 ? elem_ld<HALF>(a.q, qoff + H + h * 5 + t) : 0.f;   // qp[h][0..3] (PPF coefficients), qp[h][4] (q_h . bpe_h)
     float pv[K];
     const float* pf = a.ppf + (size_t)node * K * 4 + (t < 4 ? t : 0);
 #pragma unroll
@@ -70,12 +101,12 @@ __global__ __launch_bounds__(256) void local_attn_kernel(RoitrLocalAttn a)
 #pragma unroll
     for (int kk = 0; kk < K; ++kk) {
         const int gk = __builtin_amdgcn_readlane(g, kk);
-        VecLoad<HV>::ld(a.k + (size_t)gk * a.ldk + lane * HV, kr[kk]);
+        row_ld<HALF, HV>(a.k, (size_t)gk * a.ldk + lane * HV, kr[kk]);
     }
 #pragma unroll
     for (int kk = 0; kk < K; ++kk) {
         const int gk = __builtin_amdgcn_readlane(g, kk);
-        VecLoad<HV>::ld(a.v + (size_t)gk * a.ldv + lane * HV, vr[kk]);
+        row_ld<HALF, HV>(a.v, (size_t)gk * a.ldv + lane * HV, vr[kk]);
     }
 #pragma unroll
     for (int i = 0; i < HV; ++i) qv[i] *= a.scale;
@@ -123,7 +154,8 @@ __global__ __launch_bounds__(256) void local_attn_kernel(RoitrLocalAttn a)
         const float4 w = reinterpret_cast<const float4*>(a.wvpe)[lane * HV + i];
         o[i] = acc + (w.x * pb4.x + w.y * pb4.y + w.z * pb4.z + w.w * pb4.w + bias[i]);
     }
-    VecLoad<HV>::st(a.out + (size_t)node * a.ldo + lane * HV, o);
+    if (HALF) VecLoadH<HV>::st(reinterpret_cast<unsigned short*>(a.out) + (size_t)node * a.ldo + lane * HV, o);
+    else VecLoad<HV>::st(a.out + (size_t)node * a.ldo + lane * HV, o);
 }
 
 // Pfold (5*NH x H): row h*5+j holds Wpe[h*c + cc][j] (j<4) / bpe[h*c+cc] (j=4) at column h*c+cc, else 0.
@@ -147,11 +179,20 @@ extern "C" int roitr_local_attention(const RoitrLocalAttn* a, hipStream_t stream
     const int hv = a->H / 64;
     // heads = the 4 DPP rows of a wave; float4 row accesses need 16-byte aligned rows
     if (a->heads != 4 || a->H % 64 || (a->K != 8 && a->K != 16) || (hv != 1 && hv != 2 && hv != 4 && hv != 8)) return ROITR_ERR_UNSUPPORTED;
-    if (hv > 1 && ((a->ldq | a->ldk | a->ldv | a->ldo) % (hv > 4 ? 4 : hv) || ((uintptr_t)a->q | (uintptr_t)a->k | (uintptr_t)a->v | (uintptr_t)a->out) % 16))
+    const bool half = a->bf16 != 0;
+    if (half && a->bf16 != 3) return ROITR_ERR_UNSUPPORTED;   // bf16 rows in AND out, or fp32 both
+    if (!half && hv > 1 && ((a->ldq | a->ldk | a->ldv | a->ldo) % (hv > 4 ? 4 : hv) || ((uintptr_t)a->q | (uintptr_t)a->k | (uintptr_t)a->v | (uintptr_t)a->out) % 16))
+        return ROITR_ERR_UNSUPPORTED;
+    // bf16 rows: a lane reads HV bf16 = 2 HV bytes in pieces of at most 8 -> rows and bases aligned to min(2 HV, 8) bytes
+    if (half && (((a->ldq | a->ldk | a->ldv | a->ldo) * 2) % (hv >= 4 ? 8 : 2 * hv) || ((uintptr_t)a->q | (uintptr_t)a->k | (uintptr_t)a->v | (uintptr_t)a->out) % 8))
         return ROITR_ERR_UNSUPPORTED;
     // algorithmic bytes: q row + K gathered k and v rows + ppf + idx in, one row out
     roitr_prof_begin(ROITR_PROF_LOCAL_ATTN, (double)a->M * ((a->H + 20.0) * 4 + a->K * (2.0 * a->H * 4 + 20.0) + a->H * 4.0), stream);
-#define LA_CASE(KK, HH) local_attn_kernel<KK, HH><<<xcd_grid(div_up(a->M, 4)), 256, 0, stream>>>(*a)
+#define LA_CASE(KK, HH)                                                                                       \
+    do {                                                                                                      \
+        if (half) local_attn_kernel<KK, HH, true><<<xcd_grid(div_up(a->M, 4)), 256, 0, stream>>>(*a);         \
+        else local_attn_kernel<KK, HH, false><<<xcd_grid(div_up(a->M, 4)), 256, 0, stream>>>(*a);             \
+    } while (0)
     if (a->K == 8) { if (hv == 1) LA_CASE(8, 1); else if (hv == 2) LA_CASE(8, 2); else if (hv == 4) LA_CASE(8, 4); else LA_CASE(8, 8); }
     else { if (hv == 1) LA_CASE(16, 1); else if (hv == 2) LA_CASE(16, 2); else if (hv == 4) LA_CASE(16, 4); else LA_CASE(16, 8); }
 #undef LA_CASE

@@ -1141,48 +1141,18 @@ __global__ __launch_bounds__(64) void knn_lane_brute_kernel(int m, int nsample, 
 }
 
 // ---------------------------------------------------------------- exact replay of tied queries
-// knnquery_cuda_kernel.cu:65-108 restated for one wave.  64 distances are evaluated per step (8 steps of loads in flight)
-// and only those below the heap root are offered to the heap, in index order -- the heap sees exactly the reference's
-// insertion sequence.  The heap itself (nsample <= 100 entries) lives in REGISTERS, entry p in lane p % 64, register
-// p / 64: every index the sift-down touches is wave-uniform, so reads are v_readlane and writes a lane compare + select (a few
-// cycles each) instead of dependent LDS round trips behind a barrier -- a replayed query admits ~k ln(n / k) candidates
-// one after the other, and that serial chain is all its run time (1.08 -> ~0.1 ms per call on the k = 64, n = 30000 case).
-struct RegHeap {
-    float d0, d1; int i0, i1;
-    __device__ __forceinline__ float gd(int p) const { const float a = rl_f(d0, p & 63), b = rl_f(d1, p & 63); return p < 64 ? a : b; }
-    __device__ __forceinline__ int gi(int p) const { const int a = rl_i(i0, p & 63), b = rl_i(i1, p & 63); return p < 64 ? a : b; }
-    // writes: one compare + select per register (every index is wave-uniform; `lane` = this lane's id)
-    __device__ __forceinline__ void sd(int p, float v, int lane)
-    {
-        const bool me = lane == (p & 63);
-        d0 = (me && p < 64) ? v : d0;
-        d1 = (me && p >= 64) ? v : d1;
-    }
-    __device__ __forceinline__ void si(int p, int v, int lane)
-    {
-        const bool me = lane == (p & 63);
-        i0 = (me && p < 64) ? v : i0;
-        i1 = (me && p >= 64) ? v : i1;
-    }
-    // reheap (knnquery_cuda_kernel.cu:21-36) over the first `k` entries
-    __device__ __forceinline__ void reheap(int k, int lane)
-    {
-        int rt = 0, child = 1;
-        while (child < k) {
-            float cd = gd(child);
-            if (child + 1 < k) { const float c1 = gd(child + 1); if (c1 > cd) { child++; cd = c1; } }
-            const float rd = gd(rt);
-            if (rd > cd) break;
-            const int ri = gi(rt), ci = gi(child);
-            sd(rt, cd, lane); sd(child, rd, lane); si(rt, ci, lane); si(child, ri, lane);
-            rt = child; child = rt * 2 + 1;
-        }
-    }
-};
-
+// knnquery_cuda_kernel.cu:65-108 restated for one wave: the heap lives in LDS, every lane runs the
+// same (uniform) heap code; 64 distances are evaluated per step and only those below the root are
+// offered to the heap, in index order -- the heap sees exactly the reference's insertion sequence.
+// A replayed query admits ~k ln(n / k) candidates one after the other and that serial chain (~2 us per admission) is all
+// its run time: 0.5 ms at k = 64, n = 30000.  Measured and dropped: the heap in registers (entry p in lane p % 64, reads by
+// v_readlane, writes by lane compare + select: no LDS, no barrier) -- 1.46 vs 1.08 ms per launch on that case; 8 batches of
+// candidate loads in flight (kept) change nothing.  One query per block (up to 1024 blocks) keeps the kernel at one chain.
 __global__ __launch_bounds__(64) void knn_replay_kernel(int nsample, const float* __restrict__ xyz, const float* __restrict__ new_xyz,
                                                         const int* __restrict__ offset, const int* __restrict__ new_offset, KnnOut o)
 {
+    __shared__ float hd[128];
+    __shared__ int hi[128];
     const int lane = threadIdx.x;
     const int count = *o.tie_count;
     for (int t = blockIdx.x; t < count; t += gridDim.x) {
@@ -1190,8 +1160,10 @@ __global__ __launch_bounds__(64) void knn_replay_kernel(int nsample, const float
         int start, end, seg;
         find_segment(q, offset, new_offset, start, end, seg);
         Query Q = {new_xyz[(size_t)q * 3], new_xyz[(size_t)q * 3 + 1], new_xyz[(size_t)q * 3 + 2]};
-        RegHeap H;
-        H.d0 = KNN_FILL; H.d1 = KNN_FILL; H.i0 = start; H.i1 = start;   // best_dist = 1e10, best_idx = start (l.86-91)
+        for (int p = lane; p < nsample; p += 64) { hd[p] = KNN_FILL; hi[p] = start; }
+        __syncthreads();
+        // the scan is one wave walking the whole cloud: NB batches of 64 distances are loaded together (the admission order
+        // below is still strictly the index order), otherwise every step is a dependent HBM / L2 round trip
         constexpr int NB = 8;
         for (int base0 = start; base0 < end; base0 += 64 * NB) {
             float cdv[NB];
@@ -1209,29 +1181,52 @@ __global__ __launch_bounds__(64) void knn_replay_kernel(int nsample, const float
                 const int base = base0 + 64 * u;
                 if (base >= end) break;   // wave-uniform
                 const float cd = cdv[u];
-                float root = H.gd(0);
+                float root = hd[0];
                 unsigned long long mk = __ballot(cd < root);
                 while (mk) {
                     const int l = __ffsll((long long)mk) - 1;
                     mk &= mk - 1;
                     const float nd = rl_f(cd, l);
-                    if (nd < root) {   // strict admission (l.97), then reheap
-                        H.sd(0, nd, lane); H.si(0, base + l, lane);
-                        H.reheap(nsample, lane);
-                        root = H.gd(0);
+                    if (nd < root) {
+                        __syncthreads();
+                        if (lane == 0) {
+                            hd[0] = nd; hi[0] = base + l;
+                            int rt = 0, child = 1;  // reheap, l.21-36
+                            while (child < nsample) {
+                                if (child + 1 < nsample && hd[child + 1] > hd[child]) child++;
+                                if (hd[rt] > hd[child]) break;
+                                const float td = hd[rt]; hd[rt] = hd[child]; hd[child] = td;
+                                const int ti = hi[rt]; hi[rt] = hi[child]; hi[child] = ti;
+                                rt = child; child = rt * 2 + 1;
+                            }
+                        }
+                        __syncthreads();
+                        root = hd[0];
                     }
                 }
             }
         }
-        for (int i = nsample - 1; i > 0; i--) {   // heap_sort, l.39-48
-            const float td = H.gd(0), ld_ = H.gd(i);
-            const int ti = H.gi(0), li_ = H.gi(i);
-            H.sd(0, ld_, lane); H.sd(i, td, lane); H.si(0, li_, lane); H.si(i, ti, lane);
-            H.reheap(i, lane);
+        __syncthreads();
+        if (lane == 0) {  // heap_sort, l.39-48
+            for (int i = nsample - 1; i > 0; i--) {
+                float td = hd[0]; hd[0] = hd[i]; hd[i] = td;
+                int ti = hi[0]; hi[0] = hi[i]; hi[i] = ti;
+                int rt = 0, child = 1;
+                while (child < i) {
+                    if (child + 1 < i && hd[child + 1] > hd[child]) child++;
+                    if (hd[rt] > hd[child]) break;
+                    td = hd[rt]; hd[rt] = hd[child]; hd[child] = td;
+                    ti = hi[rt]; hi[rt] = hi[child]; hi[child] = ti;
+                    rt = child; child = rt * 2 + 1;
+                }
+            }
         }
-        const float d[2] = {H.d0, H.d1};
-        const int i[2] = {H.i0, H.i1};
+        __syncthreads();
+        float d[2]; int i[2];
+        d[0] = lane < nsample ? hd[lane] : 0.f; i[0] = lane < nsample ? hi[lane] : 0;
+        d[1] = lane + 64 < nsample ? hd[lane + 64] : 0.f; i[1] = lane + 64 < nsample ? hi[lane + 64] : 0;
         write_rows<2>(o, q, nsample, d, i, lane, xyz, Q);
+        __syncthreads();
     }
 }
 
@@ -1385,7 +1380,7 @@ extern "C" int roitr_knnquery_ex(int b, int n, int m, int nsample, const float* 
     roitr_prof_end(ROITR_PROF_KNN, stream);
     ROITR_LAUNCH_CHECK();
     roitr_prof_begin(ROITR_PROF_REPLAY, 0.0, stream);
-    knn_replay_kernel<<<min(m, 128), 64, 0, stream>>>(nsample, xyz, new_xyz, offset, new_offset, o);
+    knn_replay_kernel<<<min(m, 1024), 64, 0, stream>>>(nsample, xyz, new_xyz, offset, new_offset, o);
     roitr_prof_end(ROITR_PROF_REPLAY, stream);
     ROITR_LAUNCH_CHECK();
     {   // debug (ROITR_KNN_STATS=1, synchronous): queries that went to the exact replay / from the cell kernel to the general one
