@@ -83,6 +83,11 @@ int roitr_geo_embed_split(long rows, int C, int angle_k, const float* d_idx, con
 int roitr_geo_embed_bf16(long rows, int C, int angle_k, const float* d_idx, const float* a_idx, const float* div_term,
                          const unsigned short* Wd, const float* bd, const unsigned short* Wa, const float* ba, float* out,
                          roitr_stream_t stream);
+/* the same with the embedding itself STORED in bf16 (out: rows x C uint16) -- half the bytes of the tensor every self
+ * layer of the global transformer streams (read back by roitr_mha with e_bf16 = 1) */
+int roitr_geo_embed_bf16_out(long rows, int C, int angle_k, const float* d_idx, const float* a_idx, const float* div_term,
+                             const unsigned short* Wd, const float* bd, const unsigned short* Wa, const float* ba,
+                             unsigned short* out, roitr_stream_t stream);
 /* E = P_d + max_k P_a[:, k, :] (positional_encoding.py:146-152) */
 int roitr_geo_combine(long rows, int C, int k, const float* pd, const float* pa, float* out, roitr_stream_t stream);
 int roitr_gather_rows(long rows, int C, const float* in, const int* idx, int limit, float* out, roitr_stream_t stream);
@@ -135,6 +140,7 @@ typedef struct RoitrMha {
     float scale; int nk_max;
     float* out; int ldo;
     float* ebar;
+    int e_bf16;   /* E is stored in bf16 (uint16, same element offsets): engine operand_dtype = bf16; needs C = 256 or 512, 4 heads */
 } RoitrMha;
 int roitr_mha(const RoitrMha* a, roitr_stream_t stream);
 

@@ -784,7 +784,14 @@ extern "C" int roitr_engine_forward(void* h, const RoitrForwardIO* io, hipStream
         CHK(roitr_geo_indices(T4, p[3], D.off[3], D.cloud_of_node, D.eoff, 0.2f, 15.0f, 3, V.nmax[3], d_idx, a_idx, st));
         CHK(tap(E, st, "geo.d_idx", d_idx, sizeof(float) * etot));
         CHK(tap(E, st, "geo.a_idx", a_idx, sizeof(float) * etot * 3));
-        if (E.cfg.operand_dtype == 1 && E.proj_d.wb && E.proj_a.wb)
+        // bf16 operand mode: E (an operand of the q~ . E and a' . E contractions of every self layer) is stored bf16 when the
+        // attention kernel for this width reads it (C = 256 / 512, 4 heads, <= 512 superpoints)
+        const bool e_h = E.cfg.operand_dtype == 1 && E.proj_d.wb && E.proj_a.wb && (C4 == 256 || C4 == 512) && V.nmax[3] <= 512 &&
+                         getenv("ROITR_MHA_GENERIC") == nullptr;
+        if (e_h)
+            CHK(roitr_geo_embed_bf16_out(etot, C4, 3, d_idx, a_idx, E.geo_div, E.proj_d.wb, E.proj_d.b, E.proj_a.wb, E.proj_a.b,
+                                         reinterpret_cast<unsigned short*>(Emb), st));
+        else if (E.cfg.operand_dtype == 1 && E.proj_d.wb && E.proj_a.wb)
             CHK(roitr_geo_embed_bf16(etot, C4, 3, d_idx, a_idx, E.geo_div, E.proj_d.wb, E.proj_d.b, E.proj_a.wb, E.proj_a.b, Emb, st));
         else if (E.proj_d3)
             CHK(roitr_geo_embed_split(etot, C4, 3, d_idx, a_idx, E.geo_div, E.proj_d3, E.proj_d.b, E.proj_a3, E.proj_a.b, Emb, st));
@@ -821,6 +828,7 @@ extern "C" int roitr_engine_forward(void* h, const RoitrForwardIO* io, hipStream
                 m.q_row0 = 0; m.q_rows = T4; m.C = C4; m.heads = HEADS; m.q = qkv; m.ldq = 3 * C4; m.k = qkv + C4; m.ldk = 3 * C4;
                 m.v = qkv + 2 * C4; m.ldv = 3 * C4; m.offset = D.off[3]; m.cloud_of_row = D.cloud_of_node; m.partner = nullptr;
                 m.E = Emb; m.eoff = D.eoff; m.qt = qt; m.bp = L.p.b; m.scale = scale; m.nk_max = V.nmax[3]; m.out = hid; m.ldo = C4; m.ebar = ebar;
+                m.e_bf16 = e_h ? 1 : 0;
                 CHK(roitr_mha(&m, st));
                 {   // pos_raw[:, h-slice] = Wvp_h ebar_h + bvp_h
                     RoitrGemm gp; memset(&gp, 0, sizeof(gp));

@@ -524,6 +524,213 @@ __global__ __launch_bounds__(256) void mha_plain_kernel(RoitrMha a)
     }
 }
 
+// ------------------------------------------------------------------ the same two kernels for C = 256 CQ (CQ = 2: the factor-2
+// width of the 4DMatch configuration, model/RIGA_v2.py:24-28) and / or an E tensor stored in bf16 (engine operand_dtype =
+// bf16).  Same layout idea: a lane owns 4 CQ consecutive channels (all inside head lane / 16), rows are read coalesced,
+// E is streamed twice (the slab of a query row is n x 2 KB at C = 512: it does not fit the registers of a block).
+// Before these existed the factor-2 configuration ran on the generic mha_kernel (one row per lane, uncoalesced).
+template <int CQ> __device__ __forceinline__ void ldrow(const float* base, int lane, float4 (&d)[CQ])
+{
+#pragma unroll
+    for (int c = 0; c < CQ; ++c) d[c] = reinterpret_cast<const float4*>(base)[lane * CQ + c];
+}
+// bf16 row: 4 CQ consecutive bf16 per lane, widened exactly
+template <int CQ> __device__ __forceinline__ void ldrow_h(const unsigned short* base, int lane, float4 (&d)[CQ])
+{
+#pragma unroll
+    for (int c = 0; c < CQ; ++c) {
+        const uint2 u = reinterpret_cast<const uint2*>(base)[lane * CQ + c];
+        d[c] = make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
+    }
+}
+template <int CQ> __device__ __forceinline__ float dotq(const float4 (&x)[CQ], const float4 (&y)[CQ])
+{
+    float s = dot4(x[0], y[0]);
+#pragma unroll
+    for (int c = 1; c < CQ; ++c) s += dot4(x[c], y[c]);
+    return s;
+}
+
+template <int CQ, bool EH>
+__global__ __launch_bounds__(256) void mha_geo_wide_kernel(RoitrMha a)
+{
+    constexpr int C = 256 * CQ, NH = 4, NKP = 512;
+    __shared__ __attribute__((aligned(16))) float sc[NH][NKP];
+    __shared__ __attribute__((aligned(16))) float sc2t[NKP * 4];
+    __shared__ __attribute__((aligned(16))) float red[4][NH * C];
+    const int rowi = xcd_block_id(a.q_rows);
+    if (rowi >= a.q_rows) return;
+    const int row = a.q_row0 + rowi;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hl = lane >> 4;
+    const int cl = a.cloud_of_row[row];
+    const int ks = cl == 0 ? 0 : a.offset[cl - 1], nk = a.offset[cl] - ks;
+    const int qi = row - ks;
+    const size_t e0 = (size_t)a.eoff[cl] * C + (size_t)qi * nk * C;   // element offset of E[i, 0, 0]
+    const float* Ef = a.E + e0;
+    const unsigned short* Eh = reinterpret_cast<const unsigned short*>(a.E) + e0;
+    auto lde = [&](int j, float4 (&d)[CQ]) {
+        if (EH) ldrow_h<CQ>(Eh + (size_t)j * C, lane, d);
+        else ldrow<CQ>(Ef + (size_t)j * C, lane, d);
+    };
+    float4 qv[CQ], qt4[NH][CQ], bp4[CQ];
+    ldrow<CQ>(a.q + (size_t)row * a.ldq, lane, qv);
+#pragma unroll
+    for (int h = 0; h < NH; ++h) ldrow<CQ>(a.qt + ((size_t)row * NH + h) * C, lane, qt4[h]);
+    ldrow<CQ>(a.bp, lane, bp4);
+    const float qb = row_allsum(dotq<CQ>(qv, bp4));   // q_h . bp_h, h = this lane's row
+    // ---- scores: 4 key rows of this wave per trip (E and k rows requested together)
+    for (int j0 = wave; j0 < nk; j0 += 16) {
+        float4 ev[4][CQ], kv[4][CQ];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = min(j0 + 4 * u, nk - 1);
+            lde(j, ev[u]);
+            ldrow<CQ>(a.k + (size_t)(ks + j) * a.ldk, lane, kv[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = j0 + 4 * u;
+            const float s1 = row_allsum(dotq<CQ>(qv, kv[u]));
+            const float se0 = wave_sum(dotq<CQ>(qt4[0], ev[u])), se1 = wave_sum(dotq<CQ>(qt4[1], ev[u]));
+            const float se2 = wave_sum(dotq<CQ>(qt4[2], ev[u])), se3 = wave_sum(dotq<CQ>(qt4[3], ev[u]));
+            const float se = hl == 0 ? se0 : (hl == 1 ? se1 : (hl == 2 ? se2 : se3));
+            if (j < nk && (lane & 15) == 0) sc[hl][j] = (s1 + (se + qb)) * a.scale;
+        }
+    }
+    __syncthreads();
+    {   // softmax and diagonal-masked softmax (geoattention.py:117-134): wave = head
+        const int h = wave;
+        float mx = -INFINITY, mx2 = -INFINITY;
+        for (int j = lane; j < nk; j += 64) { const float v = sc[h][j]; mx = fmaxf(mx, v); if (j != qi) mx2 = fmaxf(mx2, v); }
+        mx = wave_max(mx); mx2 = wave_max(mx2);
+        float sm = 0.f, sm2 = 0.f;
+        for (int j = lane; j < nk; j += 64) {
+            const float v = sc[h][j];
+            const float e1 = expf(v - mx), e2 = j != qi ? expf(v - mx2) : 0.f;
+            sc[h][j] = e1; sc2t[j * 4 + h] = e2; sm += e1; sm2 += e2;
+        }
+        sm = wave_sum(sm); sm2 = wave_sum(sm2);
+        for (int j = lane; j < nk; j += 64) { sc[h][j] /= sm; sc2t[j * 4 + h] /= sm2; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u2 = 0; u2 < CQ; ++u2) {   // hidden: thread = channel tid + 256 u2
+        const int ch = tid + 256 * u2;
+        const int h = ch / (64 * CQ);
+        const float* vp = a.v + (size_t)ks * a.ldv + ch;
+        float acc = 0.f;
+        int j = 0;
+        for (; j + 8 <= nk; j += 8) {
+            float vv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) vv[u] = vp[(size_t)(j + u) * a.ldv];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc = fmaf(sc[h][j + u], vv[u], acc);
+        }
+        for (; j < nk; ++j) acc = fmaf(sc[h][j], vp[(size_t)j * a.ldv], acc);
+        a.out[(size_t)row * a.ldo + ch] = acc;
+    }
+    // ---- ebar: second pass over this wave's E rows
+    float4 acc[NH][CQ];
+#pragma unroll
+    for (int h = 0; h < NH; ++h)
+#pragma unroll
+        for (int c = 0; c < CQ; ++c) acc[h][c] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int j0 = wave; j0 < nk; j0 += 16) {
+        float4 ev[4][CQ];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) lde(min(j0 + 4 * u, nk - 1), ev[u]);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = j0 + 4 * u;
+            const float4 p2 = reinterpret_cast<const float4*>(sc2t)[j < nk ? j : 0];
+            const float w[4] = {j < nk ? p2.x : 0.f, j < nk ? p2.y : 0.f, j < nk ? p2.z : 0.f, j < nk ? p2.w : 0.f};
+#pragma unroll
+            for (int h = 0; h < NH; ++h)
+#pragma unroll
+                for (int c = 0; c < CQ; ++c) {
+                    acc[h][c].x = fmaf(w[h], ev[u][c].x, acc[h][c].x); acc[h][c].y = fmaf(w[h], ev[u][c].y, acc[h][c].y);
+                    acc[h][c].z = fmaf(w[h], ev[u][c].z, acc[h][c].z); acc[h][c].w = fmaf(w[h], ev[u][c].w, acc[h][c].w);
+                }
+        }
+    }
+#pragma unroll
+    for (int h = 0; h < NH; ++h)
+#pragma unroll
+        for (int c = 0; c < CQ; ++c) reinterpret_cast<float4*>(red[wave])[h * (64 * CQ) + lane * CQ + c] = acc[h][c];
+    __syncthreads();
+#pragma unroll
+    for (int h = 0; h < NH; ++h)
+#pragma unroll
+        for (int u2 = 0; u2 < CQ; ++u2) {
+            const int ch = tid + 256 * u2;
+            a.ebar[((size_t)row * NH + h) * C + ch] = (red[0][h * C + ch] + red[1][h * C + ch]) + (red[2][h * C + ch] + red[3][h * C + ch]);
+        }
+}
+
+template <int NKP, int CQ>   // plain (cross) attention at C = 256 CQ
+__global__ __launch_bounds__(256) void mha_plain_wide_kernel(RoitrMha a)
+{
+    constexpr int NH = 4;
+    __shared__ float sc[NH][NKP];
+    const int rowi = xcd_block_id(a.q_rows);
+    if (rowi >= a.q_rows) return;
+    const int row = a.q_row0 + rowi;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hl = lane >> 4;
+    const int cl = a.cloud_of_row[row];
+    const int kc = a.partner ? a.partner[cl] : cl;
+    const int ks = kc == 0 ? 0 : a.offset[kc - 1], nk = a.offset[kc] - ks;
+    float4 qv[CQ];
+    ldrow<CQ>(a.q + (size_t)row * a.ldq, lane, qv);
+    for (int j0 = wave; j0 < nk; j0 += 16) {   // 4 keys of this wave per trip, loads issued together
+        float4 kv[4][CQ];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = j0 + 4 * u;
+            ldrow<CQ>(a.k + (size_t)(ks + (j < nk ? j : nk - 1)) * a.ldk, lane, kv[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = j0 + 4 * u;
+            const float s_ = row_allsum(dotq<CQ>(qv, kv[u]));
+            if (j < nk && (lane & 15) == 0) sc[hl][j] = s_ * a.scale;
+        }
+    }
+    __syncthreads();
+    {   // softmax over the keys: wave = head
+        const int h = wave;
+        float e1[NKP / 64];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int u = 0; u < NKP / 64; ++u) { const int j = lane + 64 * u; e1[u] = j < nk ? sc[h][j] : -INFINITY; mx = fmaxf(mx, e1[u]); }
+        mx = wave_max(mx);
+        float sm = 0.f;
+#pragma unroll
+        for (int u = 0; u < NKP / 64; ++u) { const int j = lane + 64 * u; e1[u] = j < nk ? expf(e1[u] - mx) : 0.f; sm += e1[u]; }
+        sm = wave_sum(sm);
+#pragma unroll
+        for (int u = 0; u < NKP / 64; ++u) { const int j = lane + 64 * u; if (j < nk) sc[h][j] = e1[u] / sm; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u2 = 0; u2 < CQ; ++u2) {
+        const int ch = tid + 256 * u2;
+        const int h = ch / (64 * CQ);
+        const float* vp = a.v + (size_t)ks * a.ldv + ch;
+        float acc = 0.f;
+        int j = 0;
+        for (; j + 8 <= nk; j += 8) {
+            float vv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) vv[u] = vp[(size_t)(j + u) * a.ldv];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc = fmaf(sc[h][j + u], vv[u], acc);
+        }
+        for (; j < nk; ++j) acc = fmaf(sc[h][j], vp[(size_t)j * a.ldv], acc);
+        a.out[(size_t)row * a.ldo + ch] = acc;
+    }
+}
+
 }  // namespace
 
 extern "C" int roitr_geo_indices(int rows, const float* pts, const int* offset, const int* cloud_of_row, const long* eoff,
@@ -547,6 +754,24 @@ extern "C" int roitr_mha(const RoitrMha* a, hipStream_t stream)
     static const hipError_t attr_ = hipFuncSetAttribute((const void*)mha_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     (void)attr_;
     roitr_prof_begin(ROITR_PROF_MHA, 0.0, stream);
+    {   // factor-2 width (C = 512) and / or E stored in bf16: the wide kernels
+        const bool lay = a->heads == 4 && a->ldq % 4 == 0 && a->ldk % 4 == 0 && a->nk_max <= 512 && getenv("ROITR_MHA_GENERIC") == nullptr;
+        if (a->E && !a->partner && lay && (a->C == 512 || (a->C == 256 && a->e_bf16))) {
+            const unsigned gr = (unsigned)xcd_grid(a->q_rows);
+            if (a->C == 512) { if (a->e_bf16) mha_geo_wide_kernel<2, true><<<gr, 256, 0, stream>>>(*a); else mha_geo_wide_kernel<2, false><<<gr, 256, 0, stream>>>(*a); }
+            else mha_geo_wide_kernel<1, true><<<gr, 256, 0, stream>>>(*a);
+            roitr_prof_end(ROITR_PROF_MHA, stream);
+            ROITR_LAUNCH_CHECK();
+            return ROITR_OK;
+        }
+        if (a->E && a->e_bf16) { roitr_prof_end(ROITR_PROF_MHA, stream); roitr_set_error("roitr_mha: bf16 E needs C = 256 or 512, 4 heads, <= 512 keys", __FILE__, __LINE__); return ROITR_ERR_UNSUPPORTED; }
+        if (!a->E && lay && a->C == 512) {
+            mha_plain_wide_kernel<512, 2><<<xcd_grid(a->q_rows), 256, 0, stream>>>(*a);
+            roitr_prof_end(ROITR_PROF_MHA, stream);
+            ROITR_LAUNCH_CHECK();
+            return ROITR_OK;
+        }
+    }
     // self attention over E at the model's width: the single-pass register-resident kernel (nk_max bounds every cloud)
     const bool geo_any = a->E && !a->partner && a->C == 256 && a->heads == 4 && a->ldq % 4 == 0 && a->ldk % 4 == 0 &&
                          getenv("ROITR_MHA_GENERIC") == nullptr;

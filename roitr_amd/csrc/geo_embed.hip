@@ -218,7 +218,7 @@ __device__ __forceinline__ lds_ptr_t to_lds(const void* p) { return (lds_ptr_t)(
 // fp32 accumulate) -- the bf16 operand mode of the engine (BASELINE config 4), W3 then is the (C, C) bf16 weight.
 // (A device-function template behind two plain kernels: hipcc 7.2 silently emits no host stub for this body as a __global__
 // template.)
-template <int NP>
+template <int NP, bool OH = false>
 __device__ __forceinline__ void geo_embed_split_body(long rows, int C, int angle_k, const float* __restrict__ d_idx,
                                                      const float* __restrict__ a_idx, const float* __restrict__ div_term,
                                                      const unsigned short* __restrict__ Wd3, const float* __restrict__ bd,
@@ -334,7 +334,14 @@ __device__ __forceinline__ void geo_embed_split_body(long rows, int C, int angle
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             const long row = m0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-            if (row < rows) out[(size_t)row * C + col] = (acc[i][e] + bdv) + (amax[i][e] + bav);
+            if (row < rows) {
+                const float val_ = (acc[i][e] + bdv) + (amax[i][e] + bav);
+                if (OH) {   // E stored bf16 (round to nearest even)
+                    f32x2 pr = {val_, 0.f};
+                    reinterpret_cast<unsigned short*>(out)[(size_t)row * C + col] =
+                        (unsigned short)(__builtin_bit_cast(unsigned, __builtin_convertvector(pr, bf16x2)) & 0xffffu);
+                } else out[(size_t)row * C + col] = val_;
+            }
         }
 }
 
@@ -345,6 +352,14 @@ __global__ __launch_bounds__(256) void geo_embed_split_kernel(long rows, int C, 
                                                               float* __restrict__ out)
 {
     geo_embed_split_body<3>(rows, C, angle_k, d_idx, a_idx, div_term, Wd3, bd, Wa3, ba, out);
+}
+__global__ __launch_bounds__(256) void geo_embed_bf16o_kernel(long rows, int C, int angle_k, const float* __restrict__ d_idx,
+                                                              const float* __restrict__ a_idx, const float* __restrict__ div_term,
+                                                              const unsigned short* __restrict__ Wd, const float* __restrict__ bd,
+                                                              const unsigned short* __restrict__ Wa, const float* __restrict__ ba,
+                                                              float* __restrict__ out)
+{
+    geo_embed_split_body<1, true>(rows, C, angle_k, d_idx, a_idx, div_term, Wd, bd, Wa, ba, out);
 }
 __global__ __launch_bounds__(256) void geo_embed_bf16_kernel(long rows, int C, int angle_k, const float* __restrict__ d_idx,
                                                              const float* __restrict__ a_idx, const float* __restrict__ div_term,
@@ -420,6 +435,22 @@ extern "C" int roitr_geo_embed_bf16(long rows, int C, int angle_k, const float* 
     if (mt > 0x7fffffffL) return ROITR_ERR_UNSUPPORTED;
     roitr_prof_begin(ROITR_PROF_GEO_EMBED, 2.0 * rows * (1.0 + angle_k) * (double)C * C, stream);
     geo_embed_bf16_kernel<<<dim3(C / 128, (unsigned)mt), 256, 0, stream>>>(rows, C, angle_k, d_idx, a_idx, div_term, Wd, bd, Wa, ba, out);
+    roitr_prof_end(ROITR_PROF_GEO_EMBED, stream);
+    ROITR_LAUNCH_CHECK();
+    return ROITR_OK;
+}
+
+extern "C" int roitr_geo_embed_bf16_out(long rows, int C, int angle_k, const float* d_idx, const float* a_idx, const float* div_term,
+                                        const unsigned short* Wd, const float* bd, const unsigned short* Wa, const float* ba,
+                                        unsigned short* out, hipStream_t stream)
+{
+    if (rows <= 0) return ROITR_OK;
+    if (C % 128 || C > 1024 || angle_k < 1) return ROITR_ERR_UNSUPPORTED;
+    const long mt = (rows + BM - 1) / BM;
+    if (mt > 0x7fffffffL) return ROITR_ERR_UNSUPPORTED;
+    roitr_prof_begin(ROITR_PROF_GEO_EMBED, 2.0 * rows * (1.0 + angle_k) * (double)C * C, stream);
+    geo_embed_bf16o_kernel<<<dim3(C / 128, (unsigned)mt), 256, 0, stream>>>(rows, C, angle_k, d_idx, a_idx, div_term, Wd, bd, Wa, ba,
+                                                                           reinterpret_cast<float*>(out));
     roitr_prof_end(ROITR_PROF_GEO_EMBED, stream);
     ROITR_LAUNCH_CHECK();
     return ROITR_OK;
