@@ -190,14 +190,15 @@ int gemm(hipStream_t st, int M, const float* A, const Lin& l, float* C, bool rel
 // nn.Linear followed by (+ residual) LayerNorm (+ post-add) (ReLU): one launch when the layer is 64 wide (the LayerNorm
 // runs in the GEMM epilogue, the (M, 64) intermediate never reaches HBM), the two-launch sequence otherwise.
 // `tmp` (M x l.out) is only touched by the two-launch form.
-// The fused form is bitwise the two-launch result, so the choice may depend on the row count without breaking batch invariance:
-// 256-wide rows fuse only for small M (64 x 256 tiles leave big batches with too few, too fat blocks: +1.0 ms per 128-pair
-// forward), where the saved launch is what counts (41 add_layernorm launches per forward at one pair per call).
+// The fused form is bitwise the two-launch result, so the choice could depend on the row count without breaking batch
+// invariance.  Measured and dropped (ROITR_LN_FUSE_SMALL_M): fusing the 256-wide rows for small M to save the 41 add_layernorm
+// launches of a one-pair forward -- 5.84 vs 5.23 ms per pair: a 64 x 256 tile puts four accumulators (4096 MFMA cycles per
+// K-slab) on the critical path of a handful of blocks, which costs more than the launch it saves.
 bool ln_fuses(int N, int K, int lda, int ldw, int M = 1 << 30)
 {
     static const bool fuse = getenv("ROITR_NO_LN_FUSE") == nullptr;
     static const int fuse_max = [] { const char* e = getenv("ROITR_LN_FUSE_MAX"); return e ? atoi(e) : 128; }();
-    static const int small_m = [] { const char* e = getenv("ROITR_LN_FUSE_SMALL_M"); return e ? atoi(e) : 8192; }();
+    static const int small_m = [] { const char* e = getenv("ROITR_LN_FUSE_SMALL_M"); return e ? atoi(e) : 0; }();
     const int lim = M <= small_m ? 256 : fuse_max;
     return fuse && (N == 64 || N == 128 || N == 256) && N <= lim && K % 32 == 0 && lda % 4 == 0 && ldw % 4 == 0;
 }
