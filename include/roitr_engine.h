@@ -250,8 +250,10 @@ typedef struct RoitrEngineConfig {
     float occlusion_radius;/* lib/utils.py:485 overlap_thres */
     int operand_dtype;     /* 0 = fp32 everywhere (the reference's arithmetic); 1 = bf16 operand storage for the dense layers
                               (BASELINE config 4): weights stored bf16 once at finalize, activations rounded to bf16 as MFMA
-                              operands, GEMM-to-GEMM intermediates stored bf16, fp32 accumulation / bias / LayerNorm / softmax;
-                              FPS, kNN, PPF, partition, coarse scores, optimal transport and fine matching stay fp32 */
+                              operands, GEMM-to-GEMM intermediates, the q|k|v tensors, the attention outputs and the geometric
+                              embedding E stored bf16, the patch score contraction (RIGA_v2.py:150) on a bf16 copy of the point
+                              descriptors; fp32 accumulation / bias / LayerNorm / softmax everywhere; FPS, kNN, PPF, partition,
+                              coarse scores, optimal transport and fine matching stay fp32 */
 } RoitrEngineConfig;
 
 typedef struct RoitrForwardIO {

@@ -632,6 +632,7 @@ extern "C" int roitr_engine_forward(void* h, const RoitrForwardIO* io, hipStream
     {
         size_t need = (size_t)T1 * 4 * (64 * f * 14 + 256 * f * 2 + 600) + (size_t)etot * (C4 * 4 + 64) /* E once + its index arrays */ + (size_t)T4 * C4 * 4 * 40 +
                       (size_t)B * P_ * (LIM * LIM * 3 + (LIM + 1) * (LIM + 1) + LIM * 16) * 4 + ((size_t)64 << 20);
+        if (E.cfg.operand_dtype == 1) need += (size_t)T1 * C4 * 2 + 1024;   // bf16 copy of the point descriptors (patch scores)
         for (int l = 0; l < 4; ++l) need += roitr_knn_workspace_bytes(NC, V.T[l], T1) + 1024;
         need += (size_t)B * (roitr_coarse_scratch_floats(V.nmax[3], V.nmax[3]) + (size_t)2 * V.nmax[3] * V.nmax[3]) * 4 + 1024;
         need += 2 * roitr_knn_workspace_bytes(B, T1 + NC, T1 + NC) + (size_t)(T1 + NC) * 16 + 4096;
@@ -1006,6 +1007,18 @@ extern "C" int roitr_engine_forward(void* h, const RoitrForwardIO* io, hipStream
         g.M = LIM; g.N = LIM; g.K = C4; g.A = point_feats; g.lda = C4; g.a_idx = trows; g.a_limit = T1; g.W = point_feats; g.ldw = C4;
         g.w_idx = srows; g.w_limit = T1; g.alpha = 1.0f / sqrtf((float)C4); g.C = mscore; g.ldc = LIM; g.batch = (int)NP;
         g.sC = (long)LIM * LIM; g.sAidx = LIM; g.sWidx = LIM;
+        if (E.cfg.operand_dtype == 1) {
+            // bf16 operand mode: both operands of this contraction are the point descriptors -- one bf16 copy of them, products on
+            // the bf16 matrix cores, fp32 accumulate; the scores (and the optimal transport behind them) stay fp32
+            unsigned short* pf_h = A.get<unsigned short>((size_t)T1 * C4);
+            if (A.fail) { roitr_set_error("arena exhausted (matching)", __FILE__, __LINE__); return ROITR_ERR_ARG; }
+            RoitrGemm gh = g;
+            gh.A = reinterpret_cast<const float*>(pf_h); gh.W = reinterpret_cast<const float*>(pf_h); gh.bf16 = ROITR_BF16_W | ROITR_BF16_A;
+            if (roitr_gemm_bf16_supported(&gh)) {
+                CHK(roitr_f32_to_bf16((long)T1 * C4, point_feats, pf_h, st));
+                g = gh;
+            }
+        }
         CHK(roitr_gemm(&g, st));
     }
     {
