@@ -1,19 +1,32 @@
 #!/bin/bash
 # Round profile collection on the GPU box (run through gpurun from the repo root):
-#   bash scripts/collect_profiles.sh r01
-# 1) bench.py JSON line, 2) rocprofv3 --kernel-trace --stats (csv), 3) two separate --pmc passes (FETCH_SIZE, WRITE_SIZE).
+#   bash scripts/collect_profiles.sh r02
+# 1) bench.py JSON lines (config 2 default, one pair per step, config 3, config 4 bf16 / f32),
+# 2) rocprofv3 --kernel-trace --stats (csv) of the default bench,
+# 3) two separate --pmc passes (FETCH_SIZE, WRITE_SIZE; kernel-trace only) of the default bench,
+# 4) the config-5 kNN micro-benchmark (scripts/knn_config5.sh: timing + SQ counters, own --pmc pass).
 set -u
-tag=${1:-r01}
+tag=${1:-r02}
 export TMPDIR=/tmp
 out=gpurun_out/$tag
 rm -rf $out; mkdir -p $out
 python bench.py > $out/bench.log 2>&1
 tail -1 $out/bench.log > $out/${tag}_bench.json
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o s -- python bench.py --no-cpu-baseline --no-single-pair --steps 4 --warmup 1 > $out/stats.log 2>&1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -o f -- python bench.py --no-cpu-baseline --no-single-pair --steps 1 --warmup 1 > $out/pmc_fetch.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -o w -- python bench.py --no-cpu-baseline --no-single-pair --steps 1 --warmup 1 > $out/pmc_write.log 2>&1
+python bench.py --pairs-per-step 1 --steps 200 --warmup 20 --no-cpu-baseline > $out/bench_b1.log 2>&1
+tail -1 $out/bench_b1.log > $out/${tag}_bench_pairs1.json
+python bench.py --config 3 --no-cpu-baseline --no-single-pair > $out/bench_c3.log 2>&1
+tail -1 $out/bench_c3.log > $out/${tag}_bench_config3.json
+python bench.py --config 4 --no-single-pair > $out/bench_c4.log 2>&1
+tail -1 $out/bench_c4.log > $out/${tag}_bench_config4_bf16.json
+python bench.py --config 4 --dtype f32 --no-cpu-baseline --no-single-pair > $out/bench_c4f.log 2>&1
+tail -1 $out/bench_c4f.log > $out/${tag}_bench_config4_f32.json
+P="python bench.py --no-cpu-baseline --no-single-pair --no-rccl-selftest --no-profile-pass"
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o s -- $P --steps 4 --warmup 1 > $out/stats.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -o f -- $P --steps 1 --warmup 1 > $out/pmc_fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -o w -- $P --steps 1 --warmup 1 > $out/pmc_write.log 2>&1
 python scripts/pmc_summary.py $out/pmc_fetch/f_counter_collection.csv $out/pmc_write/w_counter_collection.csv $out/${tag}_pmc_traffic.json 512
 python scripts/prof_summary.py $out/stats s 5 45 > $out/${tag}_kernel_summary.txt
 cp $out/stats/s_kernel_stats.csv $out/${tag}_kernel_stats.csv
 python scripts/hbm_table.py $out $tag > $out/${tag}_hbm_gbs.txt
-cat $out/${tag}_bench.json
+bash scripts/knn_config5.sh $out/knn5 > $out/${tag}_knn_config5.txt 2>&1
+for f in $out/${tag}_bench*.json; do echo $f; cut -c1-400 $f; done
