@@ -1141,53 +1141,21 @@ __global__ __launch_bounds__(64) void knn_lane_brute_kernel(int m, int nsample, 
 }
 
 // ---------------------------------------------------------------- exact replay of tied queries
-// knnquery_cuda_kernel.cu:65-108 restated for one wave.  64 distances are evaluated per step (8 steps of loads in flight)
-// and only those below the heap root are offered to the heap, in index order -- the heap sees exactly the reference's
-// insertion sequence.  A replayed query admits ~k ln(n / k) candidates one after the other; that serial chain is all its run
-// time, so the heap (nsample <= 100 entries) lives in REGISTERS -- entry p in lane p % 64 of register p / 64 -- and a
-// sift-down is: every node's larger child in parallel (four ds_bpermute), then a scalar walk down that path (v_readlane;
-// the value travelling down is always the new one, so the path does not depend on it), one lane-select per level.
-// First version: LDS heap driven by lane 0 between two barriers, ~2.3 us per admission (1.08 ms per launch on the k = 64,
-// n = 30000 case); a register heap that re-read both children and the parent on every level measured 1.46 ms.
-struct RegHeap {
-    float d0, d1; int i0, i1;
-    __device__ __forceinline__ float gd(int p) const { const float a = rl_f(d0, p & 63), b = rl_f(d1, p & 63); return p < 64 ? a : b; }
-    __device__ __forceinline__ int gi(int p) const { const int a = rl_i(i0, p & 63), b = rl_i(i1, p & 63); return p < 64 ? a : b; }
-    __device__ __forceinline__ void set(int p, float v, int vi, int lane)   // p wave-uniform
-    {
-        const bool me = lane == (p & 63);
-        if (p < 64) { d0 = me ? v : d0; i0 = me ? vi : i0; }
-        else { d1 = me ? v : d1; i1 = me ? vi : i1; }
-    }
-    // reheap (knnquery_cuda_kernel.cu:21-36) over the first k <= 128 entries: the value at the root sinks while it is <= its
-    // larger child (the right child only when strictly larger than the left one)
-    __device__ __forceinline__ void reheap(int k, int lane)
-    {
-        const int c1 = 2 * lane + 1, c2 = c1 + 1;            // children of node `lane` (nodes >= 64 have none at k <= 128)
-        const float a1 = __shfl(d0, c1 & 63, 64), b1 = __shfl(d1, c1 & 63, 64);
-        const float a2 = __shfl(d0, c2 & 63, 64), b2 = __shfl(d1, c2 & 63, 64);
-        const float v1 = c1 < 64 ? a1 : b1, v2 = c2 < 64 ? a2 : b2;
-        int lc = (c2 < k && v2 > v1) ? c2 : c1;
-        lc = c1 < k ? lc : -1;
-        const float x = rl_f(d0, 0);
-        const int xi = rl_i(i0, 0);
-        int p = 0;
-#pragma unroll 1
-        for (int lvl = 0; lvl < 7; ++lvl) {
-            const int c = p < 64 ? rl_i(lc, p & 63) : -1;
-            if (c < 0) break;
-            const float cd = gd(c);
-            if (x > cd) break;
-            set(p, cd, gi(c), lane);
-            p = c;
-        }
-        set(p, x, xi, lane);
-    }
-};
-
+// knnquery_cuda_kernel.cu:65-108 restated for one wave: the heap lives in LDS, every lane runs the
+// same (uniform) heap code; 64 distances are evaluated per step and only those below the root are
+// offered to the heap, in index order -- the heap sees exactly the reference's insertion sequence.
+// A replayed query admits ~k ln(n / k) candidates one after the other and that serial chain (~2 us per admission) is all
+// its run time: 0.5 ms at k = 64, n = 30000.  Measured and dropped: the heap in registers (entry p in lane p % 64, reads by
+// v_readlane, writes by lane compare + select: no LDS, no barrier), both as a straight restatement (1.46 vs 1.08 ms per launch
+// on that case) and with every node's larger child precomputed by four ds_bpermute and a scalar walk down that path (3.10 vs
+// 2.91 ms for the whole config-5 call, 0.49 vs 0.39 ms of replay per 32-pair 4DMatch forward): with ONE wave per CU nothing
+// hides the SGPR <-> VALU hand-offs of the readlane chain, which cost as much as the LDS round trips they replace; 8 batches of
+// candidate loads in flight (kept) change nothing.  One query per block (up to 1024 blocks) keeps the kernel at one chain.
 __global__ __launch_bounds__(64) void knn_replay_kernel(int nsample, const float* __restrict__ xyz, const float* __restrict__ new_xyz,
                                                         const int* __restrict__ offset, const int* __restrict__ new_offset, KnnOut o)
 {
+    __shared__ float hd[128];
+    __shared__ int hi[128];
     const int lane = threadIdx.x;
     const int count = *o.tie_count;
     for (int t = blockIdx.x; t < count; t += gridDim.x) {
@@ -1195,8 +1163,10 @@ __global__ __launch_bounds__(64) void knn_replay_kernel(int nsample, const float
         int start, end, seg;
         find_segment(q, offset, new_offset, start, end, seg);
         Query Q = {new_xyz[(size_t)q * 3], new_xyz[(size_t)q * 3 + 1], new_xyz[(size_t)q * 3 + 2]};
-        RegHeap H;
-        H.d0 = KNN_FILL; H.d1 = KNN_FILL; H.i0 = start; H.i1 = start;   // best_dist = 1e10, best_idx = start (l.86-91)
+        for (int p = lane; p < nsample; p += 64) { hd[p] = KNN_FILL; hi[p] = start; }
+        __syncthreads();
+        // the scan is one wave walking the whole cloud: NB batches of 64 distances are loaded together (the admission order
+        // below is still strictly the index order), otherwise every step is a dependent HBM / L2 round trip
         constexpr int NB = 8;
         for (int base0 = start; base0 < end; base0 += 64 * NB) {
             float cdv[NB];
@@ -1214,30 +1184,52 @@ __global__ __launch_bounds__(64) void knn_replay_kernel(int nsample, const float
                 const int base = base0 + 64 * u;
                 if (base >= end) break;   // wave-uniform
                 const float cd = cdv[u];
-                float root = rl_f(H.d0, 0);
+                float root = hd[0];
                 unsigned long long mk = __ballot(cd < root);
                 while (mk) {
                     const int l = __ffsll((long long)mk) - 1;
                     mk &= mk - 1;
                     const float nd = rl_f(cd, l);
-                    if (nd < root) {   // strict admission (l.97): the new point replaces the root, then reheap
-                        H.set(0, nd, base + l, lane);
-                        H.reheap(nsample, lane);
-                        root = rl_f(H.d0, 0);
+                    if (nd < root) {
+                        __syncthreads();
+                        if (lane == 0) {
+                            hd[0] = nd; hi[0] = base + l;
+                            int rt = 0, child = 1;  // reheap, l.21-36
+                            while (child < nsample) {
+                                if (child + 1 < nsample && hd[child + 1] > hd[child]) child++;
+                                if (hd[rt] > hd[child]) break;
+                                const float td = hd[rt]; hd[rt] = hd[child]; hd[child] = td;
+                                const int ti = hi[rt]; hi[rt] = hi[child]; hi[child] = ti;
+                                rt = child; child = rt * 2 + 1;
+                            }
+                        }
+                        __syncthreads();
+                        root = hd[0];
                     }
                 }
             }
         }
-        for (int i = nsample - 1; i > 0; i--) {   // heap_sort, l.39-48: swap root and entry i, reheap over the first i
-            const float td = rl_f(H.d0, 0), ld_ = H.gd(i);
-            const int ti = rl_i(H.i0, 0), li_ = H.gi(i);
-            H.set(0, ld_, li_, lane);
-            H.set(i, td, ti, lane);
-            H.reheap(i, lane);
+        __syncthreads();
+        if (lane == 0) {  // heap_sort, l.39-48
+            for (int i = nsample - 1; i > 0; i--) {
+                float td = hd[0]; hd[0] = hd[i]; hd[i] = td;
+                int ti = hi[0]; hi[0] = hi[i]; hi[i] = ti;
+                int rt = 0, child = 1;
+                while (child < i) {
+                    if (child + 1 < i && hd[child + 1] > hd[child]) child++;
+                    if (hd[rt] > hd[child]) break;
+                    td = hd[rt]; hd[rt] = hd[child]; hd[child] = td;
+                    ti = hi[rt]; hi[rt] = hi[child]; hi[child] = ti;
+                    rt = child; child = rt * 2 + 1;
+                }
+            }
         }
-        const float d[2] = {H.d0, H.d1};
-        const int i[2] = {H.i0, H.i1};
+        __syncthreads();
+        float d[2]; int i[2];
+        d[0] = lane < nsample ? hd[lane] : 0.f; i[0] = lane < nsample ? hi[lane] : 0;
+        d[1] = lane + 64 < nsample ? hd[lane + 64] : 0.f; i[1] = lane + 64 < nsample ? hi[lane + 64] : 0;
         write_rows<2>(o, q, nsample, d, i, lane, xyz, Q);
+        __syncthreads();
     }
 }
 
