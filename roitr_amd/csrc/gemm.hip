@@ -67,11 +67,7 @@ __device__ __attribute__((aligned(16))) float g_zero_row[ZERO_ROW_LEN];
 // LN: fused LayerNorm epilogue (RoitrGemm::ln_*), N == 64 TN: the finished tile is parked row-major in the staging LDS
 // and every wave normalises 16 full rows with exactly the arithmetic (and summation order) of add_layernorm_kernel<TN>,
 // so the result is bitwise that of the two-launch sequence while the (M, N) intermediate never touches HBM.
-// PD: prefetch distance in K-slabs (register sets in flight).  PD = 1 is the kernel of the batched forward (PD = 2 measured
-// no different there: the big launches are throughput-bound).  PD = 3 is launched for SMALL grids only (one-pair-per-call
-// mode: a 156-row GEMM is a handful of blocks whose run time is the serial K loop, one exposed HBM / MALL weight-load latency
-// per slab); same arithmetic in the same order, so the results are bitwise those of PD = 1.
-template <bool FAST, int TN, bool LN, int PD = 1>
+template <bool FAST, int TN, bool LN>
 __global__ __launch_bounds__(256) void gemm_kernel(RoitrGemm g, int nx, int ny, int T)
 {
     constexpr bool WIDE_STORE = GEMM_WIDE_STORE != 0;
@@ -140,7 +136,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(RoitrGemm g, int nx, int ny, 
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[v][i] = 0.f;
 
-    float av[PD][8], a2v[PD][8], wv[PD][TN][8];
+    float av[8], a2v[8], wv[TN][8];
     if (FAST) {
         if (!arow) arow = g_zero_row;
         if (!arow2) arow2 = g_zero_row;
@@ -153,26 +149,22 @@ __global__ __launch_bounds__(256) void gemm_kernel(RoitrGemm g, int nx, int ny, 
         const float4 x = *reinterpret_cast<const float4*>(p), y = *reinterpret_cast<const float4*>(p + (SPLIT16 ? 16 : 4));
         d[0] = x.x; d[1] = x.y; d[2] = x.z; d[3] = x.w; d[4] = y.x; d[5] = y.y; d[6] = y.z; d[7] = y.w;
     };
-    auto fetch = [&](int sl, int k) {   // sl: register set (compile-time after unrolling)
+    auto fetch = [&](int k) {
         if (FAST) {
-            ld8(arow + k, av[sl]);
+            ld8(arow + k, av);
 #pragma unroll
-            for (int v = 0; v < TN; ++v) ld8(wrow[v] + k, wv[sl][v]);
-            if (A2) ld8(arow2 + k, a2v[sl]);  // kernel-argument uniform
+            for (int v = 0; v < TN; ++v) ld8(wrow[v] + k, wv[v]);
+            if (A2) ld8(arow2 + k, a2v);  // kernel-argument uniform
         } else {
-            load8(arow, k, g.K, a_vec, av[sl]);
-            load8(arow2, k, g.K, a_vec, a2v[sl]);
+            load8(arow, k, g.K, a_vec, av);
+            load8(arow2, k, g.K, a_vec, a2v);
 #pragma unroll
-            for (int v = 0; v < TN; ++v) load8(wrow[v], k, g.K, w_vec, wv[sl][v]);
+            for (int v = 0; v < TN; ++v) load8(wrow[v], k, g.K, w_vec, wv[v]);
         }
     };
 #pragma unroll
-    for (int sl = 0; sl < PD; ++sl)
-#pragma unroll
-        for (int i = 0; i < 8; ++i) a2v[sl][i] = 0.f;
-#pragma unroll
-    for (int sl = 0; sl < PD; ++sl)
-        if (sl * BK < g.K) fetch(sl, sl * BK + kf);
+    for (int i = 0; i < 8; ++i) a2v[i] = 0.f;
+    fetch(kf);
     const int kh = lane >> 5, ml = lane & 31;
     const float4* ar = reinterpret_cast<const float4*>(As + (kh * BM + wm * 32 + ml) * LDR);
     const float4* br = reinterpret_cast<const float4*>(Bs + (kh * TBN + wn * 32 * TN + ml) * LDR);
@@ -180,24 +172,20 @@ __global__ __launch_bounds__(256) void gemm_kernel(RoitrGemm g, int nx, int ny, 
     float4* aw1 = reinterpret_cast<float4*>(As + (1 * BM + r) * LDR + (kq >> 1));
     float4* bw0 = reinterpret_cast<float4*>(Bs + (0 * TBN + r) * LDR + (kq >> 1));
     float4* bw1 = reinterpret_cast<float4*>(Bs + (1 * TBN + r) * LDR + (kq >> 1));
-    for (int kb = 0; kb < g.K; kb += PD * BK) {
-#pragma unroll
-      for (int sl = 0; sl < PD; ++sl) {
-        const int k0 = kb + sl * BK;
-        if (PD > 1 && k0 >= g.K) break;   // block-uniform
+    for (int k0 = 0; k0 < g.K; k0 += BK) {
         __syncthreads();
         if (!FAST || A2) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) av[sl][i] += a2v[sl][i];
+            for (int i = 0; i < 8; ++i) av[i] += a2v[i];
         }
-        *aw0 = make_float4(av[sl][0], av[sl][2], av[sl][4], av[sl][6]); *aw1 = make_float4(av[sl][1], av[sl][3], av[sl][5], av[sl][7]);
+        *aw0 = make_float4(av[0], av[2], av[4], av[6]); *aw1 = make_float4(av[1], av[3], av[5], av[7]);
 #pragma unroll
         for (int v = 0; v < TN; ++v) {
-            bw0[v * 64 * LDR / 4] = make_float4(wv[sl][v][0], wv[sl][v][2], wv[sl][v][4], wv[sl][v][6]);
-            bw1[v * 64 * LDR / 4] = make_float4(wv[sl][v][1], wv[sl][v][3], wv[sl][v][5], wv[sl][v][7]);
+            bw0[v * 64 * LDR / 4] = make_float4(wv[v][0], wv[v][2], wv[v][4], wv[v][6]);
+            bw1[v * 64 * LDR / 4] = make_float4(wv[v][1], wv[v][3], wv[v][5], wv[v][7]);
         }
         __syncthreads();
-        if (k0 + PD * BK < g.K) fetch(sl, k0 + PD * BK + kf);
+        if (k0 + BK < g.K) fetch(k0 + BK + kf);
         if (TN == 1) {
             float4 af[4], bf[4];
 #pragma unroll
@@ -226,7 +214,6 @@ __global__ __launch_bounds__(256) void gemm_kernel(RoitrGemm g, int nx, int ny, 
             }
         }
         if (FAST) __builtin_amdgcn_sched_barrier(0);  // consumers of the prefetched registers stay below the MFMAs
-      }
     }
     if (LN) {
         float* tile_ = smem;   // [RP][TBN + 1]
@@ -483,12 +470,11 @@ extern "C" int roitr_gemm(const RoitrGemm* g, hipStream_t stream)
     // variant that opens the next tile (row pointers + first slab in flight) before the store epilogue (18.3-19.8 vs
     // 16.9 ms): at K = 64..512 the hardware dispatcher overlapping 7 resident 64x64 blocks per CU beats all of them.
     // Prefetch distance 2 (two alternating register sets) changes nothing either (45.7 vs 45.1 ms per forward): the
-    // staging loads are not what the waves wait for.
+    // staging loads are not what the waves wait for.  Nor does distance 3 on the small grids of the one-pair-per-call mode
+    // (round 2: 4.68 vs 4.65 ms per pair, bitwise the same results): those launches are not waiting for weight loads either.
     // The kernel alone reaches 106 TFLOP/s at K = 2048 and 78 at K = 256 (scripts/bench_gemm.py); the no-memory MFMA
     // ceiling measured on this part is 143-157 TFLOP/s (scripts/micro/mfma_peak.hip).
     static const bool dma = getenv("ROITR_GEMM_DMA") != nullptr;
-    // grids of at most this many tiles take the prefetch-distance-3 kernel (latency-bound launches of the one-pair mode)
-    static const int deep_max = [] { const char* e = getenv("ROITR_GEMM_DEEP_MAX"); return e ? atoi(e) : 512; }();
     static const bool shapes = getenv("ROITR_GEMM_SHAPES") != nullptr;  // debug: per-shape timing table at exit (synchronous)
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (shapes) { hipEventCreate(&e0); hipEventCreate(&e1); hipEventRecord(e0, stream); }
@@ -500,7 +486,6 @@ extern "C" int roitr_gemm(const RoitrGemm* g, hipStream_t stream)
     } else if (fast && dma && !g->A2 && !g->seg_off) gemm_dma_kernel<0><<<grid, 256, 0, stream>>>(*g, nx, ny, T);
     else if (fast && tn == 2) gemm_kernel<true, 2, false><<<grid, 256, 0, stream>>>(*g, nx, ny, T);
     else if (fast && tn == 4) gemm_kernel<true, 4, false><<<grid, 256, 0, stream>>>(*g, nx, ny, T);
-    else if (fast && T <= deep_max && g->K >= 4 * BK) gemm_kernel<true, 1, false, 3><<<grid, 256, 0, stream>>>(*g, nx, ny, T);
     else if (fast) gemm_kernel<true, 1, false><<<grid, 256, 0, stream>>>(*g, nx, ny, T);
     else gemm_kernel<false, 1, false><<<grid, 256, 0, stream>>>(*g, nx, ny, T);
     if (shapes) {
