@@ -68,94 +68,112 @@ template <bool HALF> __device__ __forceinline__ float elem_ld(const float* base,
 __device__ __forceinline__ void lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
 // K = neighbours per node (8 / 16), HV = H / 64 (channels per lane); heads == 4.  HALF: q / k / v rows and the output row are
-// stored in bf16 (RoitrLocalAttn::bf16); all arithmetic stays fp32.
-template <int K, int HV, bool HALF>
+// stored in bf16 (RoitrLocalAttn::bf16); all arithmetic stays fp32.  NPW = nodes a wave works on at once: the kernel is bound
+// by the latency of its two dependent gather round trips (ids -> rows), not by bytes (level 1: 10 TB/s out of L2 at full
+// occupancy), so where the registers allow it (HV = 1) a wave keeps the loads of TWO nodes in flight; per node the arithmetic and
+// its order are unchanged.
+template <int K, int HV, bool HALF, int NPW>
 __global__ __launch_bounds__(256) void local_attn_kernel(RoitrLocalAttn a)
 {
-    __shared__ __attribute__((aligned(16))) float xch[4][80];   // per wave: probs [head][16] | pbar [head][4]
+    __shared__ __attribute__((aligned(16))) float xch[4][NPW][80];   // per wave and node: probs [head][16] | pbar [head][4]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // nodes are visited in the grid's cell order when one is given, and every XCD gets a contiguous eighth of that
     // order: the k/v rows a node gathers are then re-used out of its XCD's L2 by the spatially adjacent nodes
-    const int slot = xcd_block_id((a.M + 3) >> 2) * 4 + wave;
-    if (slot >= a.M) return;
-    int node = slot;
-    if (a.node_order) node = __float_as_int(reinterpret_cast<const float4*>(a.node_order)[slot].w);
-    node = __builtin_amdgcn_readfirstlane(node);
+    const int slot0 = (xcd_block_id((a.M + 4 * NPW - 1) / (4 * NPW)) * 4 + wave) * NPW;
+    if (slot0 >= a.M) return;
     constexpr int H = 64 * HV;
     const int h = lane >> 4, t = lane & 15;
-    float* probs = xch[wave];
-    float* pbar = xch[wave] + 64;
-
+    int node[NPW]; bool live[NPW];
+#pragma unroll
+    for (int n = 0; n < NPW; ++n) {
+        live[n] = slot0 + n < a.M;                       // wave-uniform
+        const int sl = live[n] ? slot0 + n : slot0;      // a dead slot recomputes node slot0 and stores nothing
+        int nd = sl;
+        if (a.node_order) nd = __float_as_int(reinterpret_cast<const float4*>(a.node_order)[sl].w);
+        node[n] = __builtin_amdgcn_readfirstlane(nd);
+    }
     // ---- round trip 1: everything addressed by the node id
-    const int g = a.group_idx[(size_t)node * K + (lane < K ? lane : 0)];
-    const size_t qoff = (size_t)node * a.ldq;
-    float qv[HV];
-    row_ld<HALF, HV>(a.q, qoff + lane * HV, qv);
-    float ec = t < 5 ? elem_ld<HALF>(a.q, qoff + H + h * 5 + t) : 0.f;   // qp[h][0..3] (PPF coefficients), qp[h][4] (q_h . bpe_h)
-    float pv[K];
-    const float* pf = a.ppf + (size_t)node * K * 4 + (t < 4 ? t : 0);
+    int g[NPW]; float qv[NPW][HV], ec[NPW], pv[NPW][K];
 #pragma unroll
-    for (int kk = 0; kk < K; ++kk) pv[kk] = pf[kk * 4];
-    // ---- round trip 2: key and value rows of the K neighbours, all in flight together
-    float kr[K][HV], vr[K][HV];
+    for (int n = 0; n < NPW; ++n) {
+        g[n] = a.group_idx[(size_t)node[n] * K + (lane < K ? lane : 0)];
+        const size_t qoff = (size_t)node[n] * a.ldq;
+        row_ld<HALF, HV>(a.q, qoff + lane * HV, qv[n]);
+        ec[n] = t < 5 ? elem_ld<HALF>(a.q, qoff + H + h * 5 + t) : 0.f;   // qp[h][0..3] (PPF coefficients), qp[h][4] (q_h . bpe_h)
+        const float* pf = a.ppf + (size_t)node[n] * K * 4 + (t < 4 ? t : 0);
 #pragma unroll
-    for (int kk = 0; kk < K; ++kk) {
-        const int gk = __builtin_amdgcn_readlane(g, kk);
-        row_ld<HALF, HV>(a.k, (size_t)gk * a.ldk + lane * HV, kr[kk]);
+        for (int kk = 0; kk < K; ++kk) pv[n][kk] = pf[kk * 4];
+    }
+    // ---- round trip 2: key and value rows of the K neighbours of every node, all in flight together
+    float kr[NPW][K][HV], vr[NPW][K][HV];
+#pragma unroll
+    for (int n = 0; n < NPW; ++n) {
+#pragma unroll
+        for (int kk = 0; kk < K; ++kk) {
+            const int gk = __builtin_amdgcn_readlane(g[n], kk);
+            row_ld<HALF, HV>(a.k, (size_t)gk * a.ldk + lane * HV, kr[n][kk]);
+        }
+#pragma unroll
+        for (int kk = 0; kk < K; ++kk) {
+            const int gk = __builtin_amdgcn_readlane(g[n], kk);
+            row_ld<HALF, HV>(a.v, (size_t)gk * a.ldv + lane * HV, vr[n][kk]);
+        }
     }
 #pragma unroll
-    for (int kk = 0; kk < K; ++kk) {
-        const int gk = __builtin_amdgcn_readlane(g, kk);
-        row_ld<HALF, HV>(a.v, (size_t)gk * a.ldv + lane * HV, vr[kk]);
-    }
+    for (int n = 0; n < NPW; ++n) {
+        float* probs = xch[wave][n];
+        float* pbar = xch[wave][n] + 64;
 #pragma unroll
-    for (int i = 0; i < HV; ++i) qv[i] *= a.scale;
-    ec *= a.scale;
+        for (int i = 0; i < HV; ++i) qv[n][i] *= a.scale;
+        ec[n] *= a.scale;
 #pragma unroll
-    for (int kk = 0; kk < K; ++kk) pv[kk] = t < 4 ? pv[kk] : (t == 4 ? 1.0f : 0.f);
+        for (int kk = 0; kk < K; ++kk) pv[n][kk] = t < 4 ? pv[n][kk] : (t == 4 ? 1.0f : 0.f);
 
-    // ---- scores: s(h, kk) = scale * (q_h . k_h[kk] + qp_h . [ppf_kk, 1]); lane t of row h keeps s(h, t)
-    float mine = 0.f, mx = -INFINITY;
+        // ---- scores: s(h, kk) = scale * (q_h . k_h[kk] + qp_h . [ppf_kk, 1]); lane t of row h keeps s(h, t)
+        float mine = 0.f, mx = -INFINITY;
 #pragma unroll
-    for (int kk = 0; kk < K; ++kk) {
-        float d = ec * pv[kk];
+        for (int kk = 0; kk < K; ++kk) {
+            float d = ec[n] * pv[n][kk];
 #pragma unroll
-        for (int i = 0; i < HV; ++i) d = fmaf(qv[i], kr[kk][i], d);
-        d = row_allsum(d);
-        mine = t == kk ? d : mine;
-        mx = fmaxf(mx, d);
-    }
-    const float e = t < K ? expf(mine - mx) : 0.f;   // accurate exp: the reference softmax is libm-exact
-    const float p = e / row_allsum(e);
-    probs[lane] = p;   // [h][t]
-    lds_fence();
-    float pk[K];
+            for (int i = 0; i < HV; ++i) d = fmaf(qv[n][i], kr[n][kk][i], d);
+            d = row_allsum(d);
+            mine = t == kk ? d : mine;
+            mx = fmaxf(mx, d);
+        }
+        const float e = t < K ? expf(mine - mx) : 0.f;   // accurate exp: the reference softmax is libm-exact
+        const float p = e / row_allsum(e);
+        probs[lane] = p;   // [h][t]
+        lds_fence();
+        float pk[K];
 #pragma unroll
-    for (int q4 = 0; q4 < K / 4; ++q4) {
-        const float4 v4 = reinterpret_cast<const float4*>(probs + h * 16)[q4];
-        pk[4 * q4] = v4.x; pk[4 * q4 + 1] = v4.y; pk[4 * q4 + 2] = v4.z; pk[4 * q4 + 3] = v4.w;
-    }
-    // pbar[h][j] = sum_k p(h,k) ppf[k][j]   (lanes t < 4 of every row)
-    float pb = 0.f;
+        for (int q4 = 0; q4 < K / 4; ++q4) {
+            const float4 v4 = reinterpret_cast<const float4*>(probs + h * 16)[q4];
+            pk[4 * q4] = v4.x; pk[4 * q4 + 1] = v4.y; pk[4 * q4 + 2] = v4.z; pk[4 * q4 + 3] = v4.w;
+        }
+        // pbar[h][j] = sum_k p(h,k) ppf[k][j]   (lanes t < 4 of every row)
+        float pb = 0.f;
 #pragma unroll
-    for (int kk = 0; kk < K; ++kk) pb = fmaf(pk[kk], pv[kk], pb);
-    if (t < 4) pbar[h * 4 + t] = pb;
-    lds_fence();
-    const float4 pb4 = reinterpret_cast<const float4*>(pbar)[h];
+        for (int kk = 0; kk < K; ++kk) pb = fmaf(pk[kk], pv[n][kk], pb);
+        if (t < 4) pbar[h * 4 + t] = pb;
+        lds_fence();
+        const float4 pb4 = reinterpret_cast<const float4*>(pbar)[h];
 
-    // ---- output: sum_k p v  +  Wvpe pbar + bvpe
-    float o[HV], bias[HV];
-    VecLoad<HV>::ld(a.bvpe + lane * HV, bias);
+        // ---- output: sum_k p v  +  Wvpe pbar + bvpe
+        float o[HV], bias[HV];
+        VecLoad<HV>::ld(a.bvpe + lane * HV, bias);
 #pragma unroll
-    for (int i = 0; i < HV; ++i) {
-        float acc = 0.f;
+        for (int i = 0; i < HV; ++i) {
+            float acc = 0.f;
 #pragma unroll
-        for (int kk = 0; kk < K; ++kk) acc = fmaf(pk[kk], vr[kk][i], acc);
-        const float4 w = reinterpret_cast<const float4*>(a.wvpe)[lane * HV + i];
-        o[i] = acc + (w.x * pb4.x + w.y * pb4.y + w.z * pb4.z + w.w * pb4.w + bias[i]);
+            for (int kk = 0; kk < K; ++kk) acc = fmaf(pk[kk], vr[n][kk][i], acc);
+            const float4 w = reinterpret_cast<const float4*>(a.wvpe)[lane * HV + i];
+            o[i] = acc + (w.x * pb4.x + w.y * pb4.y + w.z * pb4.z + w.w * pb4.w + bias[i]);
+        }
+        if (live[n]) {
+            if (HALF) VecLoadH<HV>::st(reinterpret_cast<unsigned short*>(a.out) + (size_t)node[n] * a.ldo + lane * HV, o);
+            else VecLoad<HV>::st(a.out + (size_t)node[n] * a.ldo + lane * HV, o);
+        }
     }
-    if (HALF) VecLoadH<HV>::st(reinterpret_cast<unsigned short*>(a.out) + (size_t)node * a.ldo + lane * HV, o);
-    else VecLoad<HV>::st(a.out + (size_t)node * a.ldo + lane * HV, o);
 }
 
 // Pfold (5*NH x H): row h*5+j holds Wpe[h*c + cc][j] (j<4) / bpe[h*c+cc] (j=4) at column h*c+cc, else 0.
@@ -188,10 +206,18 @@ extern "C" int roitr_local_attention(const RoitrLocalAttn* a, hipStream_t stream
         return ROITR_ERR_UNSUPPORTED;
     // algorithmic bytes: q row + K gathered k and v rows + ppf + idx in, one row out
     roitr_prof_begin(ROITR_PROF_LOCAL_ATTN, (double)a->M * ((a->H + 20.0) * 4 + a->K * (2.0 * a->H * 4 + 20.0) + a->H * 4.0), stream);
-#define LA_CASE(KK, HH)                                                                                       \
-    do {                                                                                                      \
-        if (half) local_attn_kernel<KK, HH, true><<<xcd_grid(div_up(a->M, 4)), 256, 0, stream>>>(*a);         \
-        else local_attn_kernel<KK, HH, false><<<xcd_grid(div_up(a->M, 4)), 256, 0, stream>>>(*a);             \
+    static const int npw_env = [] { const char* e = getenv("ROITR_LOCAL_ATTN_NPW"); return e ? atoi(e) : 0; }();   // 1 / 2: force
+#define LA_LAUNCH(KK, HH, NN)                                                                                             \
+    do {                                                                                                                  \
+        if (half) local_attn_kernel<KK, HH, true, NN><<<xcd_grid(div_up(a->M, 4 * NN)), 256, 0, stream>>>(*a);            \
+        else local_attn_kernel<KK, HH, false, NN><<<xcd_grid(div_up(a->M, 4 * NN)), 256, 0, stream>>>(*a);                \
+    } while (0)
+    // two nodes per wave where a lane holds one channel (HV = 1: 64-wide levels), one otherwise (register budget)
+#define LA_CASE(KK, HH)                                                                        \
+    do {                                                                                       \
+        if ((HH) == 1 && npw_env != 1) LA_LAUNCH(KK, 1, 2);                                     \
+        else if ((HH) == 2 && npw_env == 2) LA_LAUNCH(KK, 2, 2);                                \
+        else LA_LAUNCH(KK, HH, 1);                                                             \
     } while (0)
     if (a->K == 8) { if (hv == 1) LA_CASE(8, 1); else if (hv == 2) LA_CASE(8, 2); else if (hv == 4) LA_CASE(8, 4); else LA_CASE(8, 8); }
     else { if (hv == 1) LA_CASE(16, 1); else if (hv == 2) LA_CASE(16, 2); else if (hv == 4) LA_CASE(16, 4); else LA_CASE(16, 8); }
