@@ -52,6 +52,9 @@ struct LocalT {  // LocalPPFTransformer (+ derived weights)
     float* wqkv = nullptr;  // rows: [Wq (H) ; Wqp (5*HEADS) ; Wk (H) ; Wv (H)] x H
     unsigned short* wqkv_b = nullptr;   // the same, stored bf16 (operand_dtype = 1)
     float* bqkv = nullptr;
+    // TransitionDown transformers (in_dim != H): [q|qp|k|v] straight from the layer input, W' = Wqkv Win (R x in_dim),
+    // b' = Wqkv b_in + bqkv -- in_proj and the q/k/v projections are two linear maps with nothing in between
+    float* wqkv_x = nullptr; float* bqkv_x = nullptr; unsigned short* wqkv_x_b = nullptr;
     float* wvpe = nullptr;  // (H,4)
     float* bvpe = nullptr;  // (H)
     const float* bn2_w = nullptr; const float* bn2_b = nullptr;  // block only
@@ -296,6 +299,22 @@ int fold_local(Engine& E, LocalT& L, hipStream_t st)
         if (A.fail) return ROITR_ERR_ARG;
         CHK(roitr_f32_to_bf16((long)R * H, L.wqkv, L.wqkv_b, st));
     }
+    static const bool fold_in = getenv("ROITR_NO_INPROJ_FOLD") == nullptr;
+    if (fold_in && L.in_dim != H && L.in_dim % 32 == 0) {
+        const int I = L.in_dim;
+        float* winT = A.get<float>((size_t)I * H);
+        L.wqkv_x = A.get<float>((size_t)R * I);
+        L.bqkv_x = A.get<float>(R);
+        if (A.fail) return ROITR_ERR_ARG;
+        CHK(roitr_transpose(H, I, L.in_proj.w, I, winT, H, st));                       // (in, H)
+        CHK(gemm(st, R, I, H, L.wqkv, H, winT, H, nullptr, L.wqkv_x, I));               // (R, in) = Wqkv Win
+        CHK(gemm(st, 1, R, H, L.in_proj.b, H, L.wqkv, H, L.bqkv, L.bqkv_x, R));         // Wqkv b_in + bqkv
+        if (E.cfg.operand_dtype == 1) {
+            L.wqkv_x_b = A.get<unsigned short>((size_t)R * I);
+            if (A.fail) return ROITR_ERR_ARG;
+            CHK(roitr_f32_to_bf16((long)R * I, L.wqkv_x, L.wqkv_x_b, st));
+        }
+    }
     return 0;
 }
 
@@ -329,11 +348,15 @@ int local_transformer(Engine& E, hipStream_t st, const LocalT& L, int N_in, cons
     Arena& A = E.arena;
     const size_t mark = A.off;
     const int H = L.H, NQ = 5 * HEADS;
-    float* f = A.get<float>((size_t)N_in * H);
-    CHK(gemm(st, N_in, x, L.in_proj, f));
+    // TransitionDown with folded projections: q / k / v come straight from x, and f = in_proj(x) is only needed as the
+    // LayerNorm residual of the M sampled rows
+    const bool folded = node_idx != nullptr && L.wqkv_x != nullptr;
+    float* f = A.get<float>((size_t)(folded ? M : N_in) * H);
+    if (folded) CHK(gemm(st, M, x, L.in_proj, f, false, node_idx));
+    else CHK(gemm(st, N_in, x, L.in_proj, f));
     // bf16 operand mode: the q | k | v tensor (operands of the attention products) and the attention output (operand of
     // `linear`) are stored bf16 by their producers -- half the bytes of the gather-bound attention kernel
-    const bool hb = bf16_layer(L.wqkv_b, H) && bf16_layer(L.lin.wb, H);
+    const bool hb = (folded ? bf16_layer(L.wqkv_x_b, L.in_dim) : bf16_layer(L.wqkv_b, H)) && bf16_layer(L.lin.wb, H);
     const int cq = hb ? ROITR_BF16_C : 0;
     const size_t esz = hb ? 2 : 4;
     const float *q, *k, *v; int ldq, ldkv;
@@ -348,9 +371,16 @@ int local_transformer(Engine& E, hipStream_t st, const LocalT& L, int N_in, cons
         float* qe = A.get<float>((size_t)M * (H + NQ));
         float* kv = A.get<float>((size_t)N_in * 2 * H);
         if (A.fail) return ROITR_ERR_ARG;
-        CHK(gemm(st, M, H + NQ, H, f, H, L.wqkv, H, L.bqkv, qe, H + NQ, false, node_idx, nullptr, 1.0f, L.wqkv_b, cq));
-        CHK(gemm(st, N_in, 2 * H, H, f, H, L.wqkv + (size_t)(H + NQ) * H, H, L.bqkv + H + NQ, kv, 2 * H, false, nullptr, nullptr, 1.0f,
-                 L.wqkv_b ? L.wqkv_b + (size_t)(H + NQ) * H : nullptr, cq));
+        if (folded) {
+            const int I = L.in_dim;
+            CHK(gemm(st, M, H + NQ, I, x, I, L.wqkv_x, I, L.bqkv_x, qe, H + NQ, false, node_idx, nullptr, 1.0f, L.wqkv_x_b, cq));
+            CHK(gemm(st, N_in, 2 * H, I, x, I, L.wqkv_x + (size_t)(H + NQ) * I, I, L.bqkv_x + H + NQ, kv, 2 * H, false, nullptr, nullptr, 1.0f,
+                     L.wqkv_x_b ? L.wqkv_x_b + (size_t)(H + NQ) * I : nullptr, cq));
+        } else {
+            CHK(gemm(st, M, H + NQ, H, f, H, L.wqkv, H, L.bqkv, qe, H + NQ, false, node_idx, nullptr, 1.0f, L.wqkv_b, cq));
+            CHK(gemm(st, N_in, 2 * H, H, f, H, L.wqkv + (size_t)(H + NQ) * H, H, L.bqkv + H + NQ, kv, 2 * H, false, nullptr, nullptr, 1.0f,
+                     L.wqkv_b ? L.wqkv_b + (size_t)(H + NQ) * H : nullptr, cq));
+        }
         q = qe; k = kv; v = (const float*)((const char*)kv + (size_t)H * esz); ldq = H + NQ; ldkv = 2 * H;
     }
     float* att = A.get<float>((size_t)M * H);
@@ -365,7 +395,8 @@ int local_transformer(Engine& E, hipStream_t st, const LocalT& L, int N_in, cons
     CHK(roitr_local_attention(&a, st));
     // bf16 operand mode: `y` only feeds out_proj -> the LayerNorm epilogue stores it in bf16 (half the round trip)
     const bool y_h = ln_fuses(H, H, H, H) && bf16_layer(L.lin.wb, H) && bf16_layer(L.out_proj.wb, H);   // independent of M: batch-invariant storage
-    CHK(gemm_ln(st, M, att, L.lin, f, node_idx, L.norm_w, L.norm_b, nullptr, false, hid, y, (y_h ? ROITR_BF16_C : 0) | (hb ? ROITR_BF16_A : 0)));
+    CHK(gemm_ln(st, M, att, L.lin, f, folded ? nullptr : node_idx, L.norm_w, L.norm_b, nullptr, false, hid, y,
+                (y_h ? ROITR_BF16_C : 0) | (hb ? ROITR_BF16_A : 0)));
     if (bn2_res) {
         float* t = A.get<float>((size_t)M * L.out_dim);
         if (A.fail) return ROITR_ERR_ARG;
