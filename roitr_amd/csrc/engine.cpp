@@ -300,7 +300,7 @@ int fold_local(Engine& E, LocalT& L, hipStream_t st)
         CHK(roitr_f32_to_bf16((long)R * H, L.wqkv, L.wqkv_b, st));
     }
     static const bool fold_in = getenv("ROITR_NO_INPROJ_FOLD") == nullptr;
-    if (fold_in && L.in_dim != H && (L.in_dim % 32 == 0 || L.in_dim == 1)) {
+    if (fold_in && L.in_dim != H && L.in_dim % 32 == 0) {
         const int I = L.in_dim;
         float* winT = A.get<float>((size_t)I * H);
         L.wqkv_x = A.get<float>((size_t)R * I);
@@ -366,9 +366,6 @@ int local_transformer(Engine& E, hipStream_t st, const LocalT& L, int N_in, cons
         const int R = 3 * H + NQ;
         float* qkv = A.get<float>((size_t)N_in * R);
         if (A.fail) return ROITR_ERR_ARG;
-        if (L.wqkv_x && !hb)   // first transformer of the network: one input feature -> q | k | v are an outer product of it
-            CHK(gemm(st, N_in, R, L.in_dim, x, L.in_dim, L.wqkv_x, L.in_dim, L.bqkv_x, qkv, R));
-        else
         CHK(gemm(st, N_in, R, H, f, H, L.wqkv, H, L.bqkv, qkv, R, false, nullptr, nullptr, 1.0f, L.wqkv_b, cq));
         const char* b0 = (const char*)qkv;
         q = qkv; k = (const float*)(b0 + (size_t)(H + NQ) * esz); v = (const float*)(b0 + (size_t)(2 * H + NQ) * esz); ldq = R; ldkv = R;

@@ -421,35 +421,6 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(RoitrGemm g, int nx, int 
     }
 }
 
-// K == 1 (the first in_proj of the network, model/model.py:150: one input feature per point, and the projections folded
-// onto it): C[r, n] = act(alpha * (A[r] * W[n]) + bias[n]) is an outer product -- pure store bandwidth, no tiles.  The
-// arithmetic (one rounded product, then alpha, then the bias add) is exactly what the generic kernel does for K = 1.
-__global__ __launch_bounds__(256) void gemm_k1_kernel(RoitrGemm g)
-{
-    const int n4 = (g.N + 3) >> 2;
-    const long total = (long)g.M * n4;
-    for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long)gridDim.x * 256) {
-        const int r = (int)(t / n4), c0 = (int)(t - (long)r * n4) * 4;
-        const float a = g.A[(size_t)r * g.lda];
-        float o[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int c = c0 + i;
-            float x = 0.f;
-            if (c < g.N) {
-                x = __fadd_rn(__fmul_rn(__fmul_rn(a, g.W[(size_t)c * g.ldw]), g.alpha), g.bias ? g.bias[c] : 0.f);
-                if (g.relu) x = fmaxf(x, 0.f);
-            }
-            o[i] = x;
-        }
-        float* dst = g.C + (size_t)r * g.ldc + c0;
-        if (c0 + 4 <= g.N && (g.ldc & 3) == 0 && (((uintptr_t)g.C) & 15) == 0) *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
-        else
-#pragma unroll
-            for (int i = 0; i < 4; ++i) if (c0 + i < g.N) dst[i] = o[i];
-    }
-}
-
 }  // namespace
 
 namespace {
@@ -478,14 +449,6 @@ extern "C" int roitr_gemm(const RoitrGemm* g, hipStream_t stream)
     if (g->M <= 0 || g->N <= 0 || g->batch <= 0) return ROITR_OK;
     if (g->K <= 0 || !g->A || !g->W || !g->C) return ROITR_ERR_ARG;
     if (g->bf16) return roitr_gemm_bf16_launch(g, stream);
-    if (g->K == 1 && g->batch == 1 && !g->a_idx && !g->w_idx && !g->A2 && !g->seg_off && !g->ln_gamma) {
-        roitr_prof_begin(ROITR_PROF_GEMM, 2.0 * g->M * g->N, stream);
-        const long blocks = ((long)g->M * ((g->N + 3) / 4) + 255) / 256;
-        gemm_k1_kernel<<<(unsigned)(blocks > 65536 ? 65536 : blocks), 256, 0, stream>>>(*g);
-        roitr_prof_end(ROITR_PROF_GEMM, stream);
-        ROITR_LAUNCH_CHECK();
-        return ROITR_OK;
-    }
     auto al16 = [](const void* p, long stride_floats) { return ((uintptr_t)p & 15) == 0 && (stride_floats % 4) == 0; };
     const bool fast = g->K % BK == 0 && g->K <= ZERO_ROW_LEN && g->lda % 4 == 0 && g->ldw % 4 == 0 && al16(g->A, g->sA) && al16(g->W, g->sW) &&
                       (!g->A2 || al16(g->A2, g->sA));
