@@ -45,6 +45,10 @@ typedef struct RoitrGemm {
      * written bf16 (uint16, ldc / sC in elements) with ROITR_BF16_C.  bias / ln_* stay fp32.  Needs K % 64 == 0 and
      * 16-byte aligned rows (roitr_gemm_bf16_supported). */
     int bf16;
+    /* optional K-concatenated A operand (fp32 kernel only): columns k >= k_cat of the product come from A_cat (same row
+     * index / gather as A, leading dimension lda_cat), i.e. C = [A | A_cat] @ W^T with W (N, K), K = k_cat + width(A_cat);
+     * k_cat % 32 == 0.  Lets `linear(att) + in_proj(x)` of a local transformer run as ONE GEMM. */
+    const float* A_cat; int lda_cat; int k_cat;
 } RoitrGemm;
 #define ROITR_BF16_W 1
 #define ROITR_BF16_A 2
@@ -62,6 +66,8 @@ int roitr_add_layernorm(int M, int C, const float* x, const float* res, const in
 /* F.normalize(p=2, dim=1), model/RIGA_v2.py:64-65 */
 int roitr_l2_normalize(int M, int C, const float* x, float* out, roitr_stream_t stream);
 int roitr_transpose(int rows, int cols, const float* in, int ld_in, float* out, int ld_out, roitr_stream_t stream);
+/* out = a + b over n floats (bias of a folded layer) */
+int roitr_add_vectors(int n, const float* a, const float* b, float* out, roitr_stream_t stream);
 /* out = base + 3-NN inverse-distance interpolation of feat (functions/pointops.py:168-182 + model/model.py:116);
  * dist2 = SQUARED distances as produced by the kNN call. */
 int roitr_interp3_add(int n, int C, const float* feat, const int* idx, const float* dist2, const float* base, float* out,

@@ -55,6 +55,9 @@ struct LocalT {  // LocalPPFTransformer (+ derived weights)
     // TransitionDown transformers (in_dim != H): [q|qp|k|v] straight from the layer input, W' = Wqkv Win (R x in_dim),
     // b' = Wqkv b_in + bqkv -- in_proj and the q/k/v projections are two linear maps with nothing in between
     float* wqkv_x = nullptr; float* bqkv_x = nullptr; unsigned short* wqkv_x_b = nullptr;
+    // block transformers in fp32: linear(att) + in_proj(x) as ONE GEMM over the K-concatenated operand [att | x]:
+    // wcat = [Wlin | Win] (H x (H + in_dim)), bcat = b_lin + b_in; f = in_proj(x) is then never materialised
+    float* wcat = nullptr; float* bcat = nullptr;
     float* wvpe = nullptr;  // (H,4)
     float* bvpe = nullptr;  // (H)
     const float* bn2_w = nullptr; const float* bn2_b = nullptr;  // block only
@@ -206,13 +209,16 @@ bool ln_fuses(int N, int K, int lda, int ldw, int M = 1 << 30)
     return fuse && (N == 64 || N == 128 || N == 256) && N <= lim && K % 32 == 0 && lda % 4 == 0 && ldw % 4 == 0;
 }
 // bf: ROITR_BF16_A (A stored bf16; lda in elements) and / or ROITR_BF16_C (out stored bf16: fused form only)
+// A_cat (optional): the second K-half of the operand, [A | A_cat] with A (M, k_cat) dense and A_cat (M, l.in - k_cat) of leading
+// dimension lda_cat (fp32 kernels only)
 int gemm_ln(hipStream_t st, int M, const float* A, const Lin& l, const float* res, const int* res_idx, const float* gamma,
-            const float* beta, const float* post, bool relu, float* tmp, float* out, int bf = 0)
+            const float* beta, const float* post, bool relu, float* tmp, float* out, int bf = 0, const float* A_cat = nullptr,
+            int lda_cat = 0, int k_cat = 0)
 {
     const float* w = l.w;
     const float* b = l.b;
     const int K = l.in, N = l.out;
-    const int lda = K, ldw = K;
+    const int lda = A_cat ? k_cat : K, ldw = K;
     // measured per 128-pair forward: fusing the 64-wide layers -1.55 ms, + the 128-wide ones -0.4 ms, + the 256-wide ones
     // +1.0 ms (64 x 256 tiles leave the coarse levels with too few, too fat blocks) -> default limit 128
     if (ln_fuses(N, K, lda, ldw, M)) {
@@ -220,10 +226,18 @@ int gemm_ln(hipStream_t st, int M, const float* A, const Lin& l, const float* re
         memset(&g, 0, sizeof(g));
         g.M = M; g.N = N; g.K = K; g.A = A; g.lda = lda; g.W = w; g.ldw = ldw; g.bias = b; g.alpha = 1.0f; g.C = out; g.ldc = N; g.batch = 1;
         g.ln_gamma = gamma; g.ln_beta = beta; g.ln_res = res; g.ln_res_idx = res_idx; g.ln_post = post; g.ln_relu = relu ? 1 : 0; g.ln_eps = 1e-5f;
+        g.A_cat = A_cat; g.lda_cat = lda_cat; g.k_cat = k_cat;
         CHK(use_bf16(g, w, l.wb, bf));
         return roitr_gemm(&g, st);
     }
     if (bf & ROITR_BF16_C) { roitr_set_error("engine: bf16 LayerNorm output needs the fused epilogue", __FILE__, __LINE__); return ROITR_ERR_ARG; }
+    if (A_cat) {
+        RoitrGemm g;
+        memset(&g, 0, sizeof(g));
+        g.M = M; g.N = N; g.K = K; g.A = A; g.lda = lda; g.W = w; g.ldw = ldw; g.bias = b; g.alpha = 1.0f; g.C = tmp; g.ldc = N; g.batch = 1;
+        g.A_cat = A_cat; g.lda_cat = lda_cat; g.k_cat = k_cat;
+        CHK(roitr_gemm(&g, st));
+    } else
     CHK(gemm(st, M, N, K, A, lda, w, ldw, b, tmp, N, false, nullptr, nullptr, 1.0f, l.wb, bf));
     return roitr_add_layernorm(M, N, tmp, res, res_idx, gamma, beta, post, relu ? 1 : 0, 1e-5f, out, st);
 }
@@ -300,7 +314,18 @@ int fold_local(Engine& E, LocalT& L, hipStream_t st)
         CHK(roitr_f32_to_bf16((long)R * H, L.wqkv, L.wqkv_b, st));
     }
     static const bool fold_in = getenv("ROITR_NO_INPROJ_FOLD") == nullptr;
-    if (fold_in && L.in_dim != H && L.in_dim % 32 == 0) {
+    static const bool fold_cat = getenv("ROITR_NO_CAT_FOLD") == nullptr;
+    const bool cat = fold_cat && E.cfg.operand_dtype == 0 && L.in_dim % 32 == 0;
+    if (cat) {
+        const int I = L.in_dim;
+        L.wcat = A.get<float>((size_t)H * (H + I));
+        L.bcat = A.get<float>(H);
+        if (A.fail) return ROITR_ERR_ARG;
+        ROITR_HIP(hipMemcpy2DAsync(L.wcat, sizeof(float) * (H + I), L.lin.w, sizeof(float) * H, sizeof(float) * H, H, hipMemcpyDeviceToDevice, st));
+        ROITR_HIP(hipMemcpy2DAsync(L.wcat + H, sizeof(float) * (H + I), L.in_proj.w, sizeof(float) * I, sizeof(float) * I, H, hipMemcpyDeviceToDevice, st));
+        CHK(roitr_add_vectors(H, L.lin.b, L.in_proj.b, L.bcat, st));
+    }
+    if (fold_in && (L.in_dim != H || cat) && L.in_dim % 32 == 0) {
         const int I = L.in_dim;
         float* winT = A.get<float>((size_t)I * H);
         L.wqkv_x = A.get<float>((size_t)R * I);
@@ -353,8 +378,12 @@ int local_transformer(Engine& E, hipStream_t st, const LocalT& L, int N_in, cons
     // (measured and dropped: the same fold for the first transformer of the network, K = 1 -- an outer-product kernel writing
     //  the (T, 212) q|k|v rows is no faster than the K = 64 MFMA GEMM it replaces: 59.9 vs 59.2 ms of GEMM per 512-pair step)
     const bool folded = node_idx != nullptr && L.wqkv_x != nullptr;
-    float* f = A.get<float>((size_t)(folded ? M : N_in) * H);
-    if (folded) CHK(gemm(st, M, x, L.in_proj, f, false, node_idx));
+    // block transformer in fp32 with folded projections: f = in_proj(x) is never formed -- q|k|v come from x, and the residual
+    // of the LayerNorm rides in the `linear` GEMM as the second K-half of [att | x]
+    const bool catf = node_idx == nullptr && L.wcat != nullptr && L.wqkv_x != nullptr;
+    float* f = catf ? nullptr : A.get<float>((size_t)(folded ? M : N_in) * H);
+    if (catf) {}
+    else if (folded) CHK(gemm(st, M, x, L.in_proj, f, false, node_idx));
     else CHK(gemm(st, N_in, x, L.in_proj, f));
     // bf16 operand mode: the q | k | v tensor (operands of the attention products) and the attention output (operand of
     // `linear`) are stored bf16 by their producers -- half the bytes of the gather-bound attention kernel
@@ -366,6 +395,8 @@ int local_transformer(Engine& E, hipStream_t st, const LocalT& L, int N_in, cons
         const int R = 3 * H + NQ;
         float* qkv = A.get<float>((size_t)N_in * R);
         if (A.fail) return ROITR_ERR_ARG;
+        if (catf) CHK(gemm(st, N_in, R, L.in_dim, x, L.in_dim, L.wqkv_x, L.in_dim, L.bqkv_x, qkv, R));
+        else
         CHK(gemm(st, N_in, R, H, f, H, L.wqkv, H, L.bqkv, qkv, R, false, nullptr, nullptr, 1.0f, L.wqkv_b, cq));
         const char* b0 = (const char*)qkv;
         q = qkv; k = (const float*)(b0 + (size_t)(H + NQ) * esz); v = (const float*)(b0 + (size_t)(2 * H + NQ) * esz); ldq = R; ldkv = R;
@@ -397,6 +428,10 @@ int local_transformer(Engine& E, hipStream_t st, const LocalT& L, int N_in, cons
     CHK(roitr_local_attention(&a, st));
     // bf16 operand mode: `y` only feeds out_proj -> the LayerNorm epilogue stores it in bf16 (half the round trip)
     const bool y_h = ln_fuses(H, H, H, H) && bf16_layer(L.lin.wb, H) && bf16_layer(L.out_proj.wb, H);   // independent of M: batch-invariant storage
+    if (catf) {
+        Lin lc; lc.w = L.wcat; lc.b = L.bcat; lc.out = H; lc.in = H + L.in_dim;
+        CHK(gemm_ln(st, M, att, lc, nullptr, nullptr, L.norm_w, L.norm_b, nullptr, false, hid, y, 0, x, L.in_dim, H));
+    } else
     CHK(gemm_ln(st, M, att, L.lin, f, folded ? nullptr : node_idx, L.norm_w, L.norm_b, nullptr, false, hid, y,
                 (y_h ? ROITR_BF16_C : 0) | (hb ? ROITR_BF16_A : 0)));
     if (bn2_res) {

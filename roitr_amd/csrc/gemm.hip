@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(RoitrGemm g, int nx, int ny, 
         if (m0 >= g.M || n0 >= g.N) return;  // block-uniform
     }
 
-    const float* arow = nullptr; const float* arow2 = nullptr; const float* wrow[TN];
+    const float* arow = nullptr; const float* arow2 = nullptr; const float* arowc = nullptr; const float* wrow[TN];
     {
         const int am = m0 + r;
         if (am < g.M) {
@@ -115,6 +115,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(RoitrGemm g, int nx, int ny, 
             if (src >= 0 && (g.a_limit <= 0 || src < g.a_limit)) {
                 arow = A + (size_t)src * g.lda;
                 if (A2) arow2 = A2 + (size_t)src * g.lda;
+                if (FAST && g.A_cat) arowc = g.A_cat + (size_t)src * g.lda_cat;   // column k >= k_cat of the product = A_cat[k - k_cat]
             }
         }
 #pragma unroll
@@ -140,6 +141,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(RoitrGemm g, int nx, int ny, 
     if (FAST) {
         if (!arow) arow = g_zero_row;
         if (!arow2) arow2 = g_zero_row;
+        if (g.A_cat && !arowc) arowc = g_zero_row;
 #pragma unroll
         for (int v = 0; v < TN; ++v) if (!wrow[v]) wrow[v] = g_zero_row;
     }
@@ -151,7 +153,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(RoitrGemm g, int nx, int ny, 
     };
     auto fetch = [&](int k) {
         if (FAST) {
-            ld8(arow + k, av);
+            ld8((g.A_cat && k >= g.k_cat) ? arowc + (k - g.k_cat) : arow + k, av);   // slab-uniform: k_cat % 32 == 0
 #pragma unroll
             for (int v = 0; v < TN; ++v) ld8(wrow[v] + k, wv[v]);
             if (A2) ld8(arow2 + k, a2v);  // kernel-argument uniform
@@ -452,6 +454,11 @@ extern "C" int roitr_gemm(const RoitrGemm* g, hipStream_t stream)
     auto al16 = [](const void* p, long stride_floats) { return ((uintptr_t)p & 15) == 0 && (stride_floats % 4) == 0; };
     const bool fast = g->K % BK == 0 && g->K <= ZERO_ROW_LEN && g->lda % 4 == 0 && g->ldw % 4 == 0 && al16(g->A, g->sA) && al16(g->W, g->sW) &&
                       (!g->A2 || al16(g->A2, g->sA));
+    if (g->A_cat && (!fast || g->A2 || g->batch != 1 || g->seg_off || g->k_cat % BK || g->k_cat <= 0 || g->k_cat >= g->K || g->lda_cat % 4 ||
+                     ((uintptr_t)g->A_cat & 15))) {
+        roitr_set_error("roitr_gemm: K-concatenated A needs the fast path (K % 32, 16-byte rows), k_cat % 32 == 0, no addend / batching", __FILE__, __LINE__);
+        return ROITR_ERR_UNSUPPORTED;
+    }
     static const int tn_env = [] { const char* e = getenv("ROITR_GEMM_TN"); return e ? atoi(e) : 0; }();
     static const long tn_min_blocks = [] { const char* e = getenv("ROITR_GEMM_TN_MIN_BLOCKS"); return e ? atol(e) : 0L; }();
     int tn = g->ln_gamma ? g->N / BN : 1;   // LayerNorm epilogue: one block spans the row
@@ -483,7 +490,7 @@ extern "C" int roitr_gemm(const RoitrGemm* g, hipStream_t stream)
         else if (tn == 1) gemm_kernel<true, 1, true><<<grid, 256, 0, stream>>>(*g, nx, ny, T);
         else if (tn == 2) gemm_kernel<true, 2, true><<<grid, 256, 0, stream>>>(*g, nx, ny, T);
         else gemm_kernel<true, 4, true><<<grid, 256, 0, stream>>>(*g, nx, ny, T);
-    } else if (fast && dma && !g->A2 && !g->seg_off) gemm_dma_kernel<0><<<grid, 256, 0, stream>>>(*g, nx, ny, T);
+    } else if (fast && dma && !g->A2 && !g->seg_off && !g->A_cat) gemm_dma_kernel<0><<<grid, 256, 0, stream>>>(*g, nx, ny, T);
     else if (fast && tn == 2) gemm_kernel<true, 2, false><<<grid, 256, 0, stream>>>(*g, nx, ny, T);
     else if (fast && tn == 4) gemm_kernel<true, 4, false><<<grid, 256, 0, stream>>>(*g, nx, ny, T);
     else if (fast) gemm_kernel<true, 1, false><<<grid, 256, 0, stream>>>(*g, nx, ny, T);

@@ -291,6 +291,7 @@ extern "C" int roitr_gemm_bf16_supported(const RoitrGemm* g)
     const bool a_h = (g->bf16 & ROITR_BF16_A) != 0;
     const long a_al = a_h ? 8 : 4;   // elements per 16 bytes
     if (!(g->bf16 & ROITR_BF16_W)) return 0;                       // weights must be stored bf16
+    if (g->A_cat) return 0;                                        // K-concatenated A: fp32 kernel only
     if (g->K <= 0 || g->K % BK) return 0;
     if (g->lda % a_al || g->ldw % 8 || g->sA % a_al || g->sW % 8) return 0;
     if (((uintptr_t)g->A & 15) || ((uintptr_t)g->W & 15) || (g->A2 && (((uintptr_t)g->A2 & 15) || a_h))) return 0;

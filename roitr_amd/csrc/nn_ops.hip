@@ -194,6 +194,23 @@ extern "C" int roitr_l2_normalize(int M, int C, const float* x, float* out, hipS
     return ROITR_OK;
 }
 
+namespace {
+__global__ void add_vectors_kernel(int n, const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = a[i] + b[i];
+}
+}  // namespace
+
+/* out = a + b (n floats): bias vectors of folded layers */
+extern "C" int roitr_add_vectors(int n, const float* a, const float* b, float* out, hipStream_t stream)
+{
+    if (n <= 0) return ROITR_OK;
+    add_vectors_kernel<<<div_up(n, 256), 256, 0, stream>>>(n, a, b, out);
+    ROITR_LAUNCH_CHECK();
+    return ROITR_OK;
+}
+
 extern "C" int roitr_transpose(int rows, int cols, const float* in, int ld_in, float* out, int ld_out, hipStream_t stream)
 {
     if (rows <= 0 || cols <= 0) return ROITR_OK;

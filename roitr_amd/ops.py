@@ -152,7 +152,8 @@ class _Gemm(ctypes.Structure):
                 ("sBias", ctypes.c_long), ("sAidx", ctypes.c_long), ("sWidx", ctypes.c_long), ("seg_off", _P),
                 ("seg_a0", ctypes.c_int), ("seg_w0", ctypes.c_int),
                 ("ln_gamma", _P), ("ln_beta", _P), ("ln_res", _P), ("ln_res_idx", _P), ("ln_post", _P),
-                ("ln_relu", ctypes.c_int), ("ln_eps", ctypes.c_float), ("bf16", ctypes.c_int)]
+                ("ln_relu", ctypes.c_int), ("ln_eps", ctypes.c_float), ("bf16", ctypes.c_int),
+                ("A_cat", _P), ("lda_cat", ctypes.c_int), ("k_cat", ctypes.c_int)]
 
 
 BF16_W, BF16_A, BF16_C = 1, 2, 4   # RoitrGemm::bf16 flags (include/roitr_engine.h)
