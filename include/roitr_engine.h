@@ -104,7 +104,7 @@ int roitr_calc_ppf(int m, int k, const float* centre_xyz, const float* centre_no
 
 /* ------------------------------------------------------------------ local PPF attention */
 /* attention.py:152-200 with the positional branch folded (see csrc/local_attn.hip).
- * q: (M, >= H + 5*heads) rows = [q | per head: Wpe_h^T q_h (4), q_h.bpe_h (1)]; k, v: rows of the input
+ * q: (M, >= H + 5*heads) rows = [q | per head: Wpe_h^T q_h (4), q_h.bpe_h (1)] (or (M, >= H) rows with wpe / bpe given); k, v: rows of the input
  * cloud (ld given); group_idx (M,K) int32; ppf (M,K,4); wvpe (H,4), bvpe (H); out (M,H).
  * scale = 1/sqrt(H/heads). */
 typedef struct RoitrLocalAttn {
@@ -119,6 +119,8 @@ typedef struct RoitrLocalAttn {
     const void* node_order;   /* optional float4[M] (x,y,z,index-as-bits): visiting order, e.g. roitr_knn_sorted_points() */
     int bf16;                 /* 0: fp32 rows; 3: q / k / v rows AND the output row are stored in bf16 (uint16; ld* in elements) --
                                  the engine's bf16 operand mode, where the q|k|v tensor is written bf16 by its GEMM */
+    const float* wpe; const float* bpe;   /* optional (both or none): Wpe (H,4) and bpe (H) of the folded positional branch; the
+                                 kernel then forms qp[h] = [Wpe_h^T q_h, q_h . bpe_h] itself and q rows are only H wide */
 } RoitrLocalAttn;
 int roitr_local_attention(const RoitrLocalAttn* a, roitr_stream_t stream);
 int roitr_build_pfold(int H, int heads, const float* wpe, const float* bpe, float* pfold, roitr_stream_t stream);

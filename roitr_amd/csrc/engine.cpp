@@ -58,6 +58,9 @@ struct LocalT {  // LocalPPFTransformer (+ derived weights)
     // block transformers in fp32: linear(att) + in_proj(x) as ONE GEMM over the K-concatenated operand [att | x]:
     // wcat = [Wlin | Win] (H x (H + in_dim)), bcat = b_lin + b_in; f = in_proj(x) is then never materialised
     float* wcat = nullptr; float* bcat = nullptr;
+    // the PPF coefficient rows of the query, qp[h] = [Wpe_h^T q_h, q_h . bpe_h]: computed inside the attention kernel from
+    // wpe (H,4) / bpe (H) (nq = 0: [q|k|v] is 3 H wide = whole 64-column GEMM tiles), or as 5 extra GEMM columns per head (nq = 20)
+    const float* wpe = nullptr; const float* bpe = nullptr; int nq = 0;
     float* wvpe = nullptr;  // (H,4)
     float* bvpe = nullptr;  // (H)
     const float* bn2_w = nullptr; const float* bn2_b = nullptr;  // block only
@@ -274,7 +277,9 @@ int resolve_local(Engine& E, LocalT& L, const std::string& pre, int in_dim, int 
 
 int fold_local(Engine& E, LocalT& L, hipStream_t st)
 {
-    const int H = L.H, NQ = 5 * HEADS;
+    static const bool qp_in_gemm = getenv("ROITR_QP_IN_GEMM") != nullptr;
+    const int H = L.H, NQ = qp_in_gemm ? 5 * HEADS : 0, NQF = 5 * HEADS;
+    L.nq = NQ;
     Arena& A = E.warena;
     float* weT = A.get<float>(4 * (size_t)H);
     float* wpeT = A.get<float>(4 * (size_t)H);
@@ -283,7 +288,7 @@ int fold_local(Engine& E, LocalT& L, hipStream_t st)
     float* wvpeT = A.get<float>(4 * (size_t)H);
     L.wvpe = A.get<float>(4 * (size_t)H);
     L.bvpe = A.get<float>(H);
-    float* pfold = A.get<float>((size_t)NQ * H);
+    float* pfold = A.get<float>((size_t)NQF * H);
     float* wqT = A.get<float>((size_t)H * H);
     const int R = 3 * H + NQ;
     L.wqkv = A.get<float>((size_t)R * H);
@@ -294,6 +299,7 @@ int fold_local(Engine& E, LocalT& L, hipStream_t st)
     CHK(gemm(st, 4, H, H, weT, H, L.p.w, H, nullptr, wpeT, H));
     CHK(roitr_transpose(4, H, wpeT, H, wpe, 4, st));
     CHK(gemm(st, 1, H, H, L.emb.b, H, L.p.w, H, L.p.b, bpe, H));
+    L.wpe = wpe; L.bpe = bpe;
     CHK(gemm(st, 4, H, H, weT, H, L.vp.w, H, nullptr, wvpeT, H));
     CHK(roitr_transpose(4, H, wvpeT, H, L.wvpe, 4, st));
     CHK(gemm(st, 1, H, H, L.emb.b, H, L.vp.w, H, L.vp.b, L.bvpe, H));
@@ -301,11 +307,11 @@ int fold_local(Engine& E, LocalT& L, hipStream_t st)
     CHK(roitr_build_pfold(H, HEADS, wpe, bpe, pfold, st));
     CHK(roitr_transpose(H, H, L.q.w, H, wqT, H, st));
     CHK(d2d(st, L.wqkv, L.q.w, sizeof(float) * (size_t)H * H));
-    CHK(gemm(st, NQ, H, H, pfold, H, wqT, H, nullptr, L.wqkv + (size_t)H * H, H));
+    if (NQ) CHK(gemm(st, NQ, H, H, pfold, H, wqT, H, nullptr, L.wqkv + (size_t)H * H, H));
     CHK(d2d(st, L.wqkv + (size_t)(H + NQ) * H, L.k.w, sizeof(float) * (size_t)H * H));
     CHK(d2d(st, L.wqkv + (size_t)(2 * H + NQ) * H, L.v.w, sizeof(float) * (size_t)H * H));
     CHK(d2d(st, L.bqkv, L.q.b, sizeof(float) * H));
-    CHK(gemm(st, 1, NQ, H, L.q.b, H, pfold, H, nullptr, L.bqkv + H, NQ));
+    if (NQ) CHK(gemm(st, 1, NQ, H, L.q.b, H, pfold, H, nullptr, L.bqkv + H, NQ));
     CHK(d2d(st, L.bqkv + H + NQ, L.k.b, sizeof(float) * H));
     CHK(d2d(st, L.bqkv + 2 * H + NQ, L.v.b, sizeof(float) * H));
     if (E.cfg.operand_dtype == 1) {   // folded in fp32, stored once in bf16
@@ -372,7 +378,7 @@ int local_transformer(Engine& E, hipStream_t st, const LocalT& L, int N_in, cons
 {
     Arena& A = E.arena;
     const size_t mark = A.off;
-    const int H = L.H, NQ = 5 * HEADS;
+    const int H = L.H, NQ = L.nq;
     // TransitionDown with folded projections: q / k / v come straight from x, and f = in_proj(x) is only needed as the
     // LayerNorm residual of the M sampled rows
     // (measured and dropped: the same fold for the first transformer of the network, K = 1 -- an outer-product kernel writing
@@ -425,6 +431,7 @@ int local_transformer(Engine& E, hipStream_t st, const LocalT& L, int N_in, cons
     a.M = M; a.K = K; a.H = H; a.heads = HEADS; a.q = q; a.ldq = ldq; a.k = k; a.ldk = ldkv; a.v = v; a.ldv = ldkv;
     a.group_idx = group; a.ppf = ppf; a.wvpe = L.wvpe; a.bvpe = L.bvpe; a.scale = 1.0f / sqrtf((float)(H / HEADS));
     a.out = att; a.ldo = H; a.node_order = order; a.bf16 = hb ? 3 : 0;
+    if (NQ == 0) { a.wpe = L.wpe; a.bpe = L.bpe; }   // qp computed in the kernel
     CHK(roitr_local_attention(&a, st));
     // bf16 operand mode: `y` only feeds out_proj -> the LayerNorm epilogue stores it in bf16 (half the round trip)
     const bool y_h = ln_fuses(H, H, H, H) && bf16_layer(L.lin.wb, H) && bf16_layer(L.out_proj.wb, H);   // independent of M: batch-invariant storage

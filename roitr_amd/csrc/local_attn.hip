@@ -99,7 +99,8 @@ __global__ __launch_bounds__(256) void local_attn_kernel(RoitrLocalAttn a)
         g[n] = a.group_idx[(size_t)node[n] * K + (lane < K ? lane : 0)];
         const size_t qoff = (size_t)node[n] * a.ldq;
         row_ld<HALF, HV>(a.q, qoff + lane * HV, qv[n]);
-        ec[n] = t < 5 ? elem_ld<HALF>(a.q, qoff + H + h * 5 + t) : 0.f;   // qp[h][0..3] (PPF coefficients), qp[h][4] (q_h . bpe_h)
+        // qp[h][0..3] (PPF coefficients), qp[h][4] (q_h . bpe_h): extra columns of the q row, or formed below from wpe / bpe
+        ec[n] = (!a.wpe && t < 5) ? elem_ld<HALF>(a.q, qoff + H + h * 5 + t) : 0.f;
         const float* pf = a.ppf + (size_t)node[n] * K * 4 + (t < 4 ? t : 0);
 #pragma unroll
         for (int kk = 0; kk < K; ++kk) pv[n][kk] = pf[kk * 4];
@@ -117,6 +118,22 @@ __global__ __launch_bounds__(256) void local_attn_kernel(RoitrLocalAttn a)
         for (int kk = 0; kk < K; ++kk) {
             const int gk = __builtin_amdgcn_readlane(g[n], kk);
             row_ld<HALF, HV>(a.v, (size_t)gk * a.ldv + lane * HV, vr[n][kk]);
+        }
+    }
+    if (a.wpe) {   // kernel-argument uniform: qp[h] = [Wpe_h^T q_h, q_h . bpe_h] from this lane's channels + a row reduction
+        float4 w4[HV]; float b1[HV];
+#pragma unroll
+        for (int i = 0; i < HV; ++i) { w4[i] = reinterpret_cast<const float4*>(a.wpe)[lane * HV + i]; b1[i] = a.bpe[lane * HV + i]; }
+#pragma unroll
+        for (int n = 0; n < NPW; ++n) {
+            float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f, p4 = 0.f;
+#pragma unroll
+            for (int i = 0; i < HV; ++i) {
+                p0 = fmaf(w4[i].x, qv[n][i], p0); p1 = fmaf(w4[i].y, qv[n][i], p1); p2 = fmaf(w4[i].z, qv[n][i], p2);
+                p3 = fmaf(w4[i].w, qv[n][i], p3); p4 = fmaf(b1[i], qv[n][i], p4);
+            }
+            p0 = row_allsum(p0); p1 = row_allsum(p1); p2 = row_allsum(p2); p3 = row_allsum(p3); p4 = row_allsum(p4);
+            ec[n] = t == 0 ? p0 : (t == 1 ? p1 : (t == 2 ? p2 : (t == 3 ? p3 : (t == 4 ? p4 : 0.f))));
         }
     }
 #pragma unroll
