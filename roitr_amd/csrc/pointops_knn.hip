@@ -1151,6 +1151,27 @@ __global__ __launch_bounds__(64) void knn_lane_brute_kernel(int m, int nsample, 
 // 2.91 ms for the whole config-5 call, 0.49 vs 0.39 ms of replay per 32-pair 4DMatch forward): with ONE wave per CU nothing
 // hides the SGPR <-> VALU hand-offs of the readlane chain, which cost as much as the LDS round trips they replace; 8 batches of
 // candidate loads in flight (kept) change nothing.  One query per block (up to 1024 blocks) keeps the kernel at one chain.
+// One wave per block: LDS operations of a wave complete in order, so cross-lane hand-offs only need the counter wait.
+__device__ __forceinline__ void lds_sync_wave() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+// reheap (knnquery_cuda_kernel.cu:21-36) with the sinking value kept in registers: the entry at `rt` is always the new one, so a
+// level costs ONE LDS round trip (both children and their indices requested together) instead of three dependent ones;
+// the right child wins only when strictly larger, the walk stops at the first child strictly smaller than the value.
+__device__ __forceinline__ void sift_down(float* hd, int* hi, int k, float nd, int ni)
+{
+    int rt = 0, child = 1;
+    while (child < k) {
+        const bool two = child + 1 < k;
+        const float c0 = hd[child], c1 = hd[two ? child + 1 : child];
+        const int i0 = hi[child], i1 = hi[two ? child + 1 : child];
+        const bool right = two && c1 > c0;
+        const float cd = right ? c1 : c0;
+        if (nd > cd) break;
+        hd[rt] = cd; hi[rt] = right ? i1 : i0;
+        rt = child + (right ? 1 : 0); child = rt * 2 + 1;
+    }
+    hd[rt] = nd; hi[rt] = ni;
+}
+
 __global__ __launch_bounds__(64) void knn_replay_kernel(int nsample, const float* __restrict__ xyz, const float* __restrict__ new_xyz,
                                                         const int* __restrict__ offset, const int* __restrict__ new_offset, KnnOut o)
 {
@@ -1190,41 +1211,24 @@ __global__ __launch_bounds__(64) void knn_replay_kernel(int nsample, const float
                     const int l = __ffsll((long long)mk) - 1;
                     mk &= mk - 1;
                     const float nd = rl_f(cd, l);
-                    if (nd < root) {
-                        __syncthreads();
-                        if (lane == 0) {
-                            hd[0] = nd; hi[0] = base + l;
-                            int rt = 0, child = 1;  // reheap, l.21-36
-                            while (child < nsample) {
-                                if (child + 1 < nsample && hd[child + 1] > hd[child]) child++;
-                                if (hd[rt] > hd[child]) break;
-                                const float td = hd[rt]; hd[rt] = hd[child]; hd[child] = td;
-                                const int ti = hi[rt]; hi[rt] = hi[child]; hi[child] = ti;
-                                rt = child; child = rt * 2 + 1;
-                            }
-                        }
-                        __syncthreads();
+                    if (nd < root) {   // strict admission (l.97); the new point replaces the root, then reheap (l.21-36)
+                        if (lane == 0) sift_down(hd, hi, nsample, nd, base + l);
+                        lds_sync_wave();
                         root = hd[0];
                     }
                 }
             }
         }
-        __syncthreads();
-        if (lane == 0) {  // heap_sort, l.39-48
+        lds_sync_wave();
+        if (lane == 0) {  // heap_sort, l.39-48: the root goes to slot i, the old slot-i entry sinks from the root over the first i
             for (int i = nsample - 1; i > 0; i--) {
-                float td = hd[0]; hd[0] = hd[i]; hd[i] = td;
-                int ti = hi[0]; hi[0] = hi[i]; hi[i] = ti;
-                int rt = 0, child = 1;
-                while (child < i) {
-                    if (child + 1 < i && hd[child + 1] > hd[child]) child++;
-                    if (hd[rt] > hd[child]) break;
-                    td = hd[rt]; hd[rt] = hd[child]; hd[child] = td;
-                    ti = hi[rt]; hi[rt] = hi[child]; hi[child] = ti;
-                    rt = child; child = rt * 2 + 1;
-                }
+                const float td = hd[0], ld_ = hd[i];
+                const int ti = hi[0], li_ = hi[i];
+                hd[i] = td; hi[i] = ti;
+                sift_down(hd, hi, i, ld_, li_);
             }
         }
-        __syncthreads();
+        lds_sync_wave();
         float d[2]; int i[2];
         d[0] = lane < nsample ? hd[lane] : 0.f; i[0] = lane < nsample ? hi[lane] : 0;
         d[1] = lane + 64 < nsample ? hd[lane + 64] : 0.f; i[1] = lane + 64 < nsample ? hi[lane + 64] : 0;
