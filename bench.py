@@ -109,9 +109,6 @@ def main():
     def batch(step):
         return [pool[(step * B + j) % len(pool)] for j in range(B)]
 
-    def batch_ids(step):
-        return [ids[(step * B + j) % len(pool)] for j in range(B)]
-
     def barrier():
         if distributed:
             dist.barrier()

@@ -874,7 +874,7 @@ extern "C" int roitr_engine_forward(void* h, const RoitrForwardIO* io, hipStream
             CHK(roitr_geo_embed_split(etot, C4, 3, d_idx, a_idx, E.geo_div, E.proj_d3, E.proj_d.b, E.proj_a3, E.proj_a.b, Emb, st));
         else
             CHK(roitr_geo_embed(etot, C4, 3, d_idx, a_idx, E.geo_div, E.proj_d.w, E.proj_d.b, E.proj_a.w, E.proj_a.b, Emb, st));
-        CHK(tap(E, st, "geo.emb", Emb, sizeof(float) * (size_t)etot * C4));
+        CHK(tap(E, st, "geo.emb", Emb, (e_h ? sizeof(unsigned short) : sizeof(float)) * (size_t)etot * C4));   // bf16 mode: the tap holds bf16
 
         float* fcur = A.get<float>((size_t)T4 * C4);
         float* pos = A.get<float>((size_t)T4 * C4);

@@ -1145,7 +1145,8 @@ __global__ __launch_bounds__(64) void knn_lane_brute_kernel(int m, int nsample, 
 // same (uniform) heap code; 64 distances are evaluated per step and only those below the root are
 // offered to the heap, in index order -- the heap sees exactly the reference's insertion sequence.
 // A replayed query admits ~k ln(n / k) candidates one after the other and that serial chain (~2 us per admission) is all
-// its run time: 0.5 ms at k = 64, n = 30000.  Measured and dropped: the heap in registers (entry p in lane p % 64, reads by
+// its run time: 0.5 ms at k = 64, n = 30000 (unchanged by keeping the sinking value in registers and dropping the block
+// barriers, the form below: 2.94 vs 2.99 ms for the config-5 call).  Measured and dropped: the heap in registers (entry p in lane p % 64, reads by
 // v_readlane, writes by lane compare + select: no LDS, no barrier), both as a straight restatement (1.46 vs 1.08 ms per launch
 // on that case) and with every node's larger child precomputed by four ds_bpermute and a scalar walk down that path (3.10 vs
 // 2.91 ms for the whole config-5 call, 0.49 vs 0.39 ms of replay per 32-pair 4DMatch forward): with ONE wave per CU nothing
