@@ -771,21 +771,70 @@ __global__ __launch_bounds__(256) void knn_cell_kernel(int nsample, const float*
             const bool covered = dmin == INFINITY;          // the box is the whole grid
             const float dm = dmin - margin;
             if (!covered && !(dm > 0.f)) { retry(q); continue; }
-            const float lim = covered ? INFINITY : dm * dm;
+            float lim = covered ? INFINITY : dm * dm;
 
             // ---- A: distances, compaction of the candidates inside the guarantee radius
             int cnt = 0;
-            for (int t = 0; t < T; ++t) {
-                const int j = t * 64 + lane;
-                const float4 c = cand[min(j, C - 1)];
-                const float d = sqdist3(Qp.x, Qp.y, Qp.z, c.x, c.y, c.z);
-                const bool near = j < C && j != qslot && d < lim;
-                const unsigned long long mk = __ballot(near);
-                const int pos = cnt + __popcll(mk & lt_mask);
-                if (near && pos < CELL_NEAR) { nd[pos] = d; nj[pos] = j; }
-                cnt += __popcll(mk);
+            auto scan_staged = [&]() {
+                cnt = 0;
+                for (int t = 0; t < T; ++t) {
+                    const int j = t * 64 + lane;
+                    const float4 c = cand[min(j, C - 1)];
+                    const float d = sqdist3(Qp.x, Qp.y, Qp.z, c.x, c.y, c.z);
+                    const bool near = j < C && j != qslot && d < lim;
+                    const unsigned long long mk = __ballot(near);
+                    const int pos = cnt + __popcll(mk & lt_mask);
+                    if (near && pos < CELL_NEAR) { nd[pos] = d; nj[pos] = j; }
+                    cnt += __popcll(mk);
+                }
+            };
+            scan_staged();
+            if (cnt > CELL_NEAR) { retry(q); continue; }   // too dense for the list
+            if (cnt < S) {
+                // Guarantee radius not reached (5.5 % of the queries of a uniform cube: the cells at its faces, whose sphere is cut
+                // by the boundary).  Second ring for THIS query: the 5 x 5 x 5 box's guarantee radius, capped at the radius the
+                // local density says holds ~1.7 S neighbours (the list has CELL_NEAR slots); the staged 27 cells are re-scanned
+                // from LDS with the new limit, the 98 shell cells come straight from the sorted array (slot = -(position + 1)).
+                if (covered) { retry(q); continue; }       // the whole cloud is staged and still too small: fill-entry case
+                const int x0b = max(cx - 2, 0), x1b = min(cx + 2, g.nx - 1);
+                const int y0b = max(cy - 2, 0), y1b = min(cy + 2, g.ny - 1);
+                const int z0b = max(cz - 2, 0), z1b = min(cz + 2, g.nz - 1);
+                float dmin2 = INFINITY;
+                if (x0b > 0) dmin2 = fminf(dmin2, Qp.x - __fmaf_rn((float)x0b, g.h, g.ox));
+                if (x1b < g.nx - 1) dmin2 = fminf(dmin2, __fmaf_rn((float)(x1b + 1), g.h, g.ox) - Qp.x);
+                if (y0b > 0) dmin2 = fminf(dmin2, Qp.y - __fmaf_rn((float)y0b, g.h, g.oy));
+                if (y1b < g.ny - 1) dmin2 = fminf(dmin2, __fmaf_rn((float)(y1b + 1), g.h, g.oy) - Qp.y);
+                if (z0b > 0) dmin2 = fminf(dmin2, Qp.z - __fmaf_rn((float)z0b, g.h, g.oz));
+                if (z1b < g.nz - 1) dmin2 = fminf(dmin2, __fmaf_rn((float)(z1b + 1), g.h, g.oz) - Qp.z);
+                const float dm2 = dmin2 - margin;
+                const float want = lim * powf(1.7f * (float)S / (float)max(cnt, 1), 0.6667f);   // r^2 ~ count^(2/3)
+                const float lim2 = dmin2 == INFINITY ? want : fminf(dm2 * dm2, want);
+                if (!(lim2 > lim)) { retry(q); continue; }
+                lim = lim2;
+                scan_staged();
+                for (int zz = z0b; zz <= z1b; ++zz)
+                    for (int yy = y0b; yy <= y1b; ++yy) {
+                        const int rowbase = (zz * g.ny + yy) * g.nx;
+                        const bool inner = zz >= z0 && zz <= z1 && yy >= y0 && yy <= y1;   // this row's cells x0..x1 are staged
+                        for (int part = 0; part < (inner ? 2 : 1); ++part) {
+                            const int xa = inner ? (part == 0 ? x0b : x1 + 1) : x0b;
+                            const int xb = inner ? (part == 0 ? x0 - 1 : x1b) : x1b;
+                            if (xa > xb) continue;
+                            const int rs = cs[rowbase + xa], re = cs[rowbase + xb + 1];
+                            for (int p0 = rs; p0 < re; p0 += 64) {
+                                const int pp = p0 + lane;
+                                const float4 c = sorted[min(pp, re - 1)];
+                                const float d = sqdist3(Qp.x, Qp.y, Qp.z, c.x, c.y, c.z);
+                                const bool near = pp < re && d < lim;
+                                const unsigned long long mk = __ballot(near);
+                                const int pos = cnt + __popcll(mk & lt_mask);
+                                if (near && pos < CELL_NEAR) { nd[pos] = d; nj[pos] = -(pp + 1); }
+                                cnt += __popcll(mk);
+                            }
+                        }
+                    }
+                if (cnt > CELL_NEAR || cnt < S) { retry(q); continue; }
             }
-            if (cnt > CELL_NEAR || cnt < S) { retry(q); continue; }   // too dense for the list / guarantee radius not reached
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             float e[4]; int ej[4];
             float emax = 0.f;
@@ -863,7 +912,7 @@ __global__ __launch_bounds__(256) void knn_cell_kernel(int nsample, const float*
                 if (__ballot(t) != 0ull) { tie(q); continue; }
             }
             // ---- output: row = [query itself (distance 0), the S neighbours]
-            const float4 nb = cand[j];
+            const float4 nb = j >= 0 ? cand[j] : sorted[-j - 1];   // staged slot, or a second-ring point of the sorted array
             const int ni = __float_as_int(nb.w);
             if (lane == 0) {
                 if (o.idx) o.idx[(size_t)q * nsample] = q;
