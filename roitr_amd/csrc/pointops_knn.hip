@@ -771,7 +771,11 @@ __global__ __launch_bounds__(256) void knn_cell_kernel(int nsample, const float*
             const bool covered = dmin == INFINITY;          // the box is the whole grid
             const float dm = dmin - margin;
             if (!covered && !(dm > 0.f)) { retry(q); continue; }
-            float lim = covered ? INFINITY : dm * dm;
+            // the list has CELL_NEAR slots: the first pass looks no farther than the radius that holds ~2.5 S points at the local
+            // density (a query in the middle of its cell has dm = 1.5 h: 370 points at 26 per cell), the guarantee radius at most
+            const float rho_loc = (float)C / (float)((x1 - x0 + 1) * (y1 - y0 + 1) * (z1 - z0 + 1));
+            const float rcap2 = g.h * g.h * powf(2.5f * (float)S / (4.18879f * fmaxf(rho_loc, 1e-3f)), 0.6667f);
+            float lim = covered ? rcap2 : fminf(dm * dm, rcap2);
 
             // ---- A: distances, compaction of the candidates inside the guarantee radius
             int cnt = 0;
@@ -795,7 +799,6 @@ __global__ __launch_bounds__(256) void knn_cell_kernel(int nsample, const float*
                 // by the boundary).  Second ring for THIS query: the 5 x 5 x 5 box's guarantee radius, capped at the radius the
                 // local density says holds ~1.7 S neighbours (the list has CELL_NEAR slots); the staged 27 cells are re-scanned
                 // from LDS with the new limit, the 98 shell cells come straight from the sorted array (slot = -(position + 1)).
-                if (covered) { retry(q); continue; }       // the whole cloud is staged and still too small: fill-entry case
                 const int x0b = max(cx - 2, 0), x1b = min(cx + 2, g.nx - 1);
                 const int y0b = max(cy - 2, 0), y1b = min(cy + 2, g.ny - 1);
                 const int z0b = max(cz - 2, 0), z1b = min(cz + 2, g.nz - 1);
@@ -808,10 +811,12 @@ __global__ __launch_bounds__(256) void knn_cell_kernel(int nsample, const float*
                 if (z1b < g.nz - 1) dmin2 = fminf(dmin2, __fmaf_rn((float)(z1b + 1), g.h, g.oz) - Qp.z);
                 const float dm2 = dmin2 - margin;
                 const float want = lim * powf(1.7f * (float)S / (float)max(cnt, 1), 0.6667f);   // r^2 ~ count^(2/3)
+                const float g1 = covered ? INFINITY : dm * dm;               // what the staged cells alone guarantee
                 const float lim2 = dmin2 == INFINITY ? want : fminf(dm2 * dm2, want);
                 if (!(lim2 > lim)) { retry(q); continue; }
                 lim = lim2;
                 scan_staged();
+                if (lim > g1)   // beyond the first ring's guarantee: the shell cells have to be looked at as well
                 for (int zz = z0b; zz <= z1b; ++zz)
                     for (int yy = y0b; yy <= y1b; ++yy) {
                         const int rowbase = (zz * g.ny + yy) * g.nx;
@@ -847,7 +852,7 @@ __global__ __launch_bounds__(256) void knn_cell_kernel(int nsample, const float*
                 emax = v ? fmaxf(emax, e[r]) : emax;
             }
             // ---- B: exact threshold of rank S
-            const float hi = covered ? wave_max(emax) * 1.0001f + 1e-30f : lim;
+            const float hi = lim;   // every listed distance is < lim (finite: capped by the density radius)
             const float scale = 64.0f / hi;
             hist[lane] = 0;
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
