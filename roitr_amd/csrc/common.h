@@ -39,6 +39,18 @@ __device__ __forceinline__ float sqdist3(float ax, float ay, float az, float bx,
     return __fmaf_rn(dz, dz, __fmaf_rn(dy, dy, __fmul_rn(dx, dx)));
 }
 
+// Segment (cloud) of element i under cumulative offsets off[0..n): the first c with i < off[c] + c * stride + bias, clamped to
+// n - 1.  A binary search: the batched engine has up to ~1000 clouds per call, a linear walk per thread shows up in profiles.
+__device__ __forceinline__ int segment_of(int i, const int* __restrict__ off, int n, int stride = 0, int bias = 0)
+{
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (i < off[mid] + mid * stride + bias) hi = mid; else lo = mid + 1;
+    }
+    return lo;
+}
+
 // Sum over the 16 lanes of a DPP row (result in every lane of the row).
 template <int CTRL>
 __device__ __forceinline__ float row_dpp_add(float v)

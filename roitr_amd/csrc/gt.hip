@@ -42,8 +42,7 @@ __global__ void build_padded_kernel(int B, const float* __restrict__ pts, const 
     const int t = blockIdx.x * 256 + threadIdx.x;
     if (t >= total_rows) return;
     // padded offsets: cloud c starts at pt_offset[c-1] + c
-    int c = 0;
-    while (c < 2 * B - 1 && t >= pt_offset[c] + c + 1) ++c;
+    const int c = segment_of(t, pt_offset, 2 * B, 1, 1);   // first c with t < pt_offset[c] + c + 1
     const int p0 = c == 0 ? 0 : pt_offset[c - 1];
     const int local = t - (p0 + c);
     const int n = pt_offset[c] - p0;
@@ -89,8 +88,7 @@ __global__ __launch_bounds__(64) void node_radius_kernel(RoitrNodeCorr a, float*
 {
     const int node = blockIdx.x, k = threadIdx.x;
     const int B = a.pairs, L = a.limit;
-    int c = 0;
-    while (c < 2 * B - 1 && node >= a.node_offset[c]) ++c;
+    const int c = segment_of(node, a.node_offset, 2 * B);
     const int p0 = c == 0 ? 0 : a.pt_offset[c - 1], pn = a.pt_offset[c] - p0;
     float nx = a.nodes[(size_t)node * 3], ny = a.nodes[(size_t)node * 3 + 1], nz = a.nodes[(size_t)node * 3 + 2];
     const bool src = c < B;

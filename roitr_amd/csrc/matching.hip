@@ -39,8 +39,7 @@ __global__ __launch_bounds__(256) void p2n_assign_kernel(int n_points, const flo
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n_points) return;
-    int c = 0;
-    while (c < b - 1 && i >= pt_offset[c]) ++c;
+    const int c = segment_of(i, pt_offset, b);
     (void)cloud_of_pt_hint;
     const int ns = c == 0 ? 0 : node_offset[c - 1], ne = node_offset[c];
     const float px = pts[(size_t)i * 3], py = pts[(size_t)i * 3 + 1], pz = pts[(size_t)i * 3 + 2];

@@ -130,6 +130,7 @@ struct KnnOut {
     const float* query_normals;  // (m, 3), needed for ppf
     int* tie_count;
     int* tie_list;
+    int b;             // number of clouds when the caller knows it (binary segment search), 0 = unknown (legacy entry point)
 };
 
 // writes one query's result row(s) from list-position-indexed (dist, idx) held in lanes
@@ -175,9 +176,11 @@ __device__ __forceinline__ bool has_tie(const WaveList<NR>& L, int nsample, int 
 }
 
 __device__ __forceinline__ void find_segment(int q, const int* __restrict__ offset, const int* __restrict__ new_offset, int& start,
-                                             int& end, int& seg)
+                                             int& end, int& seg, int b = 0)
 {
-    int bt = 0;  // get_bt_idx, knnquery_cuda_kernel.cu:51-62
+    int bt = 0;  // get_bt_idx, knnquery_cuda_kernel.cu:51-62 (a linear walk there; the batched engine has ~1000 clouds per call)
+    if (b > 0) bt = segment_of(q, new_offset, b);
+    else
     while (!(q < new_offset[bt])) bt++;
     start = bt == 0 ? 0 : offset[bt - 1];
     end = offset[bt];
@@ -207,7 +210,7 @@ __global__ __launch_bounds__(256) void knn_brute_kernel(int m, int nsample, cons
     const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (q >= m) return;
     int start, end, seg;
-    find_segment(q, offset, new_offset, start, end, seg);
+    find_segment(q, offset, new_offset, start, end, seg, o.b);
     Query Q = {new_xyz[(size_t)q * 3], new_xyz[(size_t)q * 3 + 1], new_xyz[(size_t)q * 3 + 2]};
     WaveList<NR> L;
     L.init(start);
@@ -337,7 +340,7 @@ __global__ __launch_bounds__(256) void knn_grid_kernel(int m, int nsample, const
     const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (q >= m) return;
     int start, end, seg;
-    find_segment(q, offset, new_offset, start, end, seg);
+    find_segment(q, offset, new_offset, start, end, seg, o.b);
     const RoitrGrid g = grids[seg];
     const int* cs = cell_start + (size_t)seg * (GRID_MAX_CELLS + 1);
     Query Q = {new_xyz[(size_t)q * 3], new_xyz[(size_t)q * 3 + 1], new_xyz[(size_t)q * 3 + 2]};
@@ -512,7 +515,7 @@ __global__ __launch_bounds__(256) void knn_gridsel_kernel(int m, int nsample, co
     const int q = qlist ? qlist[t_] : t_;
     float* bd = bd_[w]; int* bi = bi_[w]; float* ld = ld_[w]; int* li = li_[w]; int* hist = hist_[w];
     int start, end, seg;
-    find_segment(q, offset, new_offset, start, end, seg);
+    find_segment(q, offset, new_offset, start, end, seg, o.b);
     const RoitrGrid g = grids[seg];
     const int* cs = cell_start + (size_t)seg * (GRID_MAX_CELLS + 1);
     Query Q = {new_xyz[(size_t)q * 3], new_xyz[(size_t)q * 3 + 1], new_xyz[(size_t)q * 3 + 2]};
@@ -1237,7 +1240,7 @@ __global__ __launch_bounds__(64) void knn_replay_kernel(int nsample, const float
     for (int t = blockIdx.x; t < count; t += gridDim.x) {
         const int q = o.tie_list[t];
         int start, end, seg;
-        find_segment(q, offset, new_offset, start, end, seg);
+        find_segment(q, offset, new_offset, start, end, seg, o.b);
         Query Q = {new_xyz[(size_t)q * 3], new_xyz[(size_t)q * 3 + 1], new_xyz[(size_t)q * 3 + 2]};
         for (int p = lane; p < nsample; p += 64) { hd[p] = KNN_FILL; hi[p] = start; }
         __syncthreads();
@@ -1376,7 +1379,7 @@ extern "C" int roitr_knnquery_ex(int b, int n, int m, int nsample, const float* 
     if (nsample < 1 || nsample > 100) return ROITR_ERR_ARG;  // best_dist[100], knnquery_cuda_kernel.cu:86
     if (ppf && (!ref_normals || !query_normals)) return ROITR_ERR_ARG;
     WsView v = carve(ws, b, n, m_capacity);
-    KnnOut o = {idx, dist2, group_idx, ppf, ref_normals, query_normals, v.tie_count, v.tie_list};
+    KnnOut o = {idx, dist2, group_idx, ppf, ref_normals, query_normals, v.tie_count, v.tie_list, b > 0 ? b : 0};
     ROITR_HIP(hipMemsetAsync(v.tie_count, 0, 2 * sizeof(int), stream));   // tie counter + retry counter
     const int blocks = div_up(m, 4);
     // algorithmic bytes: refs xyz(+normals) once, queries when distinct, idx + dist2/ppf rows out
