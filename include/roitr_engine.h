@@ -94,6 +94,19 @@ int roitr_geo_embed_bf16(long rows, int C, int angle_k, const float* d_idx, cons
 int roitr_geo_embed_bf16_out(long rows, int C, int angle_k, const float* d_idx, const float* a_idx, const float* div_term,
                              const unsigned short* Wd, const float* bd, const unsigned short* Wa, const float* ba,
                              unsigned short* out, roitr_stream_t stream);
+/* Function-table form of the same embedding (csrc/geo_table.hip): proj_x(sinusoid(v)) is a univariate band-limited function of
+ * the scalar v per output channel (positional_encoding.py:38-62 feeds ONE value per row into the sinusoid), so it is fitted once
+ * per weight set by a degree-7 polynomial per channel on intervals of width `interval` (float64 Chebyshev interpolation on the
+ * HOST) and evaluated from LDS.  roitr_geo_table_build: all pointers are HOST memory; table holds roitr_geo_table_floats()
+ * floats; fit[0..3] = {max |poly - g_d| between the nodes, max |g_d|, the same for the angle projection}.
+ * roitr_geo_embed_table: device pointers; values outside [0, n_int * interval) are evaluated directly from div_term / W / b, so
+ * any input is served; angle_k must be 3, C a multiple of 64; out is fp32 (rows, C), or bf16 when out_bf16. */
+size_t roitr_geo_table_floats(int C, int n_int_d, int n_int_a);
+int roitr_geo_table_build(int C, const float* div_term, const float* Wd, const float* bd, const float* Wa, const float* ba,
+                          float interval, int n_int_d, int n_int_a, float* table, double* fit);
+int roitr_geo_embed_table(long rows, int C, int angle_k, const float* d_idx, const float* a_idx, const float* table, float interval,
+                          int n_int_d, int n_int_a, const float* div_term, const float* Wd, const float* bd, const float* Wa,
+                          const float* ba, void* out, int out_bf16, roitr_stream_t stream);
 /* E = P_d + max_k P_a[:, k, :] (positional_encoding.py:146-152) */
 int roitr_geo_combine(long rows, int C, int k, const float* pd, const float* pa, float* out, roitr_stream_t stream);
 int roitr_gather_rows(long rows, int C, const float* in, const int* idx, int limit, float* out, roitr_stream_t stream);
@@ -298,6 +311,9 @@ void* roitr_engine_create(const RoitrEngineConfig* cfg);
 void roitr_engine_destroy(void* engine);
 int roitr_engine_set_param(void* engine, const char* name, const float* device_ptr, long numel);
 int roitr_engine_finalize(void* engine, roitr_stream_t stream);
+/* The function table of the geometric embedding chosen by finalize (see roitr_geo_table_build): info[0..6] = {interval, n_int_d,
+ * n_int_a, fit error d, amplitude d, fit error a, amplitude a}; returns 1 when a table is in use, 0 when the GEMM form is. */
+int roitr_engine_geo_table_info(void* engine, double* info);
 int roitr_engine_forward(void* engine, const RoitrForwardIO* io, roitr_stream_t stream);
 /* Same forward, replayed as ONE hipGraphLaunch once the same (sizes, io buffers) combination has been seen twice
  * (1st call: plain forward; 2nd: capture + instantiate; then replay).  `stream` must be a real (non-NULL) stream.

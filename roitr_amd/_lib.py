@@ -25,6 +25,7 @@ def lib():
         _lib = ctypes.CDLL(LIB_PATH)
         _lib.roitr_last_error.restype = ctypes.c_char_p
         _lib.roitr_knn_workspace_bytes.restype = ctypes.c_size_t
+        _lib.roitr_geo_table_floats.restype = ctypes.c_size_t
         for name in ("roitr_engine_create",):
             if hasattr(_lib, name):
                 getattr(_lib, name).restype = ctypes.c_void_p

@@ -113,6 +113,8 @@ struct Engine {
     unsigned short* proj_d3 = nullptr; unsigned short* proj_a3 = nullptr;   // opt-in split-bf16 planes (ROITR_GEO_SPLIT=1)
     const float* geo_div = nullptr;
     float* geo_div_own = nullptr;
+    // function-table form of the embedding (geo_table.hip): built at finalize unless ROITR_GEO_TABLE=0
+    float* geo_tab = nullptr; float geo_tab_h = 0.f; int geo_tab_nd = 0, geo_tab_na = 0; double geo_tab_fit[4] = {0, 0, 0, 0};
     std::vector<GeoLayer> geo;
     const float* ot_alpha = nullptr;
     Arena warena;  // derived weights
@@ -667,9 +669,55 @@ extern "C" int roitr_engine_finalize(void* h, hipStream_t st)
             CHK(roitr_split3_bf16((long)C4 * C4, E.proj_a.w, E.proj_a3, st));
         }
     }
+    E.geo_tab = nullptr;
+    {   // GeometricStructureEmbedding as a function table: proj_x(sinusoid(v)) is univariate per channel.  The widest interval
+        // whose MEASURED fit error (float64, between the interpolation nodes) is below 2^-25 of the function's amplitude is
+        // taken; distances up to ROITR_GEO_TABLE_RANGE (default 48 = 9.6 m at sigma_d = 0.2) are tabulated, larger ones are
+        // evaluated directly by the kernel.  Angles: atan2 in [0, pi] scaled by 180 / (sigma_a pi).
+        const char* ev = getenv("ROITR_GEO_TABLE");
+        if (!(ev && atoi(ev) == 0) && C4 % 64 == 0 && !E.proj_d3) {
+            const char* rv = getenv("ROITR_GEO_TABLE_RANGE");
+            const double d_range = rv && atof(rv) > 0 ? atof(rv) : 48.0, a_range = 180.0 / 15.0;
+            std::vector<float> hd((size_t)C4 * C4), ha((size_t)C4 * C4), hbd(C4), hba(C4), hdiv(C4 / 2);
+            ROITR_HIP(hipStreamSynchronize(st));
+            ROITR_HIP(hipMemcpy(hd.data(), E.proj_d.w, sizeof(float) * hd.size(), hipMemcpyDeviceToHost));
+            ROITR_HIP(hipMemcpy(ha.data(), E.proj_a.w, sizeof(float) * ha.size(), hipMemcpyDeviceToHost));
+            ROITR_HIP(hipMemcpy(hbd.data(), E.proj_d.b, sizeof(float) * C4, hipMemcpyDeviceToHost));
+            ROITR_HIP(hipMemcpy(hba.data(), E.proj_a.b, sizeof(float) * C4, hipMemcpyDeviceToHost));
+            ROITR_HIP(hipMemcpy(hdiv.data(), E.geo_div, sizeof(float) * (C4 / 2), hipMemcpyDeviceToHost));
+            for (float h : {2.0f, 1.0f, 0.5f}) {
+                const int nd = (int)ceil(d_range / h), na = (int)floor(a_range / h) + 1;
+                const size_t nf = roitr_geo_table_floats(C4, nd, na);
+                if ((size_t)(nd + na) * 8 * 64 * sizeof(float) > 160 * 1024) break;
+                std::vector<float> tab(nf);
+                double fit[4];
+                CHK(roitr_geo_table_build(C4, hdiv.data(), hd.data(), hbd.data(), ha.data(), hba.data(), h, nd, na, tab.data(), fit));
+                const double tol = 1.0 / (double)(1 << 25);
+                if (fit[0] <= tol * fit[1] && fit[2] <= tol * fit[3]) {
+                    float* dev = E.warena.get<float>(nf);
+                    if (E.warena.fail) break;
+                    ROITR_HIP(hipMemcpy(dev, tab.data(), sizeof(float) * nf, hipMemcpyHostToDevice));
+                    E.geo_tab = dev; E.geo_tab_h = h; E.geo_tab_nd = nd; E.geo_tab_na = na;
+                    for (int q = 0; q < 4; ++q) E.geo_tab_fit[q] = fit[q];
+                    break;
+                }
+            }
+        }
+    }
     if (E.warena.fail) { roitr_set_error("derived-weight arena exhausted", __FILE__, __LINE__); return ROITR_ERR_ARG; }
     E.finalized = true;
     return 0;
+}
+
+/* The function table of the geometric embedding chosen at finalize: info = {interval, n_int_d, n_int_a, fit error of the
+ * distance projection, its amplitude, fit error of the angle projection, its amplitude}; returns 0 when no table is in use. */
+extern "C" int roitr_engine_geo_table_info(void* h, double* info)
+{
+    Engine& E = *(Engine*)h;
+    if (!E.geo_tab) return 0;
+    info[0] = E.geo_tab_h; info[1] = E.geo_tab_nd; info[2] = E.geo_tab_na;
+    for (int q = 0; q < 4; ++q) info[3 + q] = E.geo_tab_fit[q];
+    return 1;
 }
 
 extern "C" int roitr_engine_forward(void* h, const RoitrForwardIO* io, hipStream_t st)
@@ -865,7 +913,10 @@ extern "C" int roitr_engine_forward(void* h, const RoitrForwardIO* io, hipStream
         // attention kernel for this width reads it (C = 256 / 512, 4 heads, <= 512 superpoints)
         const bool e_h = E.cfg.operand_dtype == 1 && E.proj_d.wb && E.proj_a.wb && (C4 == 256 || C4 == 512) && V.nmax[3] <= 512 &&
                          getenv("ROITR_MHA_GENERIC") == nullptr;
-        if (e_h)
+        if (E.geo_tab)
+            CHK(roitr_geo_embed_table(etot, C4, 3, d_idx, a_idx, E.geo_tab, E.geo_tab_h, E.geo_tab_nd, E.geo_tab_na, E.geo_div, E.proj_d.w,
+                                      E.proj_d.b, E.proj_a.w, E.proj_a.b, Emb, e_h ? 1 : 0, st));
+        else if (e_h)
             CHK(roitr_geo_embed_bf16_out(etot, C4, 3, d_idx, a_idx, E.geo_div, E.proj_d.wb, E.proj_d.b, E.proj_a.wb, E.proj_a.b,
                                          reinterpret_cast<unsigned short*>(Emb), st));
         else if (E.cfg.operand_dtype == 1 && E.proj_d.wb && E.proj_a.wb)

@@ -109,6 +109,13 @@ void roitr_prof_begin(int cls, double bytes, hipStream_t st)
     g_open.push_back(r);
 }
 
+void roitr_prof_note(int cls, double v)
+{
+    if (!g_on) return;
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (cls >= 0 && cls < ROITR_PROF_CLASSES) { g_bytes[cls] += v; g_launches[cls] += 1; }
+}
+
 void roitr_prof_end(int cls, hipStream_t st)
 {
     if (!g_on) return;

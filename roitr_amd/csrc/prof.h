@@ -3,7 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
-#define ROITR_PROF_CLASSES 16
+#define ROITR_PROF_CLASSES 18
 enum {
     ROITR_PROF_FPS = 0,        // fps_kernel, one launch
     ROITR_PROF_KNN = 1,        // knn_grid_kernel / knn_brute_kernel (the query kernel incl. fused PPF), one launch
@@ -19,11 +19,14 @@ enum {
     ROITR_PROF_LOCAL_ATTN = 11,// local_attn_kernel
     ROITR_PROF_GEMM = 12,      // gemm_kernel: the "bytes" field carries FLOPs (2*M*N*K*batch)
     ROITR_PROF_MHA = 13,       // mha_kernel
-    ROITR_PROF_GEO_EMBED = 14  // geo_embed_kernel: "bytes" carries FLOPs
+    ROITR_PROF_GEO_EMBED = 14, // geo_embed_kernel (GEMM form): "bytes" carries FLOPs
+    ROITR_PROF_GEO_TABLE = 15, // geo_table_kernel: HBM bytes
+    ROITR_PROF_GEO_ALGO = 16   // no time: the FLOPs the GEMM form of the embedding would have spent on the rows geo_table_kernel served
 };
 
 void roitr_prof_begin(int cls, double bytes, hipStream_t st);
 void roitr_prof_end(int cls, hipStream_t st);
+void roitr_prof_note(int cls, double v);   // adds v to the class total without a timed bracket
 extern "C" void roitr_prof_enable(int on);
 extern "C" int roitr_prof_is_enabled(void);
 extern "C" void roitr_prof_reset(void);

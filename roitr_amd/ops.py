@@ -230,6 +230,35 @@ def adaptive_superpoint_matching(src_feats, tgt_feats, src_masks, tgt_masks, min
     return ia[:n].long(), ib[:n].long(), sc[:n]
 
 
+def geo_table_build(div_term, w_d, b_d, w_a, b_a, interval=2.0, d_range=48.0, a_range=12.0):
+    """Host fit of the function table of the geometric embedding (csrc/geo_table.hip): returns (table on the weights' device,
+    n_int_d, n_int_a, fit) with fit = [fit error d, amplitude d, fit error a, amplitude a] measured in float64."""
+    import math
+    C = int(w_d.shape[0])
+    nd, na = int(math.ceil(d_range / interval)), int(math.floor(a_range / interval)) + 1
+    lib = L.lib()
+    h = lambda t: t.detach().float().cpu().contiguous()
+    div_h, wd_h, bd_h, wa_h, ba_h = map(h, (div_term, w_d, b_d, w_a, b_a))
+    table = torch.empty(int(lib.roitr_geo_table_floats(C, nd, na)), dtype=torch.float32)
+    fit = (ctypes.c_double * 4)()
+    L.check(lib.roitr_geo_table_build(C, L.ptr(div_h), L.ptr(wd_h), L.ptr(bd_h), L.ptr(wa_h), L.ptr(ba_h), L.c_float(interval), nd, na,
+                                      L.ptr(table), fit), "geo_table_build")
+    return table.to(w_d.device), nd, na, list(fit)
+
+
+def geo_embed_table(d_idx, a_idx, table, interval, n_int_d, n_int_a, div_term, w_d, b_d, w_a, b_a, out_bf16=False):
+    """The embedding of geo_embed() evaluated from the function table; values outside the table are evaluated directly."""
+    rows, k = int(a_idx.shape[0]), int(a_idx.shape[1])
+    C = int(w_d.shape[0])
+    f = lambda t: t.contiguous().float()
+    d_idx, a_idx, table, div_term, w_d, b_d, w_a, b_a = map(f, (d_idx, a_idx, table, div_term, w_d, b_d, w_a, b_a))
+    out = torch.empty((rows, C), dtype=torch.bfloat16 if out_bf16 else torch.float32, device=d_idx.device)
+    L.check(L.lib().roitr_geo_embed_table(ctypes.c_long(rows), C, k, L.ptr(d_idx), L.ptr(a_idx), L.ptr(table), L.c_float(interval),
+                                          int(n_int_d), int(n_int_a), L.ptr(div_term), L.ptr(w_d), L.ptr(b_d), L.ptr(w_a), L.ptr(b_a),
+                                          L.ptr(out), 1 if out_bf16 else 0, L.stream_ptr()), "geo_embed_table")
+    return out
+
+
 def geo_embed(d_idx, a_idx, div_term, w_d, b_d, w_a, b_a, split=False, bf16=False):
     """positional_encoding.py:139-154 fused: proj_d(sinusoid(d_idx)) + max_k proj_a(sinusoid(a_idx[:, k])) for `rows` index
     rows.  split=True: the opt-in three-way bf16 split on the bf16 matrix cores (fp32-level accuracy); bf16=True: plain bf16

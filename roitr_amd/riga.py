@@ -270,7 +270,7 @@ class RIGA_v2(nn.Module):
     PROF_CLASSES = {"fps_kernel": 0, "knn_query_kernel": 1, "grid_build_kernel": 2, "knn_replay_kernel": 3, "phase.geometry": 4,
                     "phase.encoder": 5, "phase.global_transformer": 6, "phase.decoder": 7, "phase.matching": 8,
                     "phase.forward": 9, "ot_kernel": 10, "local_attn_kernel": 11, "gemm_kernel": 12, "mha_kernel": 13,
-                    "geo_embed_kernel": 14}
+                    "geo_embed_kernel": 14, "geo_table_kernel": 15, "geo_embed_reference_flops": 16}
 
     @staticmethod
     def profile_reset(enable=True):
@@ -290,6 +290,16 @@ class RIGA_v2(nn.Module):
                 out[name] = {"ms": ms.value, "launches": n.value, "bytes": by.value}
         lib.roitr_prof_enable(0)
         return out
+
+    def geo_table_info(self):
+        """The function table the engine evaluates the geometric embedding from (csrc/geo_table.hip), or None when the GEMM form is
+        in use: {interval, n_int_d, n_int_a, fit_d, amp_d, fit_a, amp_a} (fit = float64 |polynomial - function| between the nodes)."""
+        self._ensure_engine()
+        info = (ctypes.c_double * 7)()
+        if not L.lib().roitr_engine_geo_table_info(self._engine, info):
+            return None
+        keys = ("interval", "n_int_d", "n_int_a", "fit_d", "amp_d", "fit_a", "amp_a")
+        return dict(zip(keys, list(info)))
 
     def __del__(self):
         try:

@@ -259,6 +259,97 @@ def test_geo_embed_fp32_and_split_bf16_against_float64():
         assert err < 3e-6, (split, err)
 
 
+def _geo_ref(d, a, div, wd, bd, wa, ba):
+    def emb(v):   # SinusoidalPositionalEmbedding: [sin(v w0), cos(v w0), sin(v w1), ...]
+        om = v.astype(np.float64)[..., None] * div.astype(np.float64)
+        return np.stack([np.sin(om), np.cos(om)], -1).reshape(*v.shape, len(div) * 2)
+    return emb(d) @ wd.astype(np.float64).T + bd + (emb(a) @ wa.astype(np.float64).T + ba).max(1)
+
+
+def _geo_case(seed, rows, d_max=3.0):
+    rng = np.random.default_rng(seed)
+    C = 256
+    d = (rng.uniform(0, d_max, rows) / 0.2).astype(np.float32)
+    a = (rng.uniform(0, np.pi, (rows, 3)) * 180 / (15 * np.pi)).astype(np.float32)
+    div = np.exp(np.arange(0, C, 2).astype(np.float32) * np.float32(-np.log(10000.0) / C)).astype(np.float32)
+    wd, wa = (rng.normal(size=(C, C)) / 16).astype(np.float32), (rng.normal(size=(C, C)) / 16).astype(np.float32)
+    bd, ba = rng.normal(size=C).astype(np.float32), rng.normal(size=C).astype(np.float32)
+    return d, a, div, wd, bd, wa, ba, _geo_ref(d, a, div, wd, bd, wa, ba)
+
+
+@pytest.mark.parametrize("interval", [2.0, 1.0])
+@pytest.mark.parametrize("rows", [1, 63, 64, 4097, 30000])
+def test_geo_embed_table_against_float64(rows, interval):
+    """The function-table form of the embedding (geo_table.hip, the engine's default) against the float64 evaluation of
+    positional_encoding.py:139-154: closer than the fp32 MFMA form (3e-6 bound above), for ragged row counts."""
+    from roitr_amd import ops
+    d, a, div, wd, bd, wa, ba, _ = _geo_case(rows, rows, d_max=9.5)   # 9.5 m / 0.2 = 47.5 < the 48 tabulated units
+    a[0] = (0.0, 12.0, 6.0)        # the end points of atan2's range
+    d[0] = 0.0
+    ref = _geo_ref(d, a, div, wd, bd, wa, ba)
+    table, nd, na, fit = ops.geo_table_build(dev(div), dev(wd), dev(bd), dev(wa), dev(ba), interval=interval)
+    got = ops.geo_embed_table(dev(d), dev(a), table, interval, nd, na, dev(div), dev(wd), dev(bd), dev(wa), dev(ba))
+    assert got.shape == (rows, 256)
+    err = np.abs(got.cpu().numpy().astype(np.float64) - ref).max() / np.abs(ref).max()
+    assert err < 4e-7, err
+    gemm = ops.geo_embed(dev(d), dev(a), dev(div), dev(wd), dev(bd), dev(wa), dev(ba))
+    assert (got - gemm).abs().max().item() < 3e-6 * np.abs(ref).max()
+
+
+def test_geo_embed_table_serves_values_outside_the_table():
+    """Distances beyond the tabulated range (and a NaN) take the direct evaluation inside the kernel: same result as the GEMM form."""
+    from roitr_amd import ops
+    rows = 700
+    d, a, div, wd, bd, wa, ba, ref = _geo_case(11, rows, d_max=30.0)    # up to 150 units; the table below covers 16
+    table, nd, na, fit = ops.geo_table_build(dev(div), dev(wd), dev(bd), dev(wa), dev(ba), interval=2.0, d_range=16.0)
+    assert (d >= 16.0).sum() > 300 and (d < 16.0).sum() > 30
+    got = ops.geo_embed_table(dev(d), dev(a), table, 2.0, nd, na, dev(div), dev(wd), dev(bd), dev(wa), dev(ba)).cpu().numpy()
+    err = np.abs(got.astype(np.float64) - ref).max() / np.abs(ref).max()
+    assert err < 3e-6, err
+    a2 = a.copy(); a2[5, 1] = 13.9; a2[6, 2] = 40.0                     # angles past 180 / sigma_a: never produced by atan2, still defined
+    got2 = ops.geo_embed_table(dev(d), dev(a2), table, 2.0, nd, na, dev(div), dev(wd), dev(bd), dev(wa), dev(ba))
+    gemm2 = ops.geo_embed(dev(d), dev(a2), dev(div), dev(wd), dev(bd), dev(wa), dev(ba))
+    assert (got2 - gemm2).abs().max().item() < 3e-6 * np.abs(ref).max()
+    d3 = d.copy(); d3[3] = np.nan
+    got3 = ops.geo_embed_table(dev(d3), dev(a), table, 2.0, nd, na, dev(div), dev(wd), dev(bd), dev(wa), dev(ba)).cpu().numpy()
+    assert np.isnan(got3[3]).all() and np.array_equal(got3[4:], got[4:]) and np.array_equal(got3[:3], got[:3])
+
+
+def test_geo_embed_table_bf16_output_is_the_rounded_fp32_output():
+    from roitr_amd import ops
+    d, a, div, wd, bd, wa, ba, ref = _geo_case(12, 5000)
+    table, nd, na, fit = ops.geo_table_build(dev(div), dev(wd), dev(bd), dev(wa), dev(ba))
+    args = (dev(d), dev(a), table, 2.0, nd, na, dev(div), dev(wd), dev(bd), dev(wa), dev(ba))
+    full = ops.geo_embed_table(*args)
+    half = ops.geo_embed_table(*args, out_bf16=True)
+    assert half.dtype == torch.bfloat16 and torch.equal(half, full.to(torch.bfloat16))
+
+
+def test_engine_uses_the_table_and_agrees_with_the_gemm_form():
+    """Default engine: the table is in use, its measured fit error is below 2^-25 of the amplitude; ROITR_GEO_TABLE=0 brings the
+    fp32 MFMA form back and the descriptors of the two engines agree to fp32 noise."""
+    from gpu_util import build_model, pair_to_device
+    from roitr_amd import synthetic
+    pair = pair_to_device(synthetic.make_pair(3000, config=2, pair_index=5))
+    model = build_model("3DMatch")
+    info = model.geo_table_info()
+    assert info is not None and info["interval"] in (2.0, 1.0, 0.5)
+    assert info["fit_d"] < 2.0 ** -25 * info["amp_d"] and info["fit_a"] < 2.0 ** -25 * info["amp_a"]
+    with torch.no_grad():
+        out = model.forward(**pair)
+    os.environ["ROITR_GEO_TABLE"] = "0"
+    try:
+        plain = build_model("3DMatch")
+        assert plain.geo_table_info() is None
+        with torch.no_grad():
+            ref = plain.forward(**pair)
+    finally:
+        del os.environ["ROITR_GEO_TABLE"]
+    for k in ("src_node_feats", "tgt_node_feats", "src_point_feats", "tgt_point_feats"):
+        assert (out[k] - ref[k]).abs().max().item() < 2e-5, k
+    assert torch.equal(out["src_nodes"], ref["src_nodes"])
+
+
 def test_gemm_rows_do_not_depend_on_the_row_count():
     """The same rows through a 3-tile launch and through a 1094-tile launch come out bit for bit the same (what keeps a one-pair
     forward identical to the same pair inside a batch)."""
