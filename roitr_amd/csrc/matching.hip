@@ -554,10 +554,37 @@ __global__ __launch_bounds__(256) void fine_flag_kernel(RoitrFine a)
     const float* sc = a.ot + (size_t)patch * (L + 1) * (L + 1);
     for (int e = tid; e < L * L; e += 256) { const int i = e >> 6, j = e & 63; E[i][j] = expf(sc[i * (L + 1) + j]); }
     __syncthreads();
-    for (int r = wave; r < 64; r += 4) {
-        const unsigned long long mr = topk_mask(E[r][lane], a.k, a.conf);
-        const unsigned long long mc = topk_mask(E[lane][r], a.k, a.conf);
-        if (lane == 0) { rowm[r] = mr; colm[r] = mc; }
+    if (a.k <= 4) {
+        // wave 0: lane = row, wave 1: lane = column.  One pass over the 64 entries keeps the k best in registers (strict >
+        // against entries met earlier: the lower index stays ahead among equals, the order topk_mask peels them off in);
+        // E[lane][j] / E[j][lane] are conflict-free (row pitch 65).  ~64 x 12 VALU per wave instead of 96 wave-wide maxima.
+        if (wave < 2) {
+            float bv[4] = {-1.f, -1.f, -1.f, -1.f};
+            int bi[4] = {0, 0, 0, 0};
+#pragma unroll 8
+            for (int j = 0; j < 64; ++j) {
+                float x = wave == 0 ? E[lane][j] : E[j][lane];
+                int xi = j;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const bool up = x > bv[t];
+                    const float tv = bv[t]; const int ti = bi[t];
+                    bv[t] = up ? x : tv; bi[t] = up ? xi : ti;
+                    x = up ? tv : x; xi = up ? ti : xi;
+                }
+            }
+            unsigned long long m = 0ull;
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                if (t < a.k && bv[t] >= 0.f && bv[t] > a.conf) m |= 1ull << bi[t];
+            if (wave == 0) rowm[lane] = m; else colm[lane] = m;
+        }
+    } else {
+        for (int r = wave; r < 64; r += 4) {
+            const unsigned long long mr = topk_mask(E[r][lane], a.k, a.conf);
+            const unsigned long long mc = topk_mask(E[lane][r], a.k, a.conf);
+            if (lane == 0) { rowm[r] = mr; colm[r] = mc; }
+        }
     }
     __syncthreads();
     const int i = tid >> 2, j0 = (tid & 3) * 16;
