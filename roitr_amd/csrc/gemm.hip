@@ -479,6 +479,13 @@ extern "C" int roitr_gemm(const RoitrGemm* g, hipStream_t stream)
     // Prefetch distance 2 (two alternating register sets) changes nothing either (45.7 vs 45.1 ms per forward): the
     // staging loads are not what the waves wait for.  Nor does distance 3 on the small grids of the one-pair-per-call mode
     // (round 2: 4.68 vs 4.65 ms per pair, bitwise the same results): those launches are not waiting for weight loads either.
+    // Round 2, for the short-K layers of levels 1-2 (K = 64 / 128, 1.3 - 5.1 M rows; 1.8 - 3.3 TB/s, 40 - 80 TFLOP/s): a
+    // weights-stationary persistent kernel -- the (64 TN x K) weight block staged once per workgroup, row tiles walked with the
+    // next tile's rows prefetched across the MFMA block, two barriers per tile instead of two per slab, bitwise the results of
+    // this kernel -- measured per shape at 512 pairs: N = 192 / 256 at K = 64 1.57 / 1.96 vs 1.61 / 2.10 ms, N = 384 / 512 at
+    // K = 128 1.44 / 1.83 vs 1.30 / 1.68 ms, and the LayerNorm layers (N = 64 / 128, 1 - 2 resident workgroups per CU under
+    // 57 - 156 KB of LDS) 1.8 / 1.4 vs 1.07 / 0.72 ms; gemm time per step 65.7 vs 55.2 ms.  Removed: re-staging the weights is
+    // not what these launches wait for either.
     // The kernel alone reaches 106 TFLOP/s at K = 2048 and 78 at K = 256 (scripts/bench_gemm.py); the no-memory MFMA
     // ceiling measured on this part is 143-157 TFLOP/s (scripts/micro/mfma_peak.hip).
     static const bool dma = getenv("ROITR_GEMM_DMA") != nullptr;

@@ -171,10 +171,21 @@ def _bf16_flags(bf16, x, weight, out_bf16):
     return x.contiguous().float(), w, flags
 
 
-def linear(x, weight, bias=None, relu=False, alpha=1.0, bf16=False, out_bf16=False):
+def _k_cat(g, x, x_cat, keep):
+    """RoitrGemm::A_cat: the product reads [x | x_cat] along K without the concatenation ever existing (fp32 fast path only)."""
+    if x_cat is None:
+        return
+    xc = x_cat.contiguous().float()
+    keep.append(xc)
+    g.A_cat, g.lda_cat, g.k_cat = L.ptr(xc), xc.shape[1], x.shape[1]
+    g.K = x.shape[1] + xc.shape[1]
+
+
+def linear(x, weight, bias=None, relu=False, alpha=1.0, bf16=False, out_bf16=False, x_cat=None):
     """act(alpha * x @ weight.T + bias): the kernel behind every nn.Linear of the path.  Default: the fp32 MFMA GEMM.
     bf16=True: the bf16-operand kernel (csrc/gemm_bf16.hip; weights stored bf16, fp32 accumulate); x may be a bfloat16
-    tensor (stored-bf16 activation), out_bf16 stores the result in bf16."""
+    tensor (stored-bf16 activation), out_bf16 stores the result in bf16.  x_cat: a second operand block, the product is
+    [x | x_cat] @ weight.T (the K-concatenated A of the folded block transformers)."""
     x, weight, flags = _bf16_flags(bf16, x, weight, out_bf16)
     M, K = x.shape
     N = weight.shape[0]
@@ -183,11 +194,15 @@ def linear(x, weight, bias=None, relu=False, alpha=1.0, bf16=False, out_bf16=Fal
     g = _Gemm(M, N, K, L.ptr(x), L.ptr(None), K, L.ptr(None), 0, L.ptr(weight), K, L.ptr(None), 0, L.ptr(b), float(alpha), int(relu),
               L.ptr(out), N, 1, 0, 0, 0, 0, 0, 0, L.ptr(None), 0, 0)
     g.bf16 = flags
+    keep = []
+    _k_cat(g, x, x_cat, keep)
+    g.ldw = weight.shape[1]
     L.check(L.lib().roitr_gemm(ctypes.byref(g), L.stream_ptr()), "gemm")
     return out
 
 
-def linear_layernorm(x, weight, bias, gamma, beta, res=None, res_idx=None, post=None, relu=False, eps=1e-5, bf16=False, out_bf16=False):
+def linear_layernorm(x, weight, bias, gamma, beta, res=None, res_idx=None, post=None, relu=False, eps=1e-5, bf16=False, out_bf16=False,
+                     x_cat=None):
     """[relu](LayerNorm(x @ weight.T + bias + res[res_idx]) * gamma + beta + post) in ONE launch (64 / 128 / 256 output
     channels): the nn.Linear -> (+ residual) -> nn.LayerNorm call sites of attention.py:319, model/model.py:89-97,138-140.
     bf16 / out_bf16 as in linear()."""
@@ -200,6 +215,9 @@ def linear_layernorm(x, weight, bias, gamma, beta, res=None, res_idx=None, post=
     g = _Gemm(M, N, K, L.ptr(x), L.ptr(None), K, L.ptr(None), 0, L.ptr(weight), K, L.ptr(None), 0, L.ptr(b), 1.0, 0,
               L.ptr(out), N, 1, 0, 0, 0, 0, 0, 0, L.ptr(None), 0, 0, L.ptr(gm), L.ptr(bt), L.ptr(rs), L.ptr(ri), L.ptr(po), int(relu), float(eps))
     g.bf16 = flags
+    keep = []
+    _k_cat(g, x, x_cat, keep)
+    g.ldw = weight.shape[1]
     L.check(L.lib().roitr_gemm(ctypes.byref(g), L.stream_ptr()), "gemm+layernorm")
     return out
 

@@ -362,3 +362,21 @@ def test_gemm_rows_do_not_depend_on_the_row_count():
         big = ops.linear(x, w, b, relu=True)
         small = ops.linear(x[:156].contiguous(), w, b, relu=True)
         assert torch.equal(big[:156], small)
+
+
+@pytest.mark.parametrize("N,K,Kc", [(64, 64, 64), (128, 128, 128), (256, 64, 192)])
+def test_gemm_k_concatenated_operand(N, K, Kc):
+    """RoitrGemm::A_cat -- [x | x_cat] @ W^T without the concatenation (the folded block transformers: K = H + I): bitwise the
+    product of the concatenated operand, plain and with the fused LayerNorm epilogue."""
+    from roitr_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(100 + N + K)
+    M = 70037
+    x, xc = torch.randn((M, K), generator=g).cuda(), torch.randn((M, Kc), generator=g).cuda()
+    w = (torch.randn((N, K + Kc), generator=g) / (K + Kc) ** 0.5).cuda()
+    b, gam, bet = (torch.randn((N,), generator=g).cuda() for _ in range(3))
+    xx = torch.cat([x, xc], 1).contiguous()
+    assert torch.equal(ops.linear(x, w, b, relu=True, x_cat=xc), ops.linear(xx, w, b, relu=True))
+    if N <= 256:
+        assert torch.equal(ops.linear_layernorm(x, w, b, gam, bet, x_cat=xc), ops.linear_layernorm(xx, w, b, gam, bet))
+    ref = (xx[:2048].double() @ w.double().T + b.double()).clamp_min(0)
+    assert (ops.linear(x, w, b, relu=True, x_cat=xc)[:2048].double() - ref).abs().max().item() < 1e-4
