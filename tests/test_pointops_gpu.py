@@ -48,6 +48,25 @@ def test_fps_bit_exact(kind, sizes):
     assert got.dtype == np.int32 and np.array_equal(got, ref)
 
 
+@pytest.mark.parametrize("kind", ["uniform", "lattice"])
+@pytest.mark.parametrize("n_clouds,n", [(40, 1250), (24, 5000), (33, 313)])
+def test_fps_bit_exact_many_clouds(kind, n_clouds, n):
+    """More than 16 clouds per call take the 4-wave workgroups of the batched forward, 16 or fewer the 8-wave ones of the one-pair
+    mode (pointops_fps.hip launcher): the indices are the same either way, and the same as the oracle's."""
+    from roitr_amd import pointops as P
+    rng = np.random.default_rng(hash((kind, n_clouds, n)) % 2**32)
+    sizes = [n - (i % 3) for i in range(n_clouds)]
+    xyz = np.concatenate([cloud(rng, m, kind) for m in sizes])
+    off = np.cumsum(sizes).astype(np.int32)
+    noff = np.cumsum([max(m // 4, 1) for m in sizes]).astype(np.int32)
+    ref = O.furthestsampling(xyz, off, noff)
+    got = P.furthestsampling(dev(xyz), dev(off), dev(noff)).cpu().numpy()
+    assert np.array_equal(got, ref)
+    # the first 8 clouds alone (8-wave workgroups) reproduce their part of the batched call
+    few = P.furthestsampling(dev(xyz[:off[7]]), dev(off[:8]), dev(noff[:8])).cpu().numpy()
+    assert np.array_equal(few, ref[:noff[7]])
+
+
 def test_fps_golden(golden_pair):
     from roitr_amd import pointops as P
     g = golden_pair
