@@ -1391,6 +1391,9 @@ extern "C" int roitr_knnquery_ex(int b, int n, int m, int nsample, const float* 
     }
     static const int lane_min = [] { const char* e = getenv("ROITR_KNN_LANE_MIN"); return e ? atoi(e) : 8192; }();
     static const bool lane_brute = getenv("ROITR_KNN_NO_LANE_BRUTE") == nullptr;
+    // small clouds without a grid: a lane per query once there are enough queries to fill the chip that way; below that a wave
+    // per query (one pair per call: 624 queries at level 3 were 10 waves scanning 1250 references each, 152 us per call)
+    static const int lane_brute_min = [] { const char* e = getenv("ROITR_KNN_LANE_BRUTE_MIN"); return e ? atoi(e) : 65536; }();
     static const bool gridsel = getenv("ROITR_KNN_NO_GRIDSEL") == nullptr;
     static const bool cellk = getenv("ROITR_KNN_NO_CELL") == nullptr;
     const bool lane_ok = use_grid && m >= lane_min && (!ppf || group_idx) && b > 0;
@@ -1425,7 +1428,7 @@ extern "C" int roitr_knnquery_ex(int b, int n, int m, int nsample, const float* 
         if (nsample + 1 <= 66) LANE_CASE(66); else LANE_CASE(101);
     } else
 #undef LANE_CASE
-    if (!use_grid && nsample + 1 <= 34 && (!ppf || group_idx) && lane_brute) {
+    if (!use_grid && nsample + 1 <= 34 && (!ppf || group_idx) && lane_brute && m >= lane_brute_min) {
 #define LB_CASE(LC) knn_lane_brute_kernel<LC><<<div_up(m, 64), 64, 0, stream>>>(m, nsample, b, xyz, new_xyz, offset, new_offset, o)
         const int need = nsample + 1;
         if (need <= 2) LB_CASE(2); else if (need <= 4) LB_CASE(4); else if (need <= 10) LB_CASE(10);
