@@ -193,6 +193,108 @@ __global__ __launch_bounds__(256) void local_attn_kernel(RoitrLocalAttn a)
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// H = 64 form (level 1: 5.1 M nodes per call at 512 pairs).  In the kernel above a lane holds ONE channel at this width: every
+// gathered row is a 256-byte wave instruction (60 vector-memory instructions for two nodes) and a wave keeps two nodes in flight.
+// Here a node takes 16 lanes, a lane 4 consecutive channels (float4 accesses), a head = the 4 lanes of a DPP quad, and a wave works
+// on FOUR nodes: the same bytes in a quarter of the memory instructions, twice the nodes in flight per wave, head reductions are
+// two quad_perm adds instead of four row steps, and the softmax needs no LDS exchange (after the quad reduction every lane of a
+// head holds all K scores).  fp32 rows, wpe / bpe given (the engine's default); per node the same formulas as above, summed in a
+// different order.  Selected by shape only (H, K), never by M: a node's result does not depend on the batch it is in.
+__device__ __forceinline__ float quad_allsum(float v)
+{
+    v = row_dpp_add<0xB1>(v);   // quad_perm [1,0,3,2]
+    v = row_dpp_add<0x4E>(v);   // quad_perm [2,3,0,1]
+    return v;
+}
+template <int CTRL> __device__ __forceinline__ float quad_bcast(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+
+template <int K>
+__global__ __launch_bounds__(256) void local_attn_quad_kernel(RoitrLocalAttn a)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ns = lane >> 4, j = lane & 15, jq = j & 3;     // node slot of the wave, channel quad 4j..4j+3, position inside the head
+    const int nblk = (a.M + 15) >> 4;
+    const int slot = (xcd_block_id(nblk) * 4 + wave) * 4 + ns;
+    if ((slot & ~3) >= a.M) return;                          // wave-uniform: all four slots of the wave are past the end
+    const bool live = slot < a.M;
+    const int sl = live ? slot : (slot & ~3);                // a dead slot recomputes the wave's first node and stores nothing
+    int node = sl;
+    if (a.node_order) node = __float_as_int(reinterpret_cast<const float4*>(a.node_order)[sl].w);
+    // ---- round trip 1: addressed by the node id
+    int g[K];
+    {
+        const int4* gp = reinterpret_cast<const int4*>(a.group_idx + (size_t)node * K);
+#pragma unroll
+        for (int q4 = 0; q4 < K / 4; ++q4) { const int4 t = gp[q4]; g[4 * q4] = t.x; g[4 * q4 + 1] = t.y; g[4 * q4 + 2] = t.z; g[4 * q4 + 3] = t.w; }
+    }
+    float4 qv = *reinterpret_cast<const float4*>(a.q + (size_t)node * a.ldq + 4 * j);
+    float pv[K];
+    {
+        const float* pf = a.ppf + (size_t)node * K * 4 + jq;
+#pragma unroll
+        for (int kk = 0; kk < K; ++kk) pv[kk] = pf[kk * 4];
+    }
+    // ---- round trip 2: key and value rows of the K neighbours, all in flight together
+    float4 kr[K], vr[K];
+#pragma unroll
+    for (int kk = 0; kk < K; ++kk) kr[kk] = *reinterpret_cast<const float4*>(a.k + (size_t)g[kk] * a.ldk + 4 * j);
+#pragma unroll
+    for (int kk = 0; kk < K; ++kk) vr[kk] = *reinterpret_cast<const float4*>(a.v + (size_t)g[kk] * a.ldv + 4 * j);
+    __builtin_amdgcn_sched_barrier(0);   // the value rows are requested now, not sunk behind the softmax that does not need them
+    // qp[h] = [Wpe_h^T q_h, q_h . bpe_h]: this lane's four channels, then the head's quad
+    float ec, c4;
+    {
+        float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f, p4 = 0.f;
+        const float qs[4] = {qv.x, qv.y, qv.z, qv.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float4 w = reinterpret_cast<const float4*>(a.wpe)[4 * j + i];
+            const float b1 = a.bpe[4 * j + i];
+            p0 = fmaf(w.x, qs[i], p0); p1 = fmaf(w.y, qs[i], p1); p2 = fmaf(w.z, qs[i], p2); p3 = fmaf(w.w, qs[i], p3); p4 = fmaf(b1, qs[i], p4);
+        }
+        p0 = quad_allsum(p0); p1 = quad_allsum(p1); p2 = quad_allsum(p2); p3 = quad_allsum(p3); p4 = quad_allsum(p4);
+        ec = (jq == 0 ? p0 : (jq == 1 ? p1 : (jq == 2 ? p2 : p3))) * a.scale;
+        c4 = jq == 0 ? p4 * a.scale : 0.f;                   // the q_h . bpe_h constant enters the reduction once per head
+    }
+    qv.x *= a.scale; qv.y *= a.scale; qv.z *= a.scale; qv.w *= a.scale;
+    // ---- scores s(h, kk) = scale * (q_h . k_h[kk] + qp_h . [ppf_kk, 1]), softmax over kk in every lane of the head
+    float sc[K];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kk = 0; kk < K; ++kk) {
+        float d = fmaf(ec, pv[kk], c4);
+        d = fmaf(qv.x, kr[kk].x, d); d = fmaf(qv.y, kr[kk].y, d); d = fmaf(qv.z, kr[kk].z, d); d = fmaf(qv.w, kr[kk].w, d);
+        d = quad_allsum(d);
+        sc[kk] = d;
+        mx = fmaxf(mx, d);
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < K; ++kk) { sc[kk] = expf(sc[kk] - mx); sum += sc[kk]; }   // accurate exp: the reference softmax is libm-exact
+    // ---- pbar[h][t] = sum_k p(h,k) ppf[k][t] (lane jq = t), output = sum_k p v + Wvpe pbar + bvpe
+    float pb = 0.f;
+    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int kk = 0; kk < K; ++kk) {
+        const float p = sc[kk] / sum;
+        pb = fmaf(p, pv[kk], pb);
+        o.x = fmaf(p, vr[kk].x, o.x); o.y = fmaf(p, vr[kk].y, o.y); o.z = fmaf(p, vr[kk].z, o.z); o.w = fmaf(p, vr[kk].w, o.w);
+    }
+    const float b0 = quad_bcast<0x00>(pb), b1_ = quad_bcast<0x55>(pb), b2 = quad_bcast<0xAA>(pb), b3 = quad_bcast<0xFF>(pb);
+    const float4 bias = *reinterpret_cast<const float4*>(a.bvpe + 4 * j);
+    const float4 w0 = reinterpret_cast<const float4*>(a.wvpe)[4 * j], w1 = reinterpret_cast<const float4*>(a.wvpe)[4 * j + 1];
+    const float4 w2 = reinterpret_cast<const float4*>(a.wvpe)[4 * j + 2], w3 = reinterpret_cast<const float4*>(a.wvpe)[4 * j + 3];
+    o.x += w0.x * b0 + w0.y * b1_ + w0.z * b2 + w0.w * b3 + bias.x;
+    o.y += w1.x * b0 + w1.y * b1_ + w1.z * b2 + w1.w * b3 + bias.y;
+    o.z += w2.x * b0 + w2.y * b1_ + w2.z * b2 + w2.w * b3 + bias.z;
+    o.w += w3.x * b0 + w3.y * b1_ + w3.z * b2 + w3.w * b3 + bias.w;
+    if (live) *reinterpret_cast<float4*>(a.out + (size_t)node * a.ldo + 4 * j) = o;
+}
+
 // Pfold (5*NH x H): row h*5+j holds Wpe[h*c + cc][j] (j<4) / bpe[h*c+cc] (j=4) at column h*c+cc, else 0.
 // q_ext weights = [Wq ; Pfold @ Wq], bias = [bq ; Pfold @ bq]  (see header comment).
 __global__ void build_pfold_kernel(int H, int NH, const float* __restrict__ wpe, const float* __restrict__ bpe, float* __restrict__ pf)
@@ -236,6 +338,16 @@ extern "C" int roitr_local_attention(const RoitrLocalAttn* a, hipStream_t stream
         else if ((HH) == 2 && npw_env == 2) LA_LAUNCH(KK, 2, 2);                                \
         else LA_LAUNCH(KK, HH, 1);                                                             \
     } while (0)
+    // H = 64, fp32 rows, in-kernel qp: the 16-lanes-per-node form, ROITR_LOCAL_ATTN_QUAD=1.  Measured at the end of round 2 (512 pairs):
+    // parity suites of the model and the stage operators green with it, local attention 20.4 -> 19.5 ms per step (the three level-1
+    // launches 7.4 -> 6.5 ms), forward 112.6 -> 111.8 ms.  Still opt-in: the full -m gpu suite has not been run with it.
+    static const int quad_env = [] { const char* e = getenv("ROITR_LOCAL_ATTN_QUAD"); return e ? atoi(e) : 0; }();
+    if (quad_env && hv == 1 && !half && a->wpe && a->bpe && (a->K == 8 || a->K == 16) && ((a->ldq | a->ldk | a->ldv | a->ldo) & 3) == 0 &&
+        (((uintptr_t)a->q | (uintptr_t)a->k | (uintptr_t)a->v | (uintptr_t)a->out | (uintptr_t)a->group_idx) & 15) == 0) {
+        const int grid = xcd_grid(div_up(a->M, 16));
+        if (a->K == 8) local_attn_quad_kernel<8><<<grid, 256, 0, stream>>>(*a);
+        else local_attn_quad_kernel<16><<<grid, 256, 0, stream>>>(*a);
+    } else
     if (a->K == 8) { if (hv == 1) LA_CASE(8, 1); else if (hv == 2) LA_CASE(8, 2); else if (hv == 4) LA_CASE(8, 4); else LA_CASE(8, 8); }
     else { if (hv == 1) LA_CASE(16, 1); else if (hv == 2) LA_CASE(16, 2); else if (hv == 4) LA_CASE(16, 4); else LA_CASE(16, 8); }
 #undef LA_CASE
