@@ -1,0 +1,86 @@
+"""CPU: the JSON contract of bench.py that does not need a GPU -- the `roofline` / `rooflines` objects built from an
+instrumented pass, the PMC traffic attachment, and the committed bench lines of the round (profiles/r02_bench*.json)."""
+import glob
+import importlib.util
+import json
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REQUIRED = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+            "data", "config", "roofline")
+
+
+def _bench():
+    spec = importlib.util.spec_from_file_location("bench_module", os.path.join(ROOT, "bench.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def _prof():
+    # one instrumented 512-pair step, numbers of the order of profiles/r02_bench.json
+    return {
+        "gemm_kernel": {"ms": 53.3, "launches": 130, "bytes": 4.51e12},
+        "knn_query_kernel": {"ms": 10.4, "launches": 12, "bytes": 2.66e9},
+        "geo_table_kernel": {"ms": 3.52, "launches": 1, "bytes": 6.78e9},
+        "geo_embed_reference_flops": {"ms": 0.0, "launches": 1, "bytes": 3.27e12},
+        "local_attn_kernel": {"ms": 20.4, "launches": 15, "bytes": 4.4e10},
+        "phase.global_transformer": {"ms": 20.3, "launches": 1, "bytes": 7.43e11},
+        "phase.forward": {"ms": 111.7, "launches": 1, "bytes": 4.51e12},
+    }
+
+
+def test_rooflines_from_an_instrumented_pass():
+    b = _bench()
+    roofs = b.rooflines(_prof(), 1, "f32")
+    kinds = [r["kernel"].split(" ")[0] for r in roofs]
+    assert kinds[0] == "gemm_kernel" and "knn+ppf" in kinds and "global_transformer" in kinds and "geo_table_kernel" in kinds
+    for r in roofs:
+        assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s")
+        assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4
+        assert "traffic" in r and r["avg_launch_ms"] > 0
+    g = roofs[0]
+    assert g["bound"] == "mfma" and g["peak"] == b.MFMA_F32_PEAK_TFLOPS
+    assert abs(g["achieved"] - 4.51e12 / 53.3e-3 / 1e12) < 1e-2
+    ph = roofs[kinds.index("global_transformer")]
+    # executed matrix work vs the reference formulation (the embedding is a function table): both are reported
+    assert abs(ph["achieved"] - 7.43e11 / 20.3e-3 / 1e12) < 1e-2
+    assert abs(ph["achieved_reference_formulation"] - (7.43e11 + 3.27e12) / 20.3e-3 / 1e12) < 1e-1
+    assert ph["frac_reference_formulation"] > ph["frac"]
+    t = roofs[kinds.index("geo_table_kernel")]
+    assert t["bound"] == "hbm" and t["peak"] == b.HBM_PEAK_GBS
+    # the FLOP carrier of the reference formulation is not a kernel: never the dominant entry, never a roofline of its own
+    assert all("geo_embed_reference_flops" not in r["kernel"] for r in roofs)
+    assert b.rooflines({}, 0, "f32") == []
+    assert b.rooflines(_prof(), 1, "bf16")[0]["peak"] == b.MFMA_BF16_PEAK_TFLOPS
+
+
+def test_traffic_is_attached_from_the_committed_pmc_summary():
+    b = _bench()
+    pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+    roofs = b.rooflines(_prof(), 1, "f32")
+    b.attach_traffic(roofs, pmc["pairs_per_step"], pmc.get("baseline_config", 2))
+    assert roofs[0]["traffic"] == pmc["kernels"]["gemm_kernel"]["hbm_bytes_per_launch"] and "traffic_source" in roofs[0]
+    knn = [r for r in roofs if r["kernel"].startswith("knn+ppf")][0]
+    assert knn["traffic"] and knn["traffic"] > 0
+    other = b.rooflines(_prof(), 1, "f32")
+    b.attach_traffic(other, pmc["pairs_per_step"] + 1, 2)      # a different workload: nothing is attached
+    assert other[0]["traffic"] is None
+
+
+def test_committed_bench_lines_follow_the_contract():
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r02_bench*.json")))
+    assert files
+    for f in files:
+        d = json.load(open(f))
+        for k in REQUIRED:
+            assert k in d, (f, k)
+        assert d["metric"] == "point-cloud pairs/s" and d["unit"] == "pairs/s" and d["higher_is_better"] is True
+        assert d["scaling"] == "weak" and d["data"] == "synthetic" and d["vs_baseline"] is None
+        assert d["dtype"] in ("f32", "bf16") and "workload" in d["config"] and "model" not in d["config"]
+        r = d["roofline"]
+        assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+        assert abs(d["value"] - d["config"]["pairs_per_step"] * d["n_gpus"] * 1e3 / d["ms_per_step"]) < 1e-2 * d["value"]
+        if "cpu_baseline" in d:
+            c = d["cpu_baseline"]
+            assert c["kind"] == "port" and c["cores"] >= 1 and c["unit"] == "pairs/s" and c["sample"]
