@@ -988,14 +988,7 @@ __global__ __launch_bounds__(1024) void sort_queries_kernel(const float* __restr
 // queries are taken in CELL ORDER (the counting-sorted order), so the 64 lanes of a wave search neighbouring cells:
 // their trip counts agree and their candidate loads hit the same cache lines.  Same exactness rule as the wave
 // kernel: ties among the best nsample+1 distances -> the query goes to the replay kernel.
-// PEND > 0 (opt-in, ROITR_KNN_PEND=1): deferred insertion.  The branch-free sorted insertion costs ~4 L instructions and, with a lane
-// per query, runs for the whole wave whenever ANY lane has a candidate below its current worst -- i.e. for nearly every candidate
-// (17 k VALU instructions per query at L = 10, SQ pass of round 2), although a single lane accepts only ~k ln(n / k) of them.
-// Here an accepted candidate is only appended to a per-lane pending column in LDS (one ds_write); the insertion chain runs in
-// rounds when some lane's column is full and at the end of every ring, each round serving every lane that has something
-// pending.  The list ends as the same L smallest distances (insertion order only permutes equal distances, and a tie among the
-// best nsample + 1 goes to the replay either way); a candidate accepted against a stale worst is dropped by the chain's own guard.
-template <int L, int PEND = 0>
+template <int L>
 __global__ __launch_bounds__(256) void knn_lane_kernel(int m, int nsample, int b, const float* __restrict__ xyz,
                                                        const float* __restrict__ new_xyz, const int* __restrict__ offset,
                                                        const int* __restrict__ new_offset, const RoitrGrid* __restrict__ grids,
@@ -1022,9 +1015,7 @@ __global__ __launch_bounds__(256) void knn_lane_kernel(int m, int nsample, int b
 #pragma unroll
         for (int a = 0; a < 3; ++a) c0[a] = (int)fminf(fmaxf(tq[a], 0.f), (float)(dim[a] - 1));
     }
-    __shared__ float2 pend_s[PEND > 0 ? PEND * 256 : 1];
-    int cnt = 0;
-    auto insert = [&](float dd, int ci) {
+    auto offer = [&](float dd, int ci) {
         if (dd < d[L - 1]) {
 #pragma unroll
             for (int j = L - 1; j > 0; --j) {
@@ -1034,22 +1025,6 @@ __global__ __launch_bounds__(256) void knn_lane_kernel(int m, int nsample, int b
             }
             const bool h0 = d[0] > dd;
             d[0] = h0 ? dd : d[0]; id[0] = h0 ? ci : id[0];
-        }
-    };
-    auto flush = [&]() {   // the active lanes empty their pending columns, one entry per round
-        if (PEND > 0) {
-            while (__any(cnt > 0)) {
-                float dd = INFINITY; int ci = 0;
-                if (cnt > 0) { --cnt; const float2 e = pend_s[cnt * 256 + threadIdx.x]; dd = e.x; ci = __float_as_int(e.y); }
-                insert(dd, ci);
-            }
-        }
-    };
-    auto offer = [&](float dd, int ci) {
-        if (PEND == 0) insert(dd, ci);
-        else {
-            if (dd < d[L - 1]) { pend_s[cnt * 256 + threadIdx.x] = make_float2(dd, __int_as_float(ci)); ++cnt; }
-            if (__any(cnt >= PEND)) flush();
         }
     };
     auto scan = [&](int s, int e) {
@@ -1085,7 +1060,6 @@ __global__ __launch_bounds__(256) void knn_lane_kernel(int m, int nsample, int b
                 }
             }
         }
-        flush();   // the ring is complete: the list is final before the stop rule reads it
         float dmin = INFINITY;
         if (x0 > 0) dmin = fminf(dmin, qx - __fmaf_rn((float)x0, g.h, g.ox));
         if (x1 < g.nx - 1) dmin = fminf(dmin, __fmaf_rn((float)(x1 + 1), g.h, g.ox) - qx);
@@ -1432,14 +1406,9 @@ extern "C" int roitr_knnquery_ex(int b, int n, int m, int nsample, const float* 
         qorder = v.qorder;
         sort_queries_kernel<<<b, 1024, 0, stream>>>(new_xyz, new_offset, v.grids, qorder);
     }
-    static const bool pend = [] { const char* e = getenv("ROITR_KNN_PEND"); return e && atoi(e) != 0; }();   // opt-in: deferred insertion
 #define LANE_CASE(LC)                                                                                                        \
-    do {                                                                                                                     \
-        if (pend) knn_lane_kernel<LC, 8><<<div_up(m, 256), 256, 0, stream>>>(m, nsample, b, xyz, new_xyz, offset, new_offset, v.grids, \
-                                                                             v.cell_start, v.sorted, o, self_sorted, qorder, g_knn_cap2); \
-        else knn_lane_kernel<LC><<<div_up(m, 256), 256, 0, stream>>>(m, nsample, b, xyz, new_xyz, offset, new_offset, v.grids, v.cell_start, \
-                                                                     v.sorted, o, self_sorted, qorder, g_knn_cap2);          \
-    } while (0)
+    knn_lane_kernel<LC><<<div_up(m, 256), 256, 0, stream>>>(m, nsample, b, xyz, new_xyz, offset, new_offset, v.grids, v.cell_start, \
+                                                             v.sorted, o, self_sorted, qorder, g_knn_cap2)
     static const int sel_min = [] { const char* e = getenv("ROITR_KNN_SEL_MIN"); return e ? atoi(e) : 35; }();   // nsample + 1 from which the selection kernel takes over
     if (lane_ok && nsample + 1 <= 34 && nsample + 1 < sel_min) {
         const int need = nsample + 1;
