@@ -237,7 +237,9 @@ int roitr_node_occlusion_score(int n_nodes, int limit, const int* cloud_of_node,
                                const int* knn_mask, const int* node_masks, const float* d2_padded, float overlap_thres,
                                float* out, roitr_stream_t stream);
 /* lib/utils.py:530-614 (ref = tgt, src = src).  overlap: scratch (pairs, mat_stride >= max_nodes^2);
- * out_idx (pairs, mat_stride, 2) [ref, src] local node indices in torch.nonzero order, out_overlap, out_count (pairs). */
+ * out_idx (pairs, mat_stride, 2) [ref, src] local node indices in torch.nonzero order, out_overlap, out_count (pairs).
+ * During the call out_idx / out_count[0] also carry the work list of node pairs that survive the enclosing-sphere prune (they are
+ * rewritten by the final compaction); pairs * max_nodes^2 must stay below 2^31. */
 typedef struct RoitrNodeCorr {
     int pairs, limit, max_nodes;
     float pos_radius;
