@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Headline benchmark: RoITr test-mode forward throughput in point-cloud pairs/s on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config 2|3|4] [--pairs-per-step B] [--n-points N]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config 2|3|4|5] [--pairs-per-step B] [--n-points N]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -12,15 +12,21 @@ transport, fine matching, ground-truth side outputs.  Workloads (BASELINE.json `
     --config 3            the same with the test-time rotation of dataset/tdmatch.py:99-112 (3DLoMatch rotated, configs[2])
     --config 4            4DMatch settings (factor 2, adaptive coarse matching, top-2), 8000 pts/cloud, bf16 operand
                           storage for the dense layers (configs[3])
+    --config 5            kernel micro-benchmark of configs[4]: kNN(64 neighbours) + fused PPF on 32 clouds x 30000 points, one
+                          call per step (roitr_amd.pointops.knn_ppf: grid build + query + PPF); its line reports queries/s, the
+                          HBM fraction on algorithmic bytes and the VALU-issue fraction of the committed SQ pass
 `--pairs-per-step 1` times the reference's own one-pair-per-forward loop verbatim.
 Inputs are resident in HBM before the timed region.  Pairs shard over ranks with no data-path collective (weak scaling:
-every rank runs the same per-step work on its own pairs); the one collective of the path -- the gather of the per-pair
-result records (match scores) to rank 0, shard.gather_result_records -- runs once at the end, INSIDE the timed region.
+every rank runs the same per-step work on its own pairs); the result records (match scores) of EVERY timed step are packed
+as the steps finish, and the one collective of the path -- their gather to rank 0, shard.gather_result_records -- runs once at
+the end, INSIDE the timed region.  The loop and the cross-rank aggregation live in roitr_amd/benchloop.py (tested on CPU with
+two gloo ranks and a stub engine).
 
 Timing: K steps between barrier + synchronize on both sides with the HIP-event instrumentation OFF -> `value`.
 Rooflines: the same K steps are then run once more with the events of csrc/prof.cpp ON (events recorded on the launch
 stream around each instrumented kernel) -> `roofline` (dominant kernel family) and `rooflines` (+ the two north-star
-entries: kNN+PPF against HBM on algorithmic bytes, the global transformer phase against the MFMA peak).
+entries: kNN+PPF against HBM on algorithmic bytes, the global transformer phase against HBM -- it is the stream of the
+geometric embedding E -- with its executed matrix work against the MFMA peak beside it; + `whole_forward`).
 Prints ONE JSON line (rank 0); `cpu_baseline` = the CPU oracle timed on this host (rank 0, N=1 only).
 """
 import argparse
@@ -43,10 +49,13 @@ WORKLOADS = {
     3: dict(benchmark="3DLoMatch", n_points=5000, pairs=512, dtype="f32", seed_config=3,
             text="3DLoMatch-rotated synthetic pairs: {N} pts/cloud, seeded test-time SO(3) rotation of one cloud "
                  "(dataset/tdmatch.py:99-112), fp32, 3DMatch test settings, full RIGA_v2 forward"),
-    4: dict(benchmark="4DMatch", n_points=8000, pairs=32, dtype="bf16", seed_config=4,
+    4: dict(benchmark="4DMatch", n_points=8000, pairs=32, dtype="bf16", seed_config=4, weights="selective",
             text="4DMatch-sized synthetic pairs: {N} pts/cloud, 4DMatch test settings (factor 2 widths, adaptive coarse matching "
                  "min 128 / thr 0.75, top-2 fine matching), bf16 operand storage in the dense layers (fp32 accumulate; FPS / kNN / "
                  "PPF / OT in fp32), full RIGA_v2 forward"),
+    5: dict(benchmark="3DMatch", n_points=30000, pairs=32, dtype="f32", seed_config=5,
+            text="kNN + PPF stress (BASELINE configs[4]): {B} synthetic clouds x {N} points, k = 64 neighbours (knnquery nsample 65, "
+                 "column 0 dropped) + fused PPF, fp32 distances / int32 indices"),
 }
 
 
@@ -59,12 +68,16 @@ def parse():
     ap.add_argument("--pairs-per-step", type=int, default=None)
     ap.add_argument("--n-points", type=int, default=None)
     ap.add_argument("--dtype", default=None, choices=["f32", "bf16"], help="operand storage of the dense layers (default: the config's)")
+    ap.add_argument("--weights", default=None, choices=["plain", "selective"],
+                    help="closed-form weight variant (roitr_amd/weights.py); default: the config's (plain for 2 / 3, selective for 4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-single-pair", action="store_true", help="skip the one-pair-per-call measurement (profiling passes)")
     ap.add_argument("--no-profile-pass", action="store_true", help="skip the instrumented repeat of the timed steps (no rooflines)")
     ap.add_argument("--no-rccl-selftest", action="store_true",
                     help="N=1 without torch.distributed.run: do NOT create the 1-rank RCCL group the result gather otherwise runs through")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=20.0)
+    ap.add_argument("--record-scores-per-pair", type=int, default=1020,
+                    help="average score capacity per pair of the gathered result block (shard.py); the block carries every timed step")
     return ap.parse_args()
 
 
@@ -83,7 +96,7 @@ def main():
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl")  # RCCL on ROCm
-    elif not args.no_rccl_selftest:
+    elif not args.no_rccl_selftest and args.config != 5:
         # one GPU, no launcher: a 1-rank RCCL group, so that the path's collective goes through RCCL here as well
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", str(29600 + os.getpid() % 300))
@@ -92,19 +105,44 @@ def main():
         except Exception as e:   # e.g. the port is taken: the gather then stays local (reported as backend "local")
             print(f"[bench] 1-rank RCCL group not created: {e}", file=sys.stderr)
 
+    if args.config == 5:
+        out = knn_stress(args, rank, world, distributed)
+    else:
+        out = forward_bench(args, rank, world, distributed)
+    if dist.is_available() and dist.is_initialized():
+        dist.destroy_process_group()
+    if rank == 0:
+        # the JSON line goes out LAST: librccl prints its version banner through C stdio, which is flushed here first
+        import ctypes
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        print(json.dumps(out), flush=True)
+
+
+def forward_bench(args, rank, world, distributed):
+    import gc
+
+    import torch
+    import torch.distributed as dist
+
+    from roitr_amd import benchloop
     from roitr_amd.harness import build_model, pair_to_device
-    from roitr_amd.shard import gather_result_records, pairs_for_rank
+    from roitr_amd.shard import pairs_for_rank
     from roitr_amd.synthetic import make_pair
 
     wl = WORKLOADS[args.config]
     dtype = args.dtype or wl["dtype"]
     B = args.pairs_per_step or wl["pairs"]
     N = args.n_points or wl["n_points"]
-    model = build_model(wl["benchmark"], operand_dtype=dtype)
+    weights = args.weights or wl.get("weights", "plain")
+    normals = "field" if weights == "selective" else "random"
+    model = build_model(wl["benchmark"], operand_dtype=dtype, weights=weights)
     # distinct resident pairs, cycled; pair ids are sharded over ranks exactly like the test loop would
     n_resident = max(B + B // 2, 16)
     ids = pairs_for_rank(n_resident * world, rank, world)
-    pool = [pair_to_device(make_pair(N, config=wl["seed_config"], pair_index=i)) for i in ids]
+    pool = [pair_to_device(make_pair(N, config=wl["seed_config"], pair_index=i, normals=normals)) for i in ids]
 
     def batch(step):
         return [pool[(step * B + j) % len(pool)] for j in range(B)]
@@ -114,44 +152,17 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    max_scores = model.max_scores_per_pair()
-
-    def run_steps(first, steps, gather):
-        """`steps` forwards, two batches in flight: batch s+1 is enqueued before the host unpacks batch s (launch_batch never
-        waits for the GPU), so the device does not idle during the per-pair unpacking.  gather: finish with the one collective
-        of the path carrying the last step's records."""
-        n_corr = 0
-        handle = model.launch_batch(batch(first), want_gt=True)
-        recs = None
-        trace = os.environ.get("ROITR_BENCH_TRACE")
-        t_prev = time.perf_counter()
-        for s in range(steps):
-            nxt = model.launch_batch(batch(first + s + 1), want_gt=True) if s + 1 < steps else None
-            t_l = time.perf_counter()
-            res = model.finish_batch(handle)
-            n_corr += sum(int(r["corr_scores"].shape[0]) for r in res)
-            if trace:
-                t_now = time.perf_counter()
-                print(f"[bench trace] step {s}: launch {1e3 * (t_l - t_prev):.1f} ms, finish {1e3 * (t_now - t_l):.1f} ms", file=sys.stderr)
-                t_prev = t_now
-            if gather and s + 1 == steps:
-                # unique slot ids for the record block: global pair id of the pool entry, made unique per slot of the step
-                rec_ids = [rank + world * j for j in range(B)]
-                block = model.batch_records(handle, rec_ids)
-                recs = gather_result_records(block, B, max_scores)
-            handle = nxt
-        return n_corr, recs
-
-    import gc
+    spp = args.record_scores_per_pair
+    trace = bool(os.environ.get("ROITR_BENCH_TRACE"))
     with torch.no_grad():
         # warm-up with the SAME loop as the timed region (two batches in flight, the collective at the end): the caching
         # allocator then already owns both sets of output buffers, the RCCL communicator exists and the packing kernels are loaded
-        run_steps(0, max(args.warmup, 1), gather=True)
+        benchloop.run_steps(model, batch, B, 0, max(args.warmup, 1), rank, world, True, spp)
         barrier()
         gc.collect()
         gc.disable()   # a generation-2 collection of the result dicts costs ~40 ms every dozen steps
         t0 = time.perf_counter()
-        n_corr_total, records = run_steps(args.warmup, args.steps, gather=True)
+        n_corr_total, records = benchloop.run_steps(model, batch, B, args.warmup, args.steps, rank, world, True, spp, trace)
         barrier()
         dt = time.perf_counter() - t0
         gc.enable()
@@ -162,7 +173,7 @@ def main():
             prof_steps = args.steps
             gc.disable()
             model.profile_reset()
-            run_steps(args.warmup, prof_steps, gather=False)
+            benchloop.run_steps(model, batch, B, args.warmup, prof_steps, rank, world, False, spp)
             torch.cuda.synchronize()
             gc.enable()
             prof = model.profile_read(kernels_only=False)
@@ -188,21 +199,12 @@ def main():
                   "note": "one pair per engine call (the reference's DataLoader batch size), two calls in flight"}
 
     # max over ranks of the timed region; total work = pairs of all ranks
-    if distributed:
-        t = torch.tensor([dt, float(n_corr_total)], dtype=torch.float64, device="cuda")
-        tmax = t.clone()
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
-        dt = float(tmax[0].item())
-        n_corr_all = int(t[1].item())
-    else:
-        n_corr_all = n_corr_total
-    total_pairs = B * args.steps * world
-    value = total_pairs / dt
+    agg = benchloop.aggregate(dt, n_corr_total, B, args.steps)
+    dt = agg["dt"]
 
     out = {
         "metric": "point-cloud pairs/s",
-        "value": round(value, 3),
+        "value": round(agg["value"], 3),
         "unit": "pairs/s",
         "n_gpus": world,
         "steps": args.steps,
@@ -214,12 +216,13 @@ def main():
         "dtype": dtype,
         "data": "synthetic",
         "config": {
-            "workload": wl["text"].format(N=N),
+            "workload": wl["text"].format(N=N, B=B),
             "baseline_config": args.config,
             "pairs_per_step": B,
             "n_points": N,
-            "sharding": f"pairs over {world} rank(s), no data-path collective; one gather of the result records at the end",
-            "correspondences_found": int(n_corr_all),
+            "weights": f"closed-form, variant '{weights}' (roitr_amd/weights.py); normals: {normals}",
+            "sharding": f"pairs over {world} rank(s), no data-path collective; one gather of the result records of all timed steps at the end",
+            "correspondences_found": agg["n_corr"],
         },
     }
     gt = model.geo_table_info()
@@ -230,61 +233,134 @@ def main():
         if gt else "fp32 MFMA GEMM form (geo_embed_kernel)")
     if rank == 0:
         if records is not None:
-            out["result_gather"] = {"backend": {"nccl": "rccl"}.get(records.backend, records.backend), "rccl_ranks_seen": records.ranks_seen,
-                                    "records": len(records), "scores": int(sum(records.n_scores.values())),
-                                    "record_bytes_per_rank": int(B * (4 + max_scores) * 4), "collectives": 1 if records.backend != "local" else 0}
+            out["result_gather"] = benchloop.gather_summary(records, B, args.steps, spp)
         roofs = rooflines(prof, prof_steps, dtype)
-        attach_traffic(roofs, B, args.config)
+        pmc = attach_traffic(roofs, B, args.config)
         out["roofline"] = roofs[0] if roofs else None
         out["rooflines"] = roofs
         if prof_steps:
+            out["whole_forward"] = whole_forward(prof, prof_steps, dtype, out["ms_per_step"], pmc)
             out["kernel_ms_per_step"] = {k: round(v["ms"] / prof_steps, 4) for k, v in prof.items() if k != "geo_embed_reference_flops"}
             out["profile_pass"] = {"steps": prof_steps, "note": "the timed steps repeated with HIP events on; `value` is timed with them off"}
         if single:
             out["single_pair_mode"] = single
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(N, args.cpu_baseline_seconds, wl["benchmark"], wl["seed_config"])
-    if dist.is_available() and dist.is_initialized():
-        dist.destroy_process_group()
-    if rank == 0:
-        # the JSON line goes out LAST: librccl prints its version banner through C stdio, which is flushed here first
-        import ctypes
-        try:
-            ctypes.CDLL(None).fflush(None)
-        except Exception:
-            pass
-        print(json.dumps(out), flush=True)
+            out["cpu_baseline"] = cpu_baseline(N, args.cpu_baseline_seconds, wl["benchmark"], wl["seed_config"], weights, normals)
+    return out
+
+
+def knn_stress(args, rank, world, distributed):
+    """--config 5 (BASELINE configs[4]): kNN(64) + fused PPF, 32 clouds x 30000 points per call, clouds sharded over ranks (every
+    rank its own clouds, no collective).  One step = one roitr_amd.pointops.knn_ppf call: grid build, query, column-0 drop, PPF."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    from roitr_amd import pointops as P
+
+    wl = WORKLOADS[5]
+    B = args.pairs_per_step or wl["pairs"]
+    N = args.n_points or wl["n_points"]
+    K = 64
+    rng = np.random.default_rng(5000 + rank)
+    xyz = torch.from_numpy((rng.random((N * B, 3)) * 2.0).astype(np.float32)).cuda()
+    nrm = rng.standard_normal((N * B, 3))
+    nrm = torch.from_numpy((nrm / np.linalg.norm(nrm, axis=1, keepdims=True)).astype(np.float32)).cuda()
+    off = (torch.arange(1, B + 1, dtype=torch.int32) * N).cuda()
+
+    def step():
+        return P.knn_ppf(K, xyz, xyz, nrm, nrm, off, off)
+
+    def barrier():
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(max(args.warmup, 1)):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    # per-launch duration of the call on its stream (HIP events on torch's current stream = the stream pointops launches on)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(args.steps):
+        step()
+    e1.record()
+    torch.cuda.synchronize()
+    call_ms = e0.elapsed_time(e1) / args.steps
+    if distributed:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t[0].item())
+    queries = N * B * args.steps * world
+    algo = (24.0 * N + 20.0 * N * K) * B          # SURVEY.md 8d: 24 R + 4 M K (idx) + 16 M K (ppf), queries == refs
+    achieved = algo / (call_ms * 1e-3) / 1e9
+    roof = {"bound": "hbm", "kernel": "knn+ppf call (grid_build_kernel + knn_cell_kernel / knn_gridsel_kernel / knn_replay_kernel, PPF fused)",
+            "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+            "avg_launch_ms": round(call_ms, 5), "algorithmic_bytes_per_launch": int(algo), "launches_timed": args.steps,
+            "pair_evaluations_brute_force": int(float(N) * N * B),
+            "note": "an exact kNN is bound by VALU issue (selecting 64 of ~700 staged candidates per query), not by the 39 MB per cloud "
+                    "it has to move (SURVEY.md finding 3): see valu_issue"}
+    sq = load_profile_json("sq_knn_config5.json")
+    if sq and sq.get("clouds") == B and sq.get("n_points") == N:
+        roof["valu_issue"] = sq
+    out = {"metric": "kNN+PPF queries/s (k = 64, N = 30000 per cloud)", "value": round(queries / dt, 1), "unit": "queries/s", "n_gpus": world,
+           "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": wl["text"].format(N=N, B=B), "baseline_config": 5, "clouds_per_step": B, "n_points": N, "k": K},
+           "roofline": roof, "rooflines": [roof]}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline_knn(N, K, args.cpu_baseline_seconds)
+    return out
+
+
+def load_profile_json(name):
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", name)))
+    except Exception:
+        return None
 
 
 def rooflines(prof, steps, dtype):
-    """[dominant kernel family, kNN+PPF vs HBM, global transformer phase vs MFMA] from the instrumented pass.
+    """[dominant kernel family, kNN+PPF vs HBM, global transformer phase vs HBM, geo_table_kernel vs HBM] from the instrumented pass.
 
     gemm_kernel / geo_embed_kernel are MFMA-bound: achieved = algorithmic FLOPs (2*M*N*K per launch; 2*(1+k)*rows*C^2 for the
-    embedding) / kernel time vs the MFMA peak of the operand dtype.  Geometry kernels are priced on algorithmic HBM bytes
-    (SURVEY.md 8d / DESIGN.md): FPS n->m: 12n + 4m + 8n; kNN+PPF: 24R + 24M[queries != refs] + 20MK.  The global-transformer
-    entry divides the FLOPs of every GEMM / embedding launch inside the phase by the WHOLE phase time (attention, softmax and
-    LayerNorm kernels included)."""
+    embedding) / kernel time vs the MFMA peak of the operand dtype; the entry also carries the algorithmic HBM bytes per launch
+    (every operand element read once, every result written once) so that the PMC `traffic` can be read against them.
+    Geometry kernels are priced on algorithmic HBM bytes (SURVEY.md 8d / DESIGN.md): FPS n->m: 12n + 4m + 8n; kNN+PPF:
+    24R + 24M[queries != refs] + 20MK.  The global-transformer phase is priced against HBM on the algorithmic bytes of the
+    instrumented launches inside it (the stream of the geometric embedding E dominates: written once, read once per self layer)
+    over the WHOLE phase time; its executed matrix work against the MFMA peak rides along as `mfma_frac_executed`."""
     if not prof or not steps:
         return []
     mfma_peak = MFMA_BF16_PEAK_TFLOPS if dtype == "bf16" else MFMA_F32_PEAK_TFLOPS
     fwd_ms = prof.get("phase.forward", {}).get("ms", 0.0)
 
-    def entry(name, label=None):
+    def entry(name, label=None, bound=None):
         p = prof[name]
         launches = max(p["launches"], 1)
         avg_ms = p["ms"] / launches
-        per_launch = p["bytes"] / launches
         share = round(p["ms"] / fwd_ms, 4) if fwd_ms > 0 else None
-        if name in ("gemm_kernel", "geo_embed_kernel") or name.startswith("phase."):
+        mfma_class = name in ("gemm_kernel", "geo_embed_kernel")
+        if (bound or ("mfma" if mfma_class else "hbm")) == "mfma":
             achieved = p["bytes"] / (p["ms"] * 1e-3) / 1e12 if p["ms"] > 0 else 0.0
-            return {"bound": "mfma", "kernel": label or name, "achieved": round(achieved, 3), "peak": mfma_peak, "unit": "TFLOP/s",
-                    "frac": round(achieved / mfma_peak, 5), "traffic": None, "avg_launch_ms": round(avg_ms, 5),
-                    "algorithmic_flops_per_launch": int(per_launch), "launches_timed": int(p["launches"]),
-                    "share_of_forward_time": share}
-        achieved = per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+            e = {"bound": "mfma", "kernel": label or name, "achieved": round(achieved, 3), "peak": mfma_peak, "unit": "TFLOP/s",
+                 "frac": round(achieved / mfma_peak, 5), "traffic": None, "avg_launch_ms": round(avg_ms, 5),
+                 "algorithmic_flops_per_launch": int(p["bytes"] / launches), "launches_timed": int(p["launches"]),
+                 "share_of_forward_time": share}
+            if p.get("aux"):
+                e["algorithmic_bytes_per_launch"] = int(p["aux"] / launches)
+                e["hbm_gbs_on_algorithmic_bytes"] = round(p["aux"] / (p["ms"] * 1e-3) / 1e9, 1) if p["ms"] > 0 else 0.0
+            return e
+        nbytes = p["aux"] if name.startswith("phase.") else p["bytes"]
+        achieved = nbytes / (p["ms"] * 1e-3) / 1e9 if p["ms"] > 0 else 0.0
         return {"bound": "hbm", "kernel": label or name, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None, "avg_launch_ms": round(avg_ms, 5),
-                "algorithmic_bytes_per_launch": int(per_launch), "launches_timed": int(p["launches"]), "share_of_forward_time": share}
+                "algorithmic_bytes_per_launch": int(nbytes / launches), "launches_timed": int(p["launches"]), "share_of_forward_time": share}
 
     kernels = {k: v for k, v in prof.items() if not k.startswith("phase.") and k != "geo_embed_reference_flops"}
     roofs = []
@@ -293,32 +369,46 @@ def rooflines(prof, steps, dtype):
     if "knn_query_kernel" in prof:
         roofs.append(entry("knn_query_kernel", "knn+ppf (every knn_*_kernel launch of the forward, PPF fused)"))
     if "phase.global_transformer" in prof:
-        e = entry("phase.global_transformer", "global_transformer phase (FLOPs of the MFMA launches inside the phase over the whole phase time)")
+        p = prof["phase.global_transformer"]
+        e = entry("phase.global_transformer", "global_transformer phase (algorithmic HBM bytes of the instrumented launches inside the phase -- "
+                  "the E stream dominates -- over the whole phase time)", bound="hbm")
+        tf = p["bytes"] / (p["ms"] * 1e-3) / 1e12 if p["ms"] > 0 else 0.0
+        e["mfma_tflops_executed"] = round(tf, 3)
+        e["mfma_frac_executed"] = round(tf / mfma_peak, 5)
         if "geo_embed_reference_flops" in prof:
-            # the geometric embedding is evaluated from a function table (csrc/geo_table.hip), not by the reference's four
-            # (rows, C) x (C, C) products: `achieved` above counts EXECUTED matrix work only; this is the same phase priced with
-            # the FLOPs of the reference formulation (what the round-1 / GEMM-form numbers counted)
-            p = prof["phase.global_transformer"]
-            algo = (p["bytes"] + prof["geo_embed_reference_flops"]["bytes"]) / (p["ms"] * 1e-3) / 1e12 if p["ms"] > 0 else 0.0
-            e["achieved_reference_formulation"] = round(algo, 3)
-            e["frac_reference_formulation"] = round(algo / mfma_peak, 5)
+            e["note"] = ("the geometric embedding is a function table (csrc/geo_table.hip): the %.2f TFLOP per step of the reference's four "
+                         "(rows, C) x (C, C) projections are not executed and not priced here" % (prof["geo_embed_reference_flops"]["bytes"] / steps / 1e12))
         roofs.append(e)
     if "geo_table_kernel" in prof:
         roofs.append(entry("geo_table_kernel", "geo_table_kernel (geometric embedding from the LDS function table; bytes = E written once + index rows)"))
     return roofs
 
 
+def whole_forward(prof, steps, dtype, ms_per_step, pmc):
+    """The complete forward against both roofs: matrix FLOPs EXECUTED per step (every GEMM / embedding launch) and HBM bytes per
+    step (PMC: FETCH_SIZE + WRITE_SIZE summed over every kernel of a step, profiles/pmc_traffic.json) over the UNINSTRUMENTED step time."""
+    mfma_peak = MFMA_BF16_PEAK_TFLOPS if dtype == "bf16" else MFMA_F32_PEAK_TFLOPS
+    fwd = prof.get("phase.forward")
+    if not fwd or not steps or ms_per_step <= 0:
+        return None
+    flops = fwd["bytes"] / steps
+    tf = flops / (ms_per_step * 1e-3) / 1e12
+    out = {"executed_flops_per_step": int(flops), "tflops": round(tf, 3), "mfma_peak": mfma_peak, "mfma_frac": round(tf / mfma_peak, 5),
+           "algorithmic_bytes_per_step_instrumented_kernels": int(fwd.get("aux", 0.0) / steps), "ms_per_step": ms_per_step}
+    if pmc and pmc.get("total_hbm_bytes_per_step"):
+        gbs = pmc["total_hbm_bytes_per_step"] / (ms_per_step * 1e-3) / 1e9
+        out.update(pmc_hbm_bytes_per_step=int(pmc["total_hbm_bytes_per_step"]), hbm_gbs=round(gbs, 1), hbm_frac=round(gbs / HBM_PEAK_GBS, 5),
+                   traffic_source="profiles/pmc_traffic.json")
+    return out
+
+
 def attach_traffic(roofs, B, config):
     """roofline.traffic: HBM bytes per launch from the PMC passes (FETCH_SIZE / WRITE_SIZE collected in their own rocprofv3
     runs of this same command by scripts/collect_profiles.sh, gfx950 corrections applied in scripts/pmc_summary.py); only
-    attached when the committed summary was taken at the same workload."""
-    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    try:
-        pmc = json.load(open(path))
-    except Exception:
-        return
-    if pmc.get("pairs_per_step") != B or pmc.get("baseline_config", 2) != config:
-        return
+    attached when the committed summary was taken at the same workload.  Returns the summary (or None)."""
+    pmc = load_profile_json("pmc_traffic.json")
+    if not pmc or pmc.get("pairs_per_step") != B or pmc.get("baseline_config", 2) != config:
+        return None
     src = "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
     for roof in roofs:
         name = roof["kernel"].split(" ")[0]
@@ -333,15 +423,28 @@ def attach_traffic(roofs, B, config):
         if k:
             roof["traffic"] = k["hbm_bytes_per_launch"]
             roof["traffic_source"] = src
+            if roof.get("algorithmic_bytes_per_launch"):
+                roof["traffic_over_algorithmic"] = round(k["hbm_bytes_per_launch"] / roof["algorithmic_bytes_per_launch"], 3)
+    return pmc
 
 
-def cpu_baseline(N, budget_s, benchmark, seed_config):
-    """The CPU oracle (oracle/, 'port' kind) on this host: full forwards of pairs of the same workload."""
+def cpu_baseline(N, budget_s, benchmark, seed_config, weights="plain", normals="random"):
+    """The CPU oracle (oracle/, 'port' kind) on this host: full forwards of pairs of the same workload, per-stage ms included."""
     try:
         from oracle import roitr_ref
     except Exception as e:  # oracle model restatement not available
         return {"value": None, "unit": "pairs/s", "cores": 0, "kind": "port", "sample": f"unavailable: {e}"}
-    return roitr_ref.timed_baseline(N, budget_s, benchmark=benchmark, seed_config=seed_config)
+    return roitr_ref.timed_baseline(N, budget_s, benchmark=benchmark, seed_config=seed_config, weights=weights, normals=normals)
+
+
+def cpu_baseline_knn(N, K, budget_s):
+    """--config 5: the C restatement of knnquery_cuda_kernel.cu:65-108 (oracle/pointops_ref.c, brute force like the reference)
+    + the numpy PPF on single clouds of the same size, on all host cores, for about `budget_s` seconds."""
+    try:
+        from oracle import roitr_ref
+    except Exception as e:
+        return {"value": None, "unit": "queries/s", "cores": 0, "kind": "port", "sample": f"unavailable: {e}"}
+    return roitr_ref.timed_knn_baseline(N, K, budget_s)
 
 
 if __name__ == "__main__":

@@ -360,6 +360,7 @@ def forward(sd, pair, cfg=None, taps=None, threads=1, timings=None):
             f1 = cross_layer(W, lp, f1, f0, pos1, pos0)
         taps[f"geo.layer{i}"] = (f0, f1)
     g0, g1 = W.lin(f0, g + ".out_proj"), W.lin(f1, g + ".out_proj")
+    taps["geo.out"] = (g0, g1)
     _tg.__exit__()
 
     def decoder_cloud(L, tag):
@@ -421,40 +422,64 @@ def forward(sd, pair, cfg=None, taps=None, threads=1, timings=None):
     return out
 
 
-def closed_form_state(factor=1):
+def closed_form_state(factor=1, variant="plain"):
     from roitr_amd.riga import state_dict_layout
     from roitr_amd.weights import closed_form_param
     sd = {}
     for k, shape, kind in state_dict_layout(factor):
         if kind == "param":
-            sd[k] = closed_form_param(k, tuple(shape))
+            sd[k] = closed_form_param(k, tuple(shape), variant)
     return sd
 
 
 FDMATCH_CFG = {"adaptive": True, "num_est_coarse_corr": 128, "fine_matching_topk": 2}   # configs/test/fdmatch.yaml
 
 
-def timed_baseline(n_points, budget_s=20.0, max_pairs=16, benchmark="3DMatch", seed_config=2):
+def timed_baseline(n_points, budget_s=20.0, max_pairs=16, benchmark="3DMatch", seed_config=2, weights="plain", normals="random"):
     """bench.py cpu_baseline ('port'): full forwards of pairs of the bench workload on this host's cores.
 
     FPS/kNN run in the C restatement (kNN split over all cores with threads; FPS is inherently serial per
     cloud), the dense stages in numpy (BLAS threads as configured).  The bounded sample: distinct pairs are run
-    one after the other until `budget_s` seconds of wall time are used (at least one pair, at most `max_pairs`)."""
+    one after the other until `budget_s` seconds of wall time are used (at least one pair, at most `max_pairs`).
+    `stage_ms_per_pair`: wall ms per stage (fps, knn_ppf, encoder, global, decoder, matching), mean over the sample."""
     from roitr_amd.synthetic import make_pair
     cores = len(os.sched_getaffinity(0))
     fd = benchmark in ("4DMatch", "4DLoMatch")
-    sd = closed_form_state(2 if fd else 1)
+    sd = closed_form_state(2 if fd else 1, weights)
     cfg = dict(FDMATCH_CFG) if fd else None
     pairs = 0
     ncorr = 0
     dt = 0.0
+    stages = {}
     while pairs < max_pairs and (pairs == 0 or dt < budget_s):
-        pair = make_pair(n_points, config=seed_config, pair_index=pairs)
+        pair = make_pair(n_points, config=seed_config, pair_index=pairs, normals=normals)
         t0 = time.perf_counter()
-        out = forward(sd, pair, cfg=cfg, threads=cores)
+        out = forward(sd, pair, cfg=cfg, threads=cores, timings=stages)
         dt += time.perf_counter() - t0
         ncorr += int(out["corr_scores"].shape[0])
         pairs += 1
     return {"value": round(pairs / dt, 5), "unit": "pairs/s", "cores": cores, "kind": "port",
+            "stage_ms_per_pair": {k: round(1e3 * v / pairs, 1) for k, v in stages.items()},
             "sample": f"{pairs} pair(s), N={n_points} pts/cloud, {benchmark} settings, full fp32 forward each, oracle/roitr_ref.py "
                       f"(numpy fp32 + C FPS/kNN), {dt:.2f} s wall, {ncorr} correspondences"}
+
+
+def timed_knn_baseline(n_points, k, budget_s=20.0, max_clouds=8):
+    """bench.py --config 5 cpu_baseline ('port'): knnquery(k + 1) + column-0 drop + PPF on single uniform clouds of `n_points`
+    points: the C restatement of the reference's brute-force kernel (knnquery_cuda_kernel.cu:65-108) split over all host cores,
+    PPF in numpy (lib/utils.py:358-389)."""
+    cores = len(os.sched_getaffinity(0))
+    clouds, dt = 0, 0.0
+    while clouds < max_clouds and (clouds == 0 or dt < budget_s):
+        rng = np.random.default_rng(5000 + clouds)
+        xyz = (rng.random((n_points, 3)) * 2.0).astype(f32)
+        nrm = rng.standard_normal((n_points, 3))
+        nrm = (nrm / np.linalg.norm(nrm, axis=1, keepdims=True)).astype(f32)
+        o = np.array([n_points], np.int32)
+        t0 = time.perf_counter()
+        g = P.queryandgroup_idx(k, xyz, xyz, o, o, cores)
+        calc_ppf(xyz, nrm, xyz[g], nrm[g])
+        dt += time.perf_counter() - t0
+        clouds += 1
+    return {"value": round(clouds * n_points / dt, 1), "unit": "queries/s", "cores": cores, "kind": "port",
+            "sample": f"{clouds} cloud(s) of {n_points} points, k = {k}, brute-force C kNN (oracle/pointops_ref.c) + numpy PPF, {dt:.2f} s wall"}

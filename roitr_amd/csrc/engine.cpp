@@ -110,7 +110,6 @@ struct Engine {
     LocalT dec[4];
     Up up[4];
     Lin geo_in, geo_out, proj_d, proj_a, coarse_proj, fine_proj;
-    unsigned short* proj_d3 = nullptr; unsigned short* proj_a3 = nullptr;   // opt-in split-bf16 planes (ROITR_GEO_SPLIT=1)
     const float* geo_div = nullptr;
     float* geo_div_own = nullptr;
     // function-table form of the embedding (geo_table.hip): built at finalize unless ROITR_GEO_TABLE=0
@@ -202,16 +201,13 @@ int gemm(hipStream_t st, int M, const float* A, const Lin& l, float* C, bool rel
 // runs in the GEMM epilogue, the (M, 64) intermediate never reaches HBM), the two-launch sequence otherwise.
 // `tmp` (M x l.out) is only touched by the two-launch form.
 // The fused form is bitwise the two-launch result, so the choice could depend on the row count without breaking batch
-// invariance.  Measured and dropped (ROITR_LN_FUSE_SMALL_M): fusing the 256-wide rows for small M to save the 41 add_layernorm
-// launches of a one-pair forward -- 5.84 vs 5.23 ms per pair: a 64 x 256 tile puts four accumulators (4096 MFMA cycles per
-// K-slab) on the critical path of a handful of blocks, which costs more than the launch it saves.
-bool ln_fuses(int N, int K, int lda, int ldw, int M = 1 << 30)
+// invariance.  Measured and dropped: fusing the 256-wide rows as well (64 x 256 tiles leave the coarse levels with too few, too
+// fat blocks: +1.0 ms per 128-pair forward), also for small M only, to save the 41 add_layernorm launches of a one-pair
+// forward -- 5.84 vs 5.23 ms per pair: a 64 x 256 tile puts four accumulators (4096 MFMA cycles per K-slab) on the critical
+// path of a handful of blocks, which costs more than the launch it saves.
+bool ln_fuses(int N, int K, int lda, int ldw)
 {
-    static const bool fuse = getenv("ROITR_NO_LN_FUSE") == nullptr;
-    static const int fuse_max = [] { const char* e = getenv("ROITR_LN_FUSE_MAX"); return e ? atoi(e) : 128; }();
-    static const int small_m = [] { const char* e = getenv("ROITR_LN_FUSE_SMALL_M"); return e ? atoi(e) : 0; }();
-    const int lim = M <= small_m ? 256 : fuse_max;
-    return fuse && (N == 64 || N == 128 || N == 256) && N <= lim && K % 32 == 0 && lda % 4 == 0 && ldw % 4 == 0;
+    return (N == 64 || N == 128) && K % 32 == 0 && lda % 4 == 0 && ldw % 4 == 0;
 }
 // bf: ROITR_BF16_A (A stored bf16; lda in elements) and / or ROITR_BF16_C (out stored bf16: fused form only)
 // A_cat (optional): the second K-half of the operand, [A | A_cat] with A (M, k_cat) dense and A_cat (M, l.in - k_cat) of leading
@@ -226,7 +222,7 @@ int gemm_ln(hipStream_t st, int M, const float* A, const Lin& l, const float* re
     const int lda = A_cat ? k_cat : K, ldw = K;
     // measured per 128-pair forward: fusing the 64-wide layers -1.55 ms, + the 128-wide ones -0.4 ms, + the 256-wide ones
     // +1.0 ms (64 x 256 tiles leave the coarse levels with too few, too fat blocks) -> default limit 128
-    if (ln_fuses(N, K, lda, ldw, M)) {
+    if (ln_fuses(N, K, lda, ldw)) {
         RoitrGemm g;
         memset(&g, 0, sizeof(g));
         g.M = M; g.N = N; g.K = K; g.A = A; g.lda = lda; g.W = w; g.ldw = ldw; g.bias = b; g.alpha = 1.0f; g.C = out; g.ldc = N; g.batch = 1;
@@ -279,8 +275,9 @@ int resolve_local(Engine& E, LocalT& L, const std::string& pre, int in_dim, int 
 
 int fold_local(Engine& E, LocalT& L, hipStream_t st)
 {
-    static const bool qp_in_gemm = getenv("ROITR_QP_IN_GEMM") != nullptr;
-    const int H = L.H, NQ = qp_in_gemm ? 5 * HEADS : 0, NQF = 5 * HEADS;
+    // NQ = 0: the PPF coefficient rows qp of the query are formed inside the attention kernel (round 2; as 5 extra GEMM columns
+    // per head, NQ = 20, [q|k|v] was 212 wide: one 64-column tile in four was 31 % full)
+    const int H = L.H, NQ = 0, NQF = 5 * HEADS;
     L.nq = NQ;
     Arena& A = E.warena;
     float* weT = A.get<float>(4 * (size_t)H);
@@ -321,9 +318,7 @@ int fold_local(Engine& E, LocalT& L, hipStream_t st)
         if (A.fail) return ROITR_ERR_ARG;
         CHK(roitr_f32_to_bf16((long)R * H, L.wqkv, L.wqkv_b, st));
     }
-    static const bool fold_in = getenv("ROITR_NO_INPROJ_FOLD") == nullptr;
-    static const bool fold_cat = getenv("ROITR_NO_CAT_FOLD") == nullptr;
-    const bool cat = fold_cat && E.cfg.operand_dtype == 0 && L.in_dim % 32 == 0;
+    const bool cat = E.cfg.operand_dtype == 0 && L.in_dim % 32 == 0;
     if (cat) {
         const int I = L.in_dim;
         L.wcat = A.get<float>((size_t)H * (H + I));
@@ -333,7 +328,7 @@ int fold_local(Engine& E, LocalT& L, hipStream_t st)
         ROITR_HIP(hipMemcpy2DAsync(L.wcat + H, sizeof(float) * (H + I), L.in_proj.w, sizeof(float) * I, sizeof(float) * I, H, hipMemcpyDeviceToDevice, st));
         CHK(roitr_add_vectors(H, L.lin.b, L.in_proj.b, L.bcat, st));
     }
-    if (fold_in && (L.in_dim != H || cat) && L.in_dim % 32 == 0) {
+    if ((L.in_dim != H || cat) && L.in_dim % 32 == 0) {
         const int I = L.in_dim;
         float* winT = A.get<float>((size_t)I * H);
         L.wqkv_x = A.get<float>((size_t)R * I);
@@ -661,21 +656,13 @@ extern "C" int roitr_engine_finalize(void* h, hipStream_t st)
             E.geo_div = E.geo_div_own;
         }
     }
-    if (getenv("ROITR_GEO_SPLIT")) {   // opt-in: three bf16 planes of the two embedding projections
-        E.proj_d3 = E.warena.get<unsigned short>((size_t)3 * C4 * C4);
-        E.proj_a3 = E.warena.get<unsigned short>((size_t)3 * C4 * C4);
-        if (!E.warena.fail) {
-            CHK(roitr_split3_bf16((long)C4 * C4, E.proj_d.w, E.proj_d3, st));
-            CHK(roitr_split3_bf16((long)C4 * C4, E.proj_a.w, E.proj_a3, st));
-        }
-    }
     E.geo_tab = nullptr;
     {   // GeometricStructureEmbedding as a function table: proj_x(sinusoid(v)) is univariate per channel.  The widest interval
         // whose MEASURED fit error (float64, between the interpolation nodes) is below 2^-25 of the function's amplitude is
         // taken; distances up to ROITR_GEO_TABLE_RANGE (default 48 = 9.6 m at sigma_d = 0.2) are tabulated, larger ones are
         // evaluated directly by the kernel.  Angles: atan2 in [0, pi] scaled by 180 / (sigma_a pi).
         const char* ev = getenv("ROITR_GEO_TABLE");
-        if (!(ev && atoi(ev) == 0) && C4 % 64 == 0 && !E.proj_d3) {
+        if (!(ev && atoi(ev) == 0) && C4 % 64 == 0) {
             const char* rv = getenv("ROITR_GEO_TABLE_RANGE");
             const double d_range = rv && atof(rv) > 0 ? atof(rv) : 48.0, a_range = 180.0 / 15.0;
             std::vector<float> hd((size_t)C4 * C4), ha((size_t)C4 * C4), hbd(C4), hba(C4), hdiv(C4 / 2);
@@ -911,18 +898,16 @@ extern "C" int roitr_engine_forward(void* h, const RoitrForwardIO* io, hipStream
         CHK(tap(E, st, "geo.a_idx", a_idx, sizeof(float) * etot * 3));
         // bf16 operand mode: E (an operand of the q~ . E and a' . E contractions of every self layer) is stored bf16 when the
         // attention kernel for this width reads it (C = 256 / 512, 4 heads, <= 512 superpoints)
-        const bool e_h = E.cfg.operand_dtype == 1 && E.proj_d.wb && E.proj_a.wb && (C4 == 256 || C4 == 512) && V.nmax[3] <= 512 &&
-                         getenv("ROITR_MHA_GENERIC") == nullptr;
-        if (E.geo_tab)
-            CHK(roitr_geo_embed_table(etot, C4, 3, d_idx, a_idx, E.geo_tab, E.geo_tab_h, E.geo_tab_nd, E.geo_tab_na, E.geo_div, E.proj_d.w,
-                                      E.proj_d.b, E.proj_a.w, E.proj_a.b, Emb, e_h ? 1 : 0, st));
+        const bool e_h = E.cfg.operand_dtype == 1 && E.proj_d.wb && E.proj_a.wb && (C4 == 256 || C4 == 512) && V.nmax[3] <= 512;
+        if (E.geo_tab && roitr_geo_embed_table(etot, C4, 3, d_idx, a_idx, E.geo_tab, E.geo_tab_h, E.geo_tab_nd, E.geo_tab_na, E.geo_div,
+                                               E.proj_d.w, E.proj_d.b, E.proj_a.w, E.proj_a.b, Emb, e_h ? 1 : 0, st) != ROITR_OK)
+            E.geo_tab = nullptr;   // e.g. a device that does not grant the table's LDS: this engine serves the GEMM form from now on
+        if (E.geo_tab) {}
         else if (e_h)
             CHK(roitr_geo_embed_bf16_out(etot, C4, 3, d_idx, a_idx, E.geo_div, E.proj_d.wb, E.proj_d.b, E.proj_a.wb, E.proj_a.b,
                                          reinterpret_cast<unsigned short*>(Emb), st));
         else if (E.cfg.operand_dtype == 1 && E.proj_d.wb && E.proj_a.wb)
             CHK(roitr_geo_embed_bf16(etot, C4, 3, d_idx, a_idx, E.geo_div, E.proj_d.wb, E.proj_d.b, E.proj_a.wb, E.proj_a.b, Emb, st));
-        else if (E.proj_d3)
-            CHK(roitr_geo_embed_split(etot, C4, 3, d_idx, a_idx, E.geo_div, E.proj_d3, E.proj_d.b, E.proj_a3, E.proj_a.b, Emb, st));
         else
             CHK(roitr_geo_embed(etot, C4, 3, d_idx, a_idx, E.geo_div, E.proj_d.w, E.proj_d.b, E.proj_a.w, E.proj_a.b, Emb, st));
         CHK(tap(E, st, "geo.emb", Emb, (e_h ? sizeof(unsigned short) : sizeof(float)) * (size_t)etot * C4));   // bf16 mode: the tap holds bf16
@@ -957,6 +942,8 @@ extern "C" int roitr_engine_forward(void* h, const RoitrForwardIO* io, hipStream
                 m.v = qkv + 2 * C4; m.ldv = 3 * C4; m.offset = D.off[3]; m.cloud_of_row = D.cloud_of_node; m.partner = nullptr;
                 m.E = Emb; m.eoff = D.eoff; m.qt = qt; m.bp = L.p.b; m.scale = scale; m.nk_max = V.nmax[3]; m.out = hid; m.ldo = C4; m.ebar = ebar;
                 m.e_bf16 = e_h ? 1 : 0;
+                // algorithmic bytes of the launch: E read once, q | k | v, the folded queries q~, out and ebar written once
+                roitr_prof_next_bytes(ROITR_PROF_MHA, (double)etot * C4 * (e_h ? 2.0 : 4.0) + (double)T4 * C4 * 4.0 * (3 + HEADS + 1 + HEADS));
                 CHK(roitr_mha(&m, st));
                 {   // pos_raw[:, h-slice] = Wvp_h ebar_h + bvp_h
                     RoitrGemm gp; memset(&gp, 0, sizeof(gp));
@@ -989,6 +976,7 @@ extern "C" int roitr_engine_forward(void* h, const RoitrForwardIO* io, hipStream
                     m.q_row0 = q0; m.q_rows = qn; m.C = C4; m.heads = HEADS; m.q = qb_; m.ldq = C4; m.k = kb_; m.ldk = C4; m.v = vb_; m.ldv = C4;
                     m.offset = D.off[3]; m.cloud_of_row = D.cloud_of_node; m.partner = D.partner; m.scale = scale; m.nk_max = V.nmax[3];
                     m.out = hid; m.ldo = C4;
+                    roitr_prof_next_bytes(ROITR_PROF_MHA, ((double)qn * 2 + (double)kn * 2) * C4 * 4.0);
                     CHK(roitr_mha(&m, st));
                     CHK(gemm_ln(st, qn, hid + (size_t)q0 * C4, L.lin, fcur + (size_t)q0 * C4, nullptr, L.n_w, L.n_b, nullptr, false,
                                 t1 + (size_t)q0 * C4, t2 + (size_t)q0 * C4));

@@ -312,117 +312,6 @@ __global__ __launch_bounds__(256) void gemm_kernel(RoitrGemm g, int nx, int ny, 
 }
 
 
-// ---------------------------------------------------------------------------------------------------------------
-// LDS-DMA variant of the 64x64 FAST kernel (no addend), OPT-IN (ROITR_GEMM_DMA=1): the operand slabs go global -> LDS
-// directly (global_load_lds_dwordx4, 1 KB per wave instruction) instead of global -> VGPR -> ds_write_b128, two LDS
-// stages, ONE barrier per slab.  Why it exists: with the staging loads compiled out the register-staged kernel runs at
-// 122 TFLOP/s instead of 96 (K = 2048) and at 128 with the LDS stores / barriers out as well -- the load path, not the
-// MFMA feed, holds it at ~60 %.  What it measured: 98 vs 95 TFLOP/s at K = 2048, 84 vs 80 at K = 256, but 62 vs 74 at
-// K = 128 and 44 vs 56 at K = 64 (32 KB of LDS per block: 5 instead of 7 resident blocks) -> 19.8 vs 17.9 ms of GEMM per
-// 128-pair forward, so the register-staged kernel stays the default.  Also without effect on the default kernel:
-// full-64-byte-segment staging loads (kept), padded leading dimensions (no L2 channel aliasing at power-of-two strides).
-// The DMA writes LDS linearly (wave-uniform base + 16 B * lane), so the image is row-major [row][8 chunks of 4 k] and
-// the bank-conflict freedom of the b128 fragment reads comes from an XOR swizzle of the chunk index applied on the
-// SOURCE address (physical chunk = logical ^ ((row >> 1) & 7)).  Which k a lane multiplies is free as long as A and B
-// agree: lanes 0..31 take chunks 0,2,4,6 of the slab, lanes 32..63 chunks 1,3,5,7, MFMA j of chunk pair i pairs
-// k = 8 i + j with k = 8 i + 4 + j.
-typedef __attribute__((address_space(3))) void* lds_ptr_t;
-// generic pointer into __shared__ memory -> LDS address (the low 32 bits of the flat address are the LDS offset)
-__device__ __forceinline__ lds_ptr_t to_lds(const void* p) { return (lds_ptr_t)(unsigned)(uintptr_t)p; }
-
-template <int DUMMY>
-__global__ __launch_bounds__(256) void gemm_dma_kernel(RoitrGemm g, int nx, int ny, int T)
-{
-    __shared__ __attribute__((aligned(1024))) float smem[2 * 2 * BM * BK];   // [stage][A | B][64 rows][32 k]
-    const int tile = xcd_block_id(T);
-    if (tile >= T) return;
-    const int bz = tile / (nx * ny);
-    const int rem = tile - bz * nx * ny;
-    const int by_ = rem / nx, bx_ = rem - by_ * nx;
-    const float* A = g.A + (size_t)bz * g.sA;
-    const float* W = g.W + (size_t)bz * g.sW;
-    const float* bias = g.bias ? g.bias + (size_t)bz * g.sBias : nullptr;
-    float* C = g.C + (size_t)bz * g.sC;
-    const int* a_idx = g.a_idx ? g.a_idx + (size_t)bz * g.sAidx : nullptr;
-    const int* w_idx = g.w_idx ? g.w_idx + (size_t)bz * g.sWidx : nullptr;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int m0 = by_ * BM, n0 = bx_ * BN;
-
-    // staging: wave w, instruction u in {0,1} fills rows 8 (2 w + u) .. +7 of an operand slab; lane t -> row t / 8, chunk t % 8
-    const float* asrc[2]; const float* wsrc[2];
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-        const int rr = 8 * (2 * wave + u) + (lane >> 3);
-        const int lc = (lane & 7) ^ ((rr >> 1) & 7);   // the logical chunk that belongs at this physical slot
-        const float* ap = g_zero_row; const float* wp = g_zero_row;
-        const int am = m0 + rr;
-        if (am < g.M) {
-            const int src = a_idx ? a_idx[am] : am;
-            if (src >= 0 && (g.a_limit <= 0 || src < g.a_limit)) ap = A + (size_t)src * g.lda;
-        }
-        const int wr = n0 + rr;
-        if (wr < g.N) {
-            const int src = w_idx ? w_idx[wr] : wr;
-            if (src >= 0 && (g.w_limit <= 0 || src < g.w_limit)) wp = W + (size_t)src * g.ldw;
-        }
-        asrc[u] = ap + 4 * lc; wsrc[u] = wp + 4 * lc;
-    }
-    auto issue = [&](int stage, int k0) {
-        float* sa = smem + stage * (2 * BM * BK);
-        float* sb = sa + BM * BK;
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            __builtin_amdgcn_global_load_lds(asrc[u] + k0, to_lds(sa + (2 * wave + u) * 256), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds(wsrc[u] + k0, to_lds(sb + (2 * wave + u) * 256), 16, 0, 0);
-        }
-    };
-    const int kh = lane >> 5, ml = lane & 31;
-    const int arow_l = wm * 32 + ml, brow_l = wn * 32 + ml;
-    const int asw = (arow_l >> 1) & 7, bsw = (brow_l >> 1) & 7;
-    f32x16 acc;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-    issue(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    int stage = 0;
-    for (int k0 = 0; k0 < g.K; k0 += BK) {
-        if (k0 + BK < g.K) issue(stage ^ 1, k0 + BK);
-        const float* sa = smem + stage * (2 * BM * BK) + arow_l * BK;
-        const float* sb = smem + stage * (2 * BM * BK) + BM * BK + brow_l * BK;
-        float4 af[4], bf[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            af[i] = *reinterpret_cast<const float4*>(sa + 4 * ((2 * i + kh) ^ asw));
-            bf[i] = *reinterpret_cast<const float4*>(sb + 4 * ((2 * i + kh) ^ bsw));
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[i].x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[i].y, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[i].z, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[i].w, acc, 0, 0, 0);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA for the next slab has landed ...
-        __syncthreads();                                    // ... and so has everyone's; all reads of `stage` are done
-        stage ^= 1;
-    }
-    const int col = n0 + wn * 32 + (lane & 31);
-    if (col < g.N) {
-        const float bv = bias ? bias[col] : 0.f;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int row = m0 + wm * 32 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
-            if (row < g.M) {
-                float v = acc[i] * g.alpha + bv;
-                if (g.relu) v = fmaxf(v, 0.f);
-                C[(size_t)row * g.ldc + col] = v;
-            }
-        }
-    }
-}
-
 }  // namespace
 
 namespace {
@@ -459,19 +348,14 @@ extern "C" int roitr_gemm(const RoitrGemm* g, hipStream_t stream)
         roitr_set_error("roitr_gemm: K-concatenated A needs the fast path (K % 32, 16-byte rows), k_cat % 32 == 0, no addend / batching", __FILE__, __LINE__);
         return ROITR_ERR_UNSUPPORTED;
     }
-    static const int tn_env = [] { const char* e = getenv("ROITR_GEMM_TN"); return e ? atoi(e) : 0; }();
-    static const long tn_min_blocks = [] { const char* e = getenv("ROITR_GEMM_TN_MIN_BLOCKS"); return e ? atol(e) : 0L; }();
-    int tn = g->ln_gamma ? g->N / BN : 1;   // LayerNorm epilogue: one block spans the row
-    if (!g->ln_gamma && fast && !g->seg_off && (tn_env == 2 || tn_env == 4) && g->N % (BN * tn_env) == 0 &&
-        (long)(g->N / (BN * tn_env)) * div_up(g->M, BM) * g->batch >= tn_min_blocks)
-        tn = tn_env;
+    const int tn = g->ln_gamma ? g->N / BN : 1;   // LayerNorm epilogue: one block spans the row
     if (g->ln_gamma && (g->N % BN || (tn != 1 && tn != 2 && tn != 4) || g->batch != 1 || g->seg_off || g->relu || !g->ln_beta)) return ROITR_ERR_UNSUPPORTED;
     const int nx = div_up(g->N, BN * tn), ny = div_up(g->M, BM);
     const long Tl = (long)nx * ny * g->batch;
     if (Tl > 0x7ffffff0L) return ROITR_ERR_UNSUPPORTED;
     const int T = (int)Tl;
     const unsigned grid = (unsigned)xcd_grid(T);
-    roitr_prof_begin(ROITR_PROF_GEMM, 2.0 * g->M * g->N * (double)g->K * g->batch, stream);
+    roitr_prof_begin2(ROITR_PROF_GEMM, 2.0 * g->M * g->N * (double)g->K * g->batch, roitr_gemm_algorithmic_bytes(g), stream);
     // Measured and dropped (A/B on the forward bench): 64x128 / 128x128 multi-accumulator tiles (19.7 / 22.0 vs 16.9 ms of
     // GEMM per 128-pair forward), two K-slabs per barrier pair (7.9 vs 7.5 ms at 32 pairs), and a persistent-block
     // variant that opens the next tile (row pointers + first slab in flight) before the store epilogue (18.3-19.8 vs
@@ -488,7 +372,9 @@ extern "C" int roitr_gemm(const RoitrGemm* g, hipStream_t stream)
     // not what these launches wait for either.
     // The kernel alone reaches 106 TFLOP/s at K = 2048 and 78 at K = 256 (scripts/bench_gemm.py); the no-memory MFMA
     // ceiling measured on this part is 143-157 TFLOP/s (scripts/micro/mfma_peak.hip).
-    static const bool dma = getenv("ROITR_GEMM_DMA") != nullptr;
+    // Also measured and removed (round 1-2): an LDS-DMA variant (global_load_lds_dwordx4 into a swizzled row-major image, two
+    // stages, one barrier per slab): 98 vs 95 TFLOP/s at K = 2048 and 84 vs 80 at K = 256, but 62 vs 74 at K = 128 and 44 vs
+    // 56 at K = 64 (32 KB of LDS per block: 5 instead of 7 resident blocks) -> 19.8 vs 17.9 ms of GEMM per 128-pair forward.
     static const bool shapes = getenv("ROITR_GEMM_SHAPES") != nullptr;  // debug: per-shape timing table at exit (synchronous)
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (shapes) { hipEventCreate(&e0); hipEventCreate(&e1); hipEventRecord(e0, stream); }
@@ -497,10 +383,7 @@ extern "C" int roitr_gemm(const RoitrGemm* g, hipStream_t stream)
         else if (tn == 1) gemm_kernel<true, 1, true><<<grid, 256, 0, stream>>>(*g, nx, ny, T);
         else if (tn == 2) gemm_kernel<true, 2, true><<<grid, 256, 0, stream>>>(*g, nx, ny, T);
         else gemm_kernel<true, 4, true><<<grid, 256, 0, stream>>>(*g, nx, ny, T);
-    } else if (fast && dma && !g->A2 && !g->seg_off && !g->A_cat) gemm_dma_kernel<0><<<grid, 256, 0, stream>>>(*g, nx, ny, T);
-    else if (fast && tn == 2) gemm_kernel<true, 2, false><<<grid, 256, 0, stream>>>(*g, nx, ny, T);
-    else if (fast && tn == 4) gemm_kernel<true, 4, false><<<grid, 256, 0, stream>>>(*g, nx, ny, T);
-    else if (fast) gemm_kernel<true, 1, false><<<grid, 256, 0, stream>>>(*g, nx, ny, T);
+    } else if (fast) gemm_kernel<true, 1, false><<<grid, 256, 0, stream>>>(*g, nx, ny, T);
     else gemm_kernel<false, 1, false><<<grid, 256, 0, stream>>>(*g, nx, ny, T);
     if (shapes) {
         hipEventRecord(e1, stream); hipEventSynchronize(e1);

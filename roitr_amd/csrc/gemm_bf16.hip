@@ -316,7 +316,7 @@ int roitr_gemm_bf16_launch(const RoitrGemm* g, hipStream_t stream)
     const int T = (int)Tl;
     const unsigned grid = (unsigned)xcd_grid(T);
     const bool a_h = (g->bf16 & ROITR_BF16_A) != 0;
-    roitr_prof_begin(ROITR_PROF_GEMM, 2.0 * g->M * g->N * (double)g->K * g->batch, stream);
+    roitr_prof_begin2(ROITR_PROF_GEMM, 2.0 * g->M * g->N * (double)g->K * g->batch, roitr_gemm_algorithmic_bytes(g), stream);
     if (g->ln_gamma) {
         if (a_h) {
             if (tn == 1) gemm_bf16_kernel<false, 1, true><<<grid, 256, 0, stream>>>(*g, nx, ny, T);

@@ -753,9 +753,9 @@ extern "C" int roitr_mha(const RoitrMha* a, hipStream_t stream)
     if (floats * 4 > 150 * 1024) return ROITR_ERR_UNSUPPORTED;
     static const hipError_t attr_ = hipFuncSetAttribute((const void*)mha_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     (void)attr_;
-    roitr_prof_begin(ROITR_PROF_MHA, 0.0, stream);
+    roitr_prof_begin(ROITR_PROF_MHA, -1.0, stream);   // bytes: roitr_prof_next_bytes of the caller (0 otherwise)
     {   // factor-2 width (C = 512) and / or E stored in bf16: the wide kernels
-        const bool lay = a->heads == 4 && a->ldq % 4 == 0 && a->ldk % 4 == 0 && a->nk_max <= 512 && getenv("ROITR_MHA_GENERIC") == nullptr;
+        const bool lay = a->heads == 4 && a->ldq % 4 == 0 && a->ldk % 4 == 0 && a->nk_max <= 512;
         if (a->E && !a->partner && lay && (a->C == 512 || (a->C == 256 && a->e_bf16))) {
             const unsigned gr = (unsigned)xcd_grid(a->q_rows);
             if (a->C == 512) { if (a->e_bf16) mha_geo_wide_kernel<2, true><<<gr, 256, 0, stream>>>(*a); else mha_geo_wide_kernel<2, false><<<gr, 256, 0, stream>>>(*a); }
@@ -773,8 +773,7 @@ extern "C" int roitr_mha(const RoitrMha* a, hipStream_t stream)
         }
     }
     // self attention over E at the model's width: the single-pass register-resident kernel (nk_max bounds every cloud)
-    const bool geo_any = a->E && !a->partner && a->C == 256 && a->heads == 4 && a->ldq % 4 == 0 && a->ldk % 4 == 0 &&
-                         getenv("ROITR_MHA_GENERIC") == nullptr;
+    const bool geo_any = a->E && !a->partner && a->C == 256 && a->heads == 4 && a->ldq % 4 == 0 && a->ldk % 4 == 0;
     const bool geo = geo_any && a->nk_max <= 128;
     if (geo_any && !geo && a->nk_max <= 1024) {
         mha_geo_stream_kernel<<<xcd_grid(a->q_rows), 256, 0, stream>>>(*a);
@@ -782,8 +781,7 @@ extern "C" int roitr_mha(const RoitrMha* a, hipStream_t stream)
         ROITR_LAUNCH_CHECK();
         return ROITR_OK;
     }
-    const bool plain = !a->E && a->C == 256 && a->heads == 4 && a->ldq % 4 == 0 && a->ldk % 4 == 0 && a->nk_max <= 1024 &&
-                       getenv("ROITR_MHA_GENERIC") == nullptr;
+    const bool plain = !a->E && a->C == 256 && a->heads == 4 && a->ldq % 4 == 0 && a->ldk % 4 == 0 && a->nk_max <= 1024;
     if (plain && a->nk_max <= 128) mha_plain_kernel<128><<<xcd_grid(a->q_rows), 256, 0, stream>>>(*a);
     else if (plain) mha_plain_kernel<1024><<<xcd_grid(a->q_rows), 256, 0, stream>>>(*a);
     else if (geo && a->nk_max <= 80) mha_geo_kernel<20><<<xcd_grid(a->q_rows), 256, 0, stream>>>(*a);

@@ -161,7 +161,7 @@ __global__ __launch_bounds__(256) void geo_embed_kernel(long rows, int C, int an
 
 
 // ---------------------------------------------------------------------------------------------------------------
-// OPT-IN (ROITR_GEO_SPLIT=1), not the default path: the same embedding on the bf16 matrix cores with fp32-level
+// An OPERATOR only (ops.geo_embed(split=True), tested against float64 in tests/test_stages_gpu.py), never used by the engine: the same embedding on the bf16 matrix cores with fp32-level
 // accuracy.  Every fp32 operand is split into three bf16 pieces (x = hi + mid + lo, 8 + 8 + 8 mantissa bits, exact),
 // and a product keeps the six piece pairs down to 2^-24: hh, hm, mh, hl, lh, mm -- six v_mfma_f32_32x32x16_bf16
 // (fp32 accumulate, bf16 products are exact in fp32) instead of eight v_mfma_f32_32x32x2_f32 per 16 k, at 16x the
@@ -380,17 +380,12 @@ extern "C" int roitr_geo_embed(long rows, int C, int angle_k, const float* d_idx
     if (C % 128 || C > 1024 || angle_k < 1) return ROITR_ERR_UNSUPPORTED;
     const long mt = (rows + BM - 1) / BM;
     if (mt > 0x7fffffffL) return ROITR_ERR_UNSUPPORTED;
-    static const int nj_env = [] { const char* e = getenv("ROITR_GEO_NJ"); return e ? atoi(e) : 0; }();
     // measured (B=32, N=5000, C=256): NJ=1 1.90 ms (156 VGPRs, 3 blocks/CU), NJ=2 2.27 ms (284 VGPRs, 1 block/CU).
     // Also measured and dropped: one staged weight slab shared by the three angle passes (3 x 2 accumulators per wave, 199
     // VGPRs, 2 blocks/CU): 7.32 vs 7.37 ms per 128-pair forward -- weight traffic / barriers are not what holds the kernel
     // at 66 % of the MFMA peak; NJ=1 with 128 VGPRs forced (4 blocks/CU, 92 spills): 7.76 ms.
-    const int nj = (C % 256 == 0 && nj_env == 2) ? 2 : 1;
     roitr_prof_begin(ROITR_PROF_GEO_EMBED, 2.0 * rows * (1.0 + angle_k) * (double)C * C, stream);
-    if (nj == 2)
-        geo_embed_kernel<2><<<dim3(C / 256, (unsigned)mt), 256, 0, stream>>>(rows, C, angle_k, d_idx, a_idx, div_term, Wd, bd, Wa, ba, out);
-    else
-        geo_embed_kernel<1><<<dim3(C / 128, (unsigned)mt), 256, 0, stream>>>(rows, C, angle_k, d_idx, a_idx, div_term, Wd, bd, Wa, ba, out);
+    geo_embed_kernel<1><<<dim3(C / 128, (unsigned)mt), 256, 0, stream>>>(rows, C, angle_k, d_idx, a_idx, div_term, Wd, bd, Wa, ba, out);
     roitr_prof_end(ROITR_PROF_GEO_EMBED, stream);
     ROITR_LAUNCH_CHECK();
     return ROITR_OK;

@@ -22,6 +22,7 @@
 // reads of an evaluation are conflict-free stride-1 LDS reads (ds_read2st64_b32) and the store of a row slice is one
 // contiguous 256-byte line.  Bound: LDS bytes (4 evaluations x 8 coefficients per output) and the HBM write of E.
 #include "common.h"
+#include <mutex>
 #include "prof.h"
 #include <cmath>
 #include <vector>
@@ -247,18 +248,24 @@ extern "C" int roitr_geo_embed_table(long rows, int C, int angle_k, const float*
     if (C % CS || angle_k != 3 || n_int_d < 1 || n_int_a < 1) return ROITR_ERR_UNSUPPORTED;
     const size_t lds = (size_t)(n_int_d + n_int_a) * NCOEF * CS * sizeof(float);
     if (lds > 160 * 1024) return ROITR_ERR_UNSUPPORTED;
-    static bool attr_done = false;
-    if (!attr_done) {
-        ROITR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(geo_table_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        ROITR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(geo_table_bf16o_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_done = true;
+    {   // dynamic-LDS limit of the two kernels: what THIS table needs, per device, raised when a larger table comes along
+        static std::mutex mu;
+        static size_t granted[64] = {0};
+        int dev = 0;
+        ROITR_HIP(hipGetDevice(&dev));
+        std::lock_guard<std::mutex> lk(mu);
+        if (dev < 0 || dev >= 64 || lds > granted[dev]) {
+            ROITR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(geo_table_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            ROITR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(geo_table_bf16o_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            if (dev >= 0 && dev < 64) granted[dev] = lds;
+        }
     }
     GeoTableArgs g;
     g.rows = rows; g.C = C; g.nd = n_int_d; g.na = n_int_a; g.inv_h = 1.0f / interval;
     g.d_idx = d_idx; g.a_idx = a_idx; g.table = table; g.div = div_term; g.Wd = Wd; g.bd = bd; g.Wa = Wa; g.ba = ba; g.out = out;
     const int slices = C / CS;
     const int per_cu = lds <= 80 * 1024 ? 2 : 1;
-    static const int cus = [] { hipDeviceProp_t p; int d = 0; (void)hipGetDevice(&d); return hipGetDeviceProperties(&p, d) == hipSuccess ? p.multiProcessorCount : 256; }();
+    static const int cus = [] { hipDeviceProp_t p; int d = 0; (void)hipGetDevice(&d); return hipGetDeviceProperties(&p, d) == hipSuccess ? p.multiProcessorCount : 256; }();   // one part per node
     const int threads = per_cu == 2 ? 512 : 1024;   // 16 waves per CU either way
     const long nchunks = (rows + 63) / 64;
     long gy = ((long)cus * per_cu + slices - 1) / slices;

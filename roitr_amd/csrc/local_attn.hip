@@ -325,7 +325,6 @@ extern "C" int roitr_local_attention(const RoitrLocalAttn* a, hipStream_t stream
         return ROITR_ERR_UNSUPPORTED;
     // algorithmic bytes: q row + K gathered k and v rows + ppf + idx in, one row out
     roitr_prof_begin(ROITR_PROF_LOCAL_ATTN, (double)a->M * ((a->H + 20.0) * 4 + a->K * (2.0 * a->H * 4 + 20.0) + a->H * 4.0), stream);
-    static const int npw_env = [] { const char* e = getenv("ROITR_LOCAL_ATTN_NPW"); return e ? atoi(e) : 0; }();   // 1 / 2: force
 #define LA_LAUNCH(KK, HH, NN)                                                                                             \
     do {                                                                                                                  \
         if (half) local_attn_kernel<KK, HH, true, NN><<<xcd_grid(div_up(a->M, 4 * NN)), 256, 0, stream>>>(*a);            \
@@ -334,15 +333,12 @@ extern "C" int roitr_local_attention(const RoitrLocalAttn* a, hipStream_t stream
     // two nodes per wave where a lane holds one channel (HV = 1: 64-wide levels), one otherwise (register budget)
 #define LA_CASE(KK, HH)                                                                        \
     do {                                                                                       \
-        if ((HH) == 1 && npw_env != 1) LA_LAUNCH(KK, 1, 2);                                     \
-        else if ((HH) == 2 && npw_env == 2) LA_LAUNCH(KK, 2, 2);                                \
+        if ((HH) == 1) LA_LAUNCH(KK, 1, 2);                                                     \
         else LA_LAUNCH(KK, HH, 1);                                                             \
     } while (0)
-    // H = 64, fp32 rows, in-kernel qp: the 16-lanes-per-node form, ROITR_LOCAL_ATTN_QUAD=1.  Measured at the end of round 2 (512 pairs):
-    // parity suites of the model and the stage operators green with it, local attention 20.4 -> 19.5 ms per step (the three level-1
-    // launches 7.4 -> 6.5 ms), forward 112.6 -> 111.8 ms.  Still opt-in: the full -m gpu suite has not been run with it.
-    static const int quad_env = [] { const char* e = getenv("ROITR_LOCAL_ATTN_QUAD"); return e ? atoi(e) : 0; }();
-    if (quad_env && hv == 1 && !half && a->wpe && a->bpe && (a->K == 8 || a->K == 16) && ((a->ldq | a->ldk | a->ldv | a->ldo) & 3) == 0 &&
+    // H = 64, fp32 rows, in-kernel qp: the 16-lanes-per-node form (round 3: the default for this shape; measured at the end of
+    // round 2 at 512 pairs: the three level-1 launches 7.4 -> 6.5 ms).  The wave-per-node kernel serves every other shape.
+    if (hv == 1 && !half && a->wpe && a->bpe && (a->K == 8 || a->K == 16) && ((a->ldq | a->ldk | a->ldv | a->ldo) & 3) == 0 &&
         (((uintptr_t)a->q | (uintptr_t)a->k | (uintptr_t)a->v | (uintptr_t)a->out | (uintptr_t)a->group_idx) & 15) == 0) {
         const int grid = xcd_grid(div_up(a->M, 16));
         if (a->K == 8) local_attn_quad_kernel<8><<<grid, 256, 0, stream>>>(*a);

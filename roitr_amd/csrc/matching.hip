@@ -628,7 +628,9 @@ __global__ __launch_bounds__(1024) void fine_scan_kernel(int n, const int* __res
         int wb = 0;
         for (int w = 0; w < wave; ++w) wb += wsum[w];
         const int carry = carry_s;
-        if (i < n) offsets[i] = carry + wb + incl - v;
+        // clamped like *n_out: with a caller-chosen out_cap below the true total the offsets of the patches past the cap all
+        // read out_cap (their rows are not emitted), so offsets[i+1] - offsets[i] never exceeds what was written
+        if (i < n) { const int o_ = carry + wb + incl - v; offsets[i] = (out_cap > 0 && o_ > out_cap) ? (int)out_cap : o_; }
         __syncthreads();
         if (tid == 1023) carry_s = carry + wb + incl;
         __syncthreads();

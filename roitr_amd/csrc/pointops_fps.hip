@@ -256,12 +256,10 @@ extern "C" int roitr_furthestsampling(int b, int n_max, const float* xyz, const 
     int bits = 0;
     while ((1 << bits) <= mask) ++bits;
     const int lds_pts = n_max <= FPS_PTS_CAP ? n_max : 0;
-    // experiment knob: ROITR_FPS_BLOCK forces the workgroup size (register-resident variants only)
-    static const int forced_env = [] { const char* e = getenv("ROITR_FPS_BLOCK"); return e ? atoi(e) : 0; }();
     // few clouds (the one-pair-per-call mode): the chain of m dependent arg-max iterations is the critical path of the whole
     // forward and the chip is empty -- 8 waves per cloud halve the per-lane work of an iteration (4.36 vs 4.48 ms per pair;
     // 16 waves: 5.03, the cross-wave stage grows faster than the lane work shrinks).  Same indices for every block size.
-    const int forced = forced_env ? forced_env : (b <= 16 && n_max <= 512 * 16 ? 512 : 0);
+    const int forced = b <= 16 && n_max <= 512 * 16 ? 512 : 0;
 #define FPS_CASE(BLK, P)                                                                              \
     if (n_max <= (BLK) * (P) && (forced == 0 || forced == (BLK))) {                                   \
         static const hipError_t attr_ = hipFuncSetAttribute((const void*)fps_kernel<BLK, P>,          \
@@ -286,22 +284,10 @@ extern "C" int roitr_furthestsampling(int b, int n_max, const float* xyz, const 
         FPS_CASE(512, 24)
         FPS_CASE(512, 32)
     } else {
-        FPS_CASE(64, 2)
-        FPS_CASE(128, 4)
-        FPS_CASE(128, 16)
-        FPS_CASE(128, 40)
-        FPS_CASE(256, 4)
-        FPS_CASE(256, 8)
-        FPS_CASE(256, 20)
-        FPS_CASE(256, 32)
         FPS_CASE(512, 2)
         FPS_CASE(512, 4)
         FPS_CASE(512, 10)
         FPS_CASE(512, 16)
-        FPS_CASE(1024, 1)
-        FPS_CASE(1024, 2)
-        FPS_CASE(1024, 5)
-        FPS_CASE(1024, 8)
     }
 #undef FPS_CASE
     // Measured and dropped for 16 k .. 30 k points: coordinates in registers (512 threads x 60 points) with the running

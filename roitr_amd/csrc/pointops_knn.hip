@@ -1352,8 +1352,7 @@ extern "C" int roitr_knn_build_grid_ex(int b, int n, int m_capacity, const float
 {
     if (b <= 0 || n <= 0) return ROITR_OK;
     WsView v = carve(ws, b, n, m_capacity);
-    static const float rho_env = [] { const char* e = getenv("ROITR_KNN_RHO"); return e ? (float)atof(e) : 0.f; }();
-    const float rho = rho_env > 0.f ? rho_env : (target_occupancy > 0.f ? target_occupancy : 6.0f);
+    const float rho = target_occupancy > 0.f ? target_occupancy : 6.0f;
     roitr_prof_begin(ROITR_PROF_GRID, 12.0 * n + 16.0 * n, stream);
     grid_build_kernel<<<b, 1024, 0, stream>>>(xyz, offset, v.grids, v.cell_start, v.sorted, rho);
     roitr_prof_end(ROITR_PROF_GRID, stream);
@@ -1368,12 +1367,13 @@ extern "C" const void* roitr_knn_sorted_points(int b, int n, int m_capacity, voi
 
 // The general entry point.  use_grid != 0 requires a prior roitr_knn_build_grid on the same ws.
 // Outputs idx / dist2 / group_idx / ppf are each optional (null = not wanted).
-namespace { float g_knn_cap2 = INFINITY; }
-
-extern "C" int roitr_knnquery_ex(int b, int n, int m, int nsample, const float* xyz, const float* new_xyz, const int* offset,
-                                 const int* new_offset, int* idx, float* dist2, int* group_idx, float* ppf,
-                                 const float* ref_normals, const float* query_normals, int use_grid, int m_capacity, void* ws,
-                                 hipStream_t stream)
+namespace {
+// cap2: the lane kernels may stop a query's ring search once everything unseen is beyond sqrt(cap2) (roitr_knn_within);
+// INFINITY = the exact k nearest neighbours
+int knnquery_impl(int b, int n, int m, int nsample, const float* xyz, const float* new_xyz, const int* offset,
+                  const int* new_offset, int* idx, float* dist2, int* group_idx, float* ppf,
+                  const float* ref_normals, const float* query_normals, int use_grid, int m_capacity, void* ws,
+                  float cap2, hipStream_t stream)
 {
     if (m <= 0) return ROITR_OK;
     if (nsample < 1 || nsample > 100) return ROITR_ERR_ARG;  // best_dist[100], knnquery_cuda_kernel.cu:86
@@ -1389,13 +1389,10 @@ extern "C" int roitr_knnquery_ex(int b, int n, int m, int nsample, const float* 
         bytes += ((idx ? 4.0 * nsample : 0.0) + (dist2 ? 4.0 * nsample : 0.0) + (group_idx ? 4.0 * kk : 0.0) + (ppf ? 16.0 * kk : 0.0)) * m;
         roitr_prof_begin(ROITR_PROF_KNN, bytes, stream);
     }
-    static const int lane_min = [] { const char* e = getenv("ROITR_KNN_LANE_MIN"); return e ? atoi(e) : 8192; }();
-    static const bool lane_brute = getenv("ROITR_KNN_NO_LANE_BRUTE") == nullptr;
+    // kernel choice by shape only (never by the data): a lane per query from 8192 queries on a grid;
     // small clouds without a grid: a lane per query once there are enough queries to fill the chip that way; below that a wave
     // per query (one pair per call: 624 queries at level 3 were 10 waves scanning 1250 references each, 152 us per call)
-    static const int lane_brute_min = [] { const char* e = getenv("ROITR_KNN_LANE_BRUTE_MIN"); return e ? atoi(e) : 65536; }();
-    static const bool gridsel = getenv("ROITR_KNN_NO_GRIDSEL") == nullptr;
-    static const bool cellk = getenv("ROITR_KNN_NO_CELL") == nullptr;
+    constexpr int lane_min = 8192, lane_brute_min = 65536;
     const bool lane_ok = use_grid && m >= lane_min && (!ppf || group_idx) && b > 0;
     const int self_sorted = (new_xyz == xyz && new_offset == offset && m == n) ? 1 : 0;
     // non-self queries: walk them in reference-cell order; the order array reuses the tie list's tail
@@ -1408,27 +1405,26 @@ extern "C" int roitr_knnquery_ex(int b, int n, int m, int nsample, const float* 
     }
 #define LANE_CASE(LC)                                                                                                        \
     knn_lane_kernel<LC><<<div_up(m, 256), 256, 0, stream>>>(m, nsample, b, xyz, new_xyz, offset, new_offset, v.grids, v.cell_start, \
-                                                             v.sorted, o, self_sorted, qorder, g_knn_cap2)
-    static const int sel_min = [] { const char* e = getenv("ROITR_KNN_SEL_MIN"); return e ? atoi(e) : 35; }();   // nsample + 1 from which the selection kernel takes over
-    if (lane_ok && nsample + 1 <= 34 && nsample + 1 < sel_min) {
+                                                             v.sorted, o, self_sorted, qorder, cap2)
+    if (lane_ok && nsample + 1 <= 34) {   // from nsample + 1 = 35 the selection kernels take over
         const int need = nsample + 1;
         if (need <= 2) LANE_CASE(2); else if (need <= 4) LANE_CASE(4); else if (need <= 10) LANE_CASE(10);
         else if (need <= 18) LANE_CASE(18); else LANE_CASE(34);
-    } else if (use_grid && cellk && self_sorted && b > 0 && v.qorder && nsample - 1 <= 64) {
+    } else if (use_grid && self_sorted && b > 0 && v.qorder && nsample - 1 <= 64) {
         // large k, self queries: workgroup per cell over the LDS-staged neighbourhood; what it cannot decide goes through the
         // retry list to the general selection kernel
         int* retry_count = v.tie_count + 1;
         knn_cell_kernel<<<dim3(1024, b), 256, 0, stream>>>(nsample, xyz, offset, v.grids, v.cell_start, v.sorted, o, retry_count, v.qorder);
         knn_gridsel_kernel<<<1024, 256, 0, stream>>>(m, nsample, xyz, new_xyz, offset, new_offset, v.grids, v.cell_start, v.sorted, o, v.qorder,
                                                       retry_count);
-    } else if (use_grid && gridsel && nsample + 1 <= 128) {
+    } else if (use_grid && nsample + 1 <= 128) {
         knn_gridsel_kernel<<<min(blocks, 65536), 256, 0, stream>>>(m, nsample, xyz, new_xyz, offset, new_offset, v.grids, v.cell_start, v.sorted, o,
                                                                     nullptr, nullptr);
     } else if (lane_ok && m >= 4 * lane_min) {
         if (nsample + 1 <= 66) LANE_CASE(66); else LANE_CASE(101);
     } else
 #undef LANE_CASE
-    if (!use_grid && nsample + 1 <= 34 && (!ppf || group_idx) && lane_brute && m >= lane_brute_min) {
+    if (!use_grid && nsample + 1 <= 34 && (!ppf || group_idx) && m >= lane_brute_min) {
 #define LB_CASE(LC) knn_lane_brute_kernel<LC><<<div_up(m, 64), 64, 0, stream>>>(m, nsample, b, xyz, new_xyz, offset, new_offset, o)
         const int need = nsample + 1;
         if (need <= 2) LB_CASE(2); else if (need <= 4) LB_CASE(4); else if (need <= 10) LB_CASE(10);
@@ -1466,6 +1462,16 @@ extern "C" int roitr_knnquery_ex(int b, int n, int m, int nsample, const float* 
     }
     return ROITR_OK;
 }
+}  // namespace
+
+extern "C" int roitr_knnquery_ex(int b, int n, int m, int nsample, const float* xyz, const float* new_xyz, const int* offset,
+                                 const int* new_offset, int* idx, float* dist2, int* group_idx, float* ppf,
+                                 const float* ref_normals, const float* query_normals, int use_grid, int m_capacity, void* ws,
+                                 hipStream_t stream)
+{
+    return knnquery_impl(b, n, m, nsample, xyz, new_xyz, offset, new_offset, idx, dist2, group_idx, ppf, ref_normals, query_normals, use_grid,
+                         m_capacity, ws, INFINITY, stream);
+}
 
 // Exact drop-in for knnquery_cuda_kernel.h:9-17: no batch count, no point count, no workspace, void
 // return, legacy default stream.  Brute-force path (segments are discovered on the device exactly as
@@ -1495,9 +1501,6 @@ extern "C" void knnquery_cuda_launcher(int m, int nsample, const float* xyz, con
 extern "C" int roitr_knn_within(int b, int n, int m, const float* xyz, const float* new_xyz, const int* offset, const int* new_offset,
                                 float cap2, float* dist2, int use_grid, int m_capacity, void* ws, hipStream_t stream)
 {
-    g_knn_cap2 = cap2;
-    const int rc = roitr_knnquery_ex(b, n, m, 1, xyz, new_xyz, offset, new_offset, nullptr, dist2, nullptr, nullptr, nullptr, nullptr, use_grid,
-                                     m_capacity, ws, stream);
-    g_knn_cap2 = INFINITY;
-    return rc;
+    return knnquery_impl(b, n, m, 1, xyz, new_xyz, offset, new_offset, nullptr, dist2, nullptr, nullptr, nullptr, nullptr, use_grid,
+                         m_capacity, ws, cap2, stream);
 }

@@ -7,15 +7,16 @@
 #include <vector>
 
 #include "prof.h"
+#include "roitr_engine.h"
 
 namespace {
-struct Rec { int cls; hipEvent_t a, b; double bytes; };
+struct Rec { int cls; hipEvent_t a, b; double bytes, aux; };
 std::mutex g_mu;
 bool g_on = false;
 std::vector<Rec> g_open;   // begun, not ended (one per class at a time)
 std::vector<Rec> g_done;
 std::vector<hipEvent_t> g_pool;
-double g_ms[ROITR_PROF_CLASSES], g_bytes[ROITR_PROF_CLASSES];
+double g_ms[ROITR_PROF_CLASSES], g_bytes[ROITR_PROF_CLASSES], g_aux[ROITR_PROF_CLASSES];
 long g_launches[ROITR_PROF_CLASSES];
 double g_next_bytes[ROITR_PROF_CLASSES];
 
@@ -35,7 +36,7 @@ void recycle()
     while (n < g_done.size() && hipEventQuery(g_done[n].b) == hipSuccess) {
         Rec& r = g_done[n];
         float ms = 0.f;
-        if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) { g_ms[r.cls] += ms; g_bytes[r.cls] += r.bytes; g_launches[r.cls] += 1; }
+        if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) { g_ms[r.cls] += ms; g_bytes[r.cls] += r.bytes; g_aux[r.cls] += r.aux; g_launches[r.cls] += 1; }
         g_pool.push_back(r.a); g_pool.push_back(r.b);
         ++n;
     }
@@ -47,7 +48,7 @@ void drain()
     for (auto& r : g_done) {
         (void)hipEventSynchronize(r.b);
         float ms = 0.f;
-        if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) { g_ms[r.cls] += ms; g_bytes[r.cls] += r.bytes; g_launches[r.cls] += 1; }
+        if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) { g_ms[r.cls] += ms; g_bytes[r.cls] += r.bytes; g_aux[r.cls] += r.aux; g_launches[r.cls] += 1; }
         g_pool.push_back(r.a); g_pool.push_back(r.b);
     }
     g_done.clear();
@@ -75,7 +76,7 @@ extern "C" void roitr_prof_reset(void)
         if (hipEventCreate(&e) != hipSuccess) break;
         g_pool.push_back(e);
     }
-    for (int i = 0; i < ROITR_PROF_CLASSES; ++i) { g_ms[i] = 0; g_bytes[i] = 0; g_launches[i] = 0; }
+    for (int i = 0; i < ROITR_PROF_CLASSES; ++i) { g_ms[i] = 0; g_bytes[i] = 0; g_aux[i] = 0; g_launches[i] = 0; }
 }
 
 extern "C" int roitr_prof_read(int cls, double* ms, long* launches, double* bytes)
@@ -87,6 +88,17 @@ extern "C" int roitr_prof_read(int cls, double* ms, long* launches, double* byte
     return 0;
 }
 
+// the second accumulator of a class: algorithmic HBM bytes of the MFMA classes (whose "bytes" carry FLOPs); for the engine
+// phases the algorithmic HBM bytes of every instrumented launch inside the phase
+extern "C" int roitr_prof_read_aux(int cls, double* aux)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (cls < 0 || cls >= ROITR_PROF_CLASSES) return 1;
+    drain();
+    *aux = g_aux[cls];
+    return 0;
+}
+
 // bytes for the next begin() of `cls` that passes a negative byte count (the wrapper does not know the sizes)
 extern "C" void roitr_prof_next_bytes(int cls, double bytes)
 {
@@ -94,17 +106,26 @@ extern "C" void roitr_prof_next_bytes(int cls, double bytes)
     if (cls >= 0 && cls < ROITR_PROF_CLASSES) g_next_bytes[cls] = bytes;
 }
 
-void roitr_prof_begin(int cls, double bytes, hipStream_t st)
+void roitr_prof_begin(int cls, double bytes, hipStream_t st) { roitr_prof_begin2(cls, bytes, 0.0, st); }
+
+void roitr_prof_begin2(int cls, double bytes, double aux, hipStream_t st)
 {
     if (!g_on) return;
     std::lock_guard<std::mutex> lk(g_mu);
     if (g_pool.size() < 2 && g_done.size() > 256) recycle();
-    Rec r; r.cls = cls; r.bytes = bytes >= 0.0 ? bytes : g_next_bytes[cls]; r.a = get_event(); r.b = get_event();
-    // MFMA work issued inside an open engine phase is also booked on the phase: the "bytes" of a phase class are the FLOPs
-    // of its GEMM / geo_embed launches (bench.py prices the global-transformer phase against the MFMA peak with them)
-    if (cls == ROITR_PROF_GEMM || cls == ROITR_PROF_GEO_EMBED)
+    Rec r; r.cls = cls; r.bytes = bytes >= 0.0 ? bytes : g_next_bytes[cls]; r.aux = aux; r.a = get_event(); r.b = get_event();
+    if (bytes < 0.0) g_next_bytes[cls] = 0.0;   // consumed: a later launch of the class without its own figure counts 0
+    // Work issued inside an open engine phase is also booked on the phase: the "bytes" of a phase class are the FLOPs of its
+    // GEMM / geo_embed launches (bench.py prices the global-transformer phase against the MFMA peak with them), its "aux" the
+    // algorithmic HBM bytes of every instrumented launch inside it (MFMA classes carry them in aux, the others in bytes)
+    const bool mfma = cls == ROITR_PROF_GEMM || cls == ROITR_PROF_GEO_EMBED;
+    const bool phase = cls >= ROITR_PROF_PH_GEOM && cls <= ROITR_PROF_PH_FORWARD;
+    if (!phase && cls != ROITR_PROF_GEO_ALGO)
         for (auto& o : g_open)
-            if (o.cls >= ROITR_PROF_PH_GEOM && o.cls <= ROITR_PROF_PH_FORWARD) o.bytes += r.bytes;
+            if (o.cls >= ROITR_PROF_PH_GEOM && o.cls <= ROITR_PROF_PH_FORWARD) {
+                if (mfma) { o.bytes += r.bytes; o.aux += r.aux; }
+                else o.aux += r.bytes;
+            }
     (void)hipEventRecord(r.a, st);
     g_open.push_back(r);
 }
@@ -128,4 +149,15 @@ void roitr_prof_end(int cls, hipStream_t st)
             return;
         }
     }
+}
+
+double roitr_gemm_algorithmic_bytes(const RoitrGemm* g)
+{
+    const double ea = (g->bf16 & ROITR_BF16_A) ? 2.0 : 4.0, ew = (g->bf16 & ROITR_BF16_W) ? 2.0 : 4.0, ec = (g->bf16 & ROITR_BF16_C) ? 2.0 : 4.0;
+    const double M = g->M, N = g->N, K = g->K;
+    double per = M * K * ea + N * K * ew + M * N * ec;
+    if (g->A2) per += M * K * 4.0;
+    if (g->ln_res) per += M * N * 4.0;
+    if (g->ln_post) per += M * N * 4.0;
+    return per * g->batch;
 }

@@ -25,6 +25,7 @@ enum {
 };
 
 void roitr_prof_begin(int cls, double bytes, hipStream_t st);
+void roitr_prof_begin2(int cls, double bytes, double aux, hipStream_t st);   // aux: second accumulator (prof.cpp roitr_prof_read_aux)
 void roitr_prof_end(int cls, hipStream_t st);
 void roitr_prof_note(int cls, double v);   // adds v to the class total without a timed bracket
 extern "C" void roitr_prof_enable(int on);
@@ -32,3 +33,9 @@ extern "C" int roitr_prof_is_enabled(void);
 extern "C" void roitr_prof_reset(void);
 extern "C" void roitr_prof_next_bytes(int cls, double bytes);
 extern "C" int roitr_prof_read(int cls, double* ms, long* launches, double* bytes);
+extern "C" int roitr_prof_read_aux(int cls, double* aux);
+
+// Algorithmic HBM bytes of one GEMM launch: every operand element read once, every result written once (rows gathered from a
+// larger tensor count as read once each, a ragged batch is priced at its bounding M x N).  bench.py `roofline` of gemm_kernel.
+struct RoitrGemm;
+double roitr_gemm_algorithmic_bytes(const RoitrGemm* g);

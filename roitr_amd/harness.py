@@ -4,9 +4,10 @@ import numpy as np
 import torch
 
 
-def build_model(benchmark="3DMatch", operand_dtype="f32"):
+def build_model(benchmark="3DMatch", operand_dtype="f32", weights="plain"):
     """create_model(test config of `benchmark`) with closed-form weights on the current ROCm device.
-    operand_dtype: 'f32' (reference arithmetic) or 'bf16' (BASELINE config 4: bf16 operand storage for the dense layers)."""
+    operand_dtype: 'f32' (reference arithmetic) or 'bf16' (BASELINE config 4: bf16 operand storage for the dense layers).
+    weights: closed-form variant, 'plain' | 'selective' (roitr_amd/weights.py)."""
     from .config import test_config
     from .riga import create_model, state_dict_layout
     from .weights import closed_form_param
@@ -17,7 +18,7 @@ def build_model(benchmark="3DMatch", operand_dtype="f32"):
     sd = model.state_dict()
     for k, shape, kind in state_dict_layout(model.factor, model.architecture):  # factor 2 for 4DMatch
         if kind == "param":
-            sd[k].copy_(torch.from_numpy(closed_form_param(k, tuple(shape))))
+            sd[k].copy_(torch.from_numpy(closed_form_param(k, tuple(shape), weights)))
     model = model.cuda().eval()
     model.sync_engine()
     return model

@@ -56,13 +56,14 @@ def _knn(nsample, xyz, new_xyz, offset, new_offset, want_idx=True, want_dist=Tru
     offset, new_offset = _i32(offset).contiguous(), _i32(new_offset).contiguous()
     n, m, b = xyz.shape[0], new_xyz.shape[0], offset.shape[0]
     dev = xyz.device
-    idx = torch.zeros((m, nsample), dtype=torch.int32, device=dev) if want_idx else None
-    d2 = torch.zeros((m, nsample), dtype=torch.float32, device=dev) if want_dist else None
-    grp = torch.zeros((m, nsample - 1), dtype=torch.int32, device=dev) if want_group else None
+    # every element of the outputs is written by the query kernels (the engine hands them uninitialised arena memory too)
+    idx = torch.empty((m, nsample), dtype=torch.int32, device=dev) if want_idx else None
+    d2 = torch.empty((m, nsample), dtype=torch.float32, device=dev) if want_dist else None
+    grp = torch.empty((m, nsample - 1), dtype=torch.int32, device=dev) if want_group else None
     ppf = None
     if ref_normals is not None:
         assert ref_normals.is_contiguous() and query_normals.is_contiguous()
-        ppf = torch.zeros((m, nsample - 1, 4), dtype=torch.float32, device=dev)
+        ppf = torch.empty((m, nsample - 1, 4), dtype=torch.float32, device=dev)
     if use_grid is None:
         use_grid = n > GRID_MIN_POINTS * b
     lib = L.lib()

@@ -286,8 +286,12 @@ class RIGA_v2(nn.Module):
         for name, cid in cls.PROF_CLASSES.items():
             ms, n, by = ctypes.c_double(0), ctypes.c_long(0), ctypes.c_double(0)
             lib.roitr_prof_read(cid, ctypes.byref(ms), ctypes.byref(n), ctypes.byref(by))
+            aux = ctypes.c_double(0)
+            lib.roitr_prof_read_aux(cid, ctypes.byref(aux))
             if n.value and (not kernels_only or not name.startswith("phase.")):
-                out[name] = {"ms": ms.value, "launches": n.value, "bytes": by.value}
+                # bytes: algorithmic HBM bytes (FLOPs for gemm_kernel / geo_embed_kernel / the phases); aux: algorithmic HBM bytes
+                # of the MFMA classes and of every instrumented launch inside a phase (csrc/prof.cpp)
+                out[name] = {"ms": ms.value, "launches": n.value, "bytes": by.value, "aux": aux.value}
         lib.roitr_prof_enable(0)
         return out
 
@@ -471,16 +475,20 @@ class RIGA_v2(nn.Module):
         return dict(pairs=pairs, out=out, B=B, P=P, n_all=n_all, n4=n4, have_gt=have_gt, meta_host=slot["meta_host"], done=done, keep=keep)
 
     def max_scores_per_pair(self):
-        """Correspondence capacity of one pair's result record (shard.py): exact for the 3DMatch settings; the adaptive
-        4DMatch matching may select every node pair, there the record keeps 4x its min_num_correspondences patches."""
+        """Exact upper bound of the correspondences one pair can emit under the 3DMatch settings (mutual top-k fine matching on
+        num_est_coarse_corr patches); the adaptive 4DMatch matching may select every node pair, so it has no such bound."""
         from .shard import max_scores_per_pair
-        patches = self.num_est_coarse_corr if self.factor == 1 else 4 * self.num_est_coarse_corr
-        return max_scores_per_pair(patches, self.point_per_patch, self.fine_topk, self.fine_mutual)
+        return max_scores_per_pair(self.num_est_coarse_corr, self.point_per_patch, self.fine_topk, self.fine_mutual)
+
+    def record_scores_per_pair(self):
+        """AVERAGE score capacity per pair of the rank's result-record block (shard.py; config key `record_scores_per_pair`)."""
+        from .shard import DEFAULT_SCORES_PER_PAIR
+        return int(_cfg_get(self.config, "record_scores_per_pair", DEFAULT_SCORES_PER_PAIR))
 
     def batch_records(self, handle, pair_ids, aux=None):
-        """The result records (shard.py layout) of a FINISHED batch, packed on the device."""
+        """The result records (shard.RecordBatch) of a FINISHED batch: headers + one contiguous slice of the engine's scores."""
         from .shard import pack_records
-        return pack_records(pair_ids, handle["starts"], handle["out"]["out_scores"], self.max_scores_per_pair(), aux)
+        return pack_records(pair_ids, handle["starts"], handle["out"]["out_scores"], aux)
 
     def graph_count(self):
         """Forwards currently held as instantiated HIP graphs."""

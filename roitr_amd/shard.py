@@ -5,18 +5,21 @@ state, read-only weights), so the partition is the one a DistributedSampler woul
 pair i -> rank i mod W.  No data-path collective exists; the only exchange is ONE gather of the per-pair
 result records (match scores) to rank 0 over RCCL/xGMI at the end of a run.
 
-Record layout (int32 words, fixed size so that no size pre-exchange is needed):
-    [pair_id, n_scores, aux0, aux1 | score bits ... padded to max_scores]
-`pair_id` = -1 marks an unused slot, `n_scores` is the TRUE number of correspondences of the pair (a value above
-`max_scores` means the tail was cut: with the reference's mutual top-k fine matching `num_corr * 64 * k` is an exact
-upper bound, so 3DMatch records are never cut), aux0/aux1 carry two fp32 values (the tester puts IR / PIR there),
-scores travel as their fp32 bit patterns.  Every rank contributes `slots` records; slots = ceil(n_pairs / world) is
-known on every rank from the pair count alone.
+Block layout (one per rank, int32 words, fixed size so that no size pre-exchange is needed):
+    [slots x (pair_id, n_scores, aux0, aux1)] [pool: slots * scores_per_pair score words]
+The headers are one per slot; `pair_id` = -1 marks an unused slot, `n_scores` is the TRUE number of correspondences of the
+pair, aux0 / aux1 carry two fp32 values (the tester puts IR / PIR there).  The scores of the used slots lie back to back in
+the pool in slot order as fp32 bit patterns -- a pair may use more than `scores_per_pair` words as long as the rank's total
+fits (`scores_per_pair` is the AVERAGE capacity: the exact upper bound of the mutual top-k fine matching, num_corr * 64 * k =
+49 152 for the 3DMatch settings, is 100 MB per 512 pairs, three orders of magnitude above what travels).  When the pool is
+full the tail is cut: the receiver sees it from the headers (sum of n_scores > pool) and lists the cut pairs in `.truncated`.
+Default: 4092 scores per pair on average = 16 KB per slot, 8 MB per 512 pairs.
 """
 import torch
 import torch.distributed as dist
 
 HEADER = 4
+DEFAULT_SCORES_PER_PAIR = 4092
 
 
 def pairs_for_rank(n_pairs, rank, world):
@@ -31,6 +34,10 @@ def slots_per_rank(n_pairs, world):
 def max_scores_per_pair(num_corr, point_limit, fine_topk, mutual=True):
     """Upper bound of correspondences one pair can emit (modules.py:259-266: row top-k AND/OR column top-k per patch)."""
     return int(num_corr) * int(point_limit) * int(fine_topk) * (1 if mutual else 2)
+
+
+def block_words(slots, scores_per_pair):
+    return int(slots) * (HEADER + int(scores_per_pair))
 
 
 def _group_device():
@@ -48,80 +55,99 @@ def gather_counts(value):
     return [int(x.item()) for x in out]
 
 
-def empty_records(slots, max_scores, device):
-    buf = torch.zeros((slots, HEADER + max_scores), dtype=torch.int32, device=device)
-    buf[:, 0] = -1
-    return buf
+class RecordBatch:
+    """The records of one engine batch before they are laid into the rank's block: `headers` (B, 4) int32 and the batch's
+    scores (n,) float32, pair after pair -- both on the device the scores came from."""
+
+    def __init__(self, headers, scores):
+        self.headers, self.scores = headers, scores
+
+    def __len__(self):
+        return int(self.headers.shape[0])
 
 
-def pack_records(pair_ids, starts, scores_flat, max_scores, aux=None):
-    """Records of one engine batch, built on the device without a host round trip per pair.
+def pack_records(pair_ids, starts, scores_flat, aux=None):
+    """Records of one engine batch.  No per-pair work: the engine already emits the scores of a batch pair after pair, so the
+    pool part is ONE contiguous slice of its `out_scores` (copied, so that the 100 MB output buffer is not kept alive), and the
+    header is built on the host from numbers finish_batch() holds there anyway.
 
-    pair_ids: B global pair indices; starts: B+1 row offsets into `scores_flat` (the engine's fine_offsets + n_out, as
-    finish_batch() already holds them on the host); scores_flat: the engine's out_scores; aux: optional (B,2) float tensor."""
+    pair_ids: B global pair indices; starts: B+1 row offsets into `scores_flat` (the engine's fine_offsets + n_out);
+    aux: optional (B, 2) float tensor (device)."""
     dev = scores_flat.device
     B = len(pair_ids)
-    buf = empty_records(B, max_scores, dev)
-    if B == 0:
-        return buf
-    st = torch.as_tensor(list(starts), dtype=torch.int64, device=dev)
-    buf[:, 0] = torch.as_tensor(list(pair_ids), dtype=torch.int32, device=dev)
-    buf[:, 1] = (st[1:] - st[:-1]).to(torch.int32)
-    if aux is not None:
-        buf[:, 2:4] = aux.to(device=dev, dtype=torch.float32).contiguous().view(torch.int32)
-    lo, hi = int(starts[0]), int(starts[-1])
-    if hi > lo:
-        r = torch.arange(lo, hi, device=dev)
-        pair = torch.searchsorted(st[1:], r, right=True)
-        col = r - st[pair]
-        keep = col < max_scores
-        bits = scores_flat[lo:hi].contiguous().view(torch.int32)
-        buf[pair[keep], HEADER + col[keep]] = bits[keep]
-    return buf
+    head = torch.zeros((B, HEADER), dtype=torch.int32)
+    if B:
+        st = torch.as_tensor(list(starts), dtype=torch.int64)
+        head[:, 0] = torch.as_tensor(list(pair_ids), dtype=torch.int32)
+        head[:, 1] = (st[1:] - st[:-1]).to(torch.int32)
+    head = head.to(dev)
+    if aux is not None and B:
+        head[:, 2:4] = aux.to(device=dev, dtype=torch.float32).contiguous().view(torch.int32)
+    lo, hi = (int(starts[0]), int(starts[-1])) if B else (0, 0)
+    return RecordBatch(head, scores_flat[lo:hi].to(torch.float32).clone())
 
 
-def records_from_list(records, max_scores, device=None):
-    """[(pair_id, 1-D float tensor)] or [(pair_id, tensor, (aux0, aux1))] -> packed record buffer."""
-    if device is None:
-        device = records[0][1].device if records else "cpu"
-    buf = empty_records(len(records), max_scores, device)
+def records_from_list(records):
+    """[(pair_id, 1-D float tensor)] or [(pair_id, tensor, (aux0, aux1))] -> RecordBatch (host-side helper of the tests)."""
+    device = records[0][1].device if records else "cpu"
+    head = torch.zeros((len(records), HEADER), dtype=torch.int32)
     for i, rec in enumerate(records):
-        pid, s = rec[0], rec[1]
-        n = int(s.numel())
-        buf[i, 0] = int(pid)
-        buf[i, 1] = n
+        head[i, 0], head[i, 1] = int(rec[0]), int(rec[1].numel())
         if len(rec) > 2:
-            buf[i, 2:4] = torch.tensor(list(rec[2]), dtype=torch.float32, device=device).view(torch.int32)
-        k = min(n, max_scores)
-        if k:
-            buf[i, HEADER:HEADER + k] = s.detach().to(device, torch.float32).contiguous().view(torch.int32)[:k]
-    return buf
+            head[i, 2:4] = torch.tensor(list(rec[2]), dtype=torch.float32).view(torch.int32)
+    scores = torch.cat([r[1].detach().to(device, torch.float32).reshape(-1) for r in records]) if records else torch.zeros(0)
+    return RecordBatch(head.to(device), scores)
+
+
+def assemble_block(batches, slots, scores_per_pair=DEFAULT_SCORES_PER_PAIR, device=None):
+    """Lay the RecordBatches of a rank (in order) into its fixed-size block; unused slots get pair_id -1."""
+    batches = list(batches)
+    if device is None:
+        device = batches[0].headers.device if batches else "cpu"
+    n = sum(len(b) for b in batches)
+    if n > slots:
+        raise ValueError(f"{n} records for {slots} slots")
+    pool = int(slots) * int(scores_per_pair)
+    block = torch.zeros(block_words(slots, scores_per_pair), dtype=torch.int32, device=device)
+    heads = block[:slots * HEADER].view(slots, HEADER)
+    heads[n:, 0] = -1
+    if n:
+        heads[:n] = torch.cat([b.headers.to(device) for b in batches], 0)
+        sc = torch.cat([b.scores.to(device) for b in batches])
+        k = min(int(sc.numel()), pool)
+        block[slots * HEADER:slots * HEADER + k] = sc[:k].contiguous().view(torch.int32)
+    return block
 
 
 class GatheredRecords:
-    """Rank 0's view of the gathered record blocks: a read-only mapping {pair_id: scores (1-D float32 cpu tensor)}.
-    Only the record headers are copied to the host eagerly; a pair's scores leave the device when they are read.
-    .aux {pair_id: (aux0, aux1)}, .n_scores {pair_id: true count}, .truncated [pair ids whose tail was cut],
-    .ranks_seen (ranks that contributed at least one record), .backend ('nccl' = RCCL, 'gloo', 'local' = no process group)."""
+    """Rank 0's view of the gathered blocks: a read-only mapping {pair_id: scores (1-D float32 cpu tensor)}.
+    Only the headers are copied to the host eagerly; a pair's scores leave the device when they are read.
+    .aux {pair_id: (aux0, aux1)}, .n_scores {pair_id: true count}, .truncated [pair ids whose scores were cut by a full
+    pool], .ranks_seen (ranks that contributed at least one record), .backend ('nccl' = RCCL, 'gloo', 'local' = no group)."""
 
-    def __init__(self, blocks, max_scores, backend):
-        self.blocks, self.max_scores, self.backend = blocks, max_scores, backend
+    def __init__(self, blocks, slots, scores_per_pair, backend):
+        self.blocks, self.slots, self.scores_per_pair, self.backend = blocks, int(slots), int(scores_per_pair), backend
         self.aux, self.n_scores, self.truncated, self._where = {}, {}, [], {}
-        heads = torch.stack([b[:, :HEADER] for b in blocks]).cpu() if blocks and blocks[0].shape[0] else torch.zeros((len(blocks), 0, HEADER), dtype=torch.int32)
+        pool = self.slots * self.scores_per_pair
+        heads = (torch.stack([b[:self.slots * HEADER].view(self.slots, HEADER) for b in blocks]).cpu() if blocks and self.slots
+                 else torch.zeros((len(blocks), 0, HEADER), dtype=torch.int32))
         auxf = heads[:, :, 2:4].contiguous().view(torch.float32)
         seen = set()
         for r in range(heads.shape[0]):
             ids, ns = heads[r, :, 0].tolist(), heads[r, :, 1].tolist()
             ax = auxf[r].tolist()
+            cur = 0
             for i, pid in enumerate(ids):
                 if pid < 0:
                     continue
                 seen.add(r)
-                self._where[pid] = (r, i)
+                have = max(0, min(ns[i], pool - cur))
+                self._where[pid] = (r, cur, have)
                 self.n_scores[pid] = ns[i]
                 self.aux[pid] = (ax[i][0], ax[i][1])
-                if ns[i] > max_scores:
+                if have < ns[i]:
                     self.truncated.append(pid)
+                cur += ns[i]
         self.ranks_seen = len(seen)
 
     def __len__(self):
@@ -137,38 +163,39 @@ class GatheredRecords:
         return self._where.keys()
 
     def __getitem__(self, pid):
-        r, i = self._where[pid]
-        k = min(self.n_scores[pid], self.max_scores)
-        return self.blocks[r][i, HEADER:HEADER + k].cpu().view(torch.float32)
+        r, off, k = self._where[pid]
+        base = self.slots * HEADER + off
+        return self.blocks[r][base:base + k].cpu().view(torch.float32)
 
     def items(self):
         return [(pid, self[pid]) for pid in self._where]
 
 
-def gather_result_records(records, slots, max_scores):
-    """THE collective of the path: every rank sends its (slots, HEADER + max_scores) int32 record block to rank 0 in ONE
+def gather_result_records(records, slots, scores_per_pair=DEFAULT_SCORES_PER_PAIR):
+    """THE collective of the path: every rank sends its block (block_words(slots, scores_per_pair) int32) to rank 0 in ONE
     `gather` (RCCL over xGMI with backend 'nccl', gloo in the CPU tests; nothing is exchanged without a process group).
 
-    records: a packed buffer (pack_records / records_from_list; fewer than `slots` rows are padded with empty slots) or a
-    list accepted by records_from_list.  Returns a GatheredRecords on rank 0, None elsewhere."""
+    records: an assembled block, a RecordBatch, a list of RecordBatches (laid out in order) or a list accepted by
+    records_from_list.  Returns a GatheredRecords on rank 0, None elsewhere."""
     distributed = dist.is_available() and dist.is_initialized()
     dev = _group_device() if distributed else None
+    if isinstance(records, RecordBatch):
+        records = [records]
     if not torch.is_tensor(records):
-        records = records_from_list(records, max_scores, dev)
-    if records.shape[0] > slots:
-        raise ValueError(f"{records.shape[0]} records for {slots} slots")
-    if records.shape[1] != HEADER + max_scores:
-        raise ValueError("record width does not match max_scores")
+        records = list(records)
+        if records and not isinstance(records[0], RecordBatch):
+            records = [records_from_list(records)]
+        records = assemble_block(records, slots, scores_per_pair, dev)
+    if records.numel() != block_words(slots, scores_per_pair):
+        raise ValueError("block size does not match (slots, scores_per_pair)")
     if distributed and records.device.type != torch.device(dev).type:
         records = records.to(dev)
-    if records.shape[0] < slots:
-        records = torch.cat([records, empty_records(slots - records.shape[0], max_scores, records.device)], 0)
     records = records.contiguous()
     if not distributed:
-        return GatheredRecords([records], max_scores, "local")
+        return GatheredRecords([records], slots, scores_per_pair, "local")
     world, rank = dist.get_world_size(), dist.get_rank()
     blocks = [torch.empty_like(records) for _ in range(world)] if rank == 0 else None
     dist.gather(records, blocks, dst=0)
     if rank != 0:
         return None
-    return GatheredRecords(blocks, max_scores, dist.get_backend())
+    return GatheredRecords(blocks, slots, scores_per_pair, dist.get_backend())

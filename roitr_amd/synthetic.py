@@ -32,6 +32,16 @@ def _normals(rng, pts):
     return n
 
 
+def field_normals(scene_pts):
+    """A smooth unit vector field of the SCENE position: the same physical point carries the same normal in both clouds of a
+    pair (up to the pair's rotation), so the PPFs of re-observed neighbourhoods agree -- what real surfaces give the reference."""
+    p = scene_pts
+    g = np.stack([np.cos(3.1 * p[:, 0] + 0.3) + 0.7 * np.sin(2.3 * p[:, 1]),
+                  np.sin(2.7 * p[:, 1] + 1.1) + 0.6 * np.cos(3.3 * p[:, 2]),
+                  np.cos(2.9 * p[:, 2] - 0.4) + 0.8 * np.sin(2.1 * p[:, 0] + p[:, 1])], 1) + 0.35
+    return g / np.linalg.norm(g, axis=1, keepdims=True)
+
+
 def euler_zyx(a):
     """scipy Rotation.from_euler('zyx', a).as_matrix() (dataset/tdmatch.py:102): extrinsic rotations about z, then y, then x."""
     cz, sz, cy, sy, cx, sx = np.cos(a[0]), np.sin(a[0]), np.cos(a[1]), np.sin(a[1]), np.cos(a[2]), np.sin(a[2])
@@ -41,8 +51,10 @@ def euler_zyx(a):
     return rx @ ry @ rz
 
 
-def make_pair(n_src, n_tgt=None, config=2, pair_index=0, overlap=0.6, jitter=0.002, rotated=None):
+def make_pair(n_src, n_tgt=None, config=2, pair_index=0, overlap=0.6, jitter=0.002, rotated=None, normals="random"):
     """Returns a dict of float32 numpy arrays following the reference input contract.
+    normals: 'random' (independent unit vectors per cloud, flipped toward the origin like dataset/common.py:312-320) or 'field'
+    (field_normals of the scene position, carried through the pair's rigid transform: corresponding points share their normal).
     rotated (default: config == 3, BASELINE config 3 "3DLoMatch rotated"): the test-time rotation of dataset/tdmatch.py:99-112 --
     a seeded full-range euler rotation applied to the source or the target cloud, folded into rot / trans."""
     n_tgt = n_src if n_tgt is None else n_tgt
@@ -62,6 +74,11 @@ def make_pair(n_src, n_tgt=None, config=2, pair_index=0, overlap=0.6, jitter=0.0
     rot = random_rotation(rng)
     trans = rng.uniform(-1.0, 1.0, (3, 1))
     tgt = tgt_scene @ rot.T + trans.T
+    src_n = tgt_n = None
+    if normals == "field":
+        src_n, tgt_n = field_normals(src), field_normals(tgt_scene) @ rot.T
+    elif normals != "random":
+        raise ValueError(f"normals must be 'random' or 'field', got {normals!r}")
     if rotated is None:
         rotated = config == 3
     if rotated:
@@ -69,12 +86,15 @@ def make_pair(n_src, n_tgt=None, config=2, pair_index=0, overlap=0.6, jitter=0.0
         if rng.random() > 0.5:
             src = src @ rot_ab.T
             rot = rot @ rot_ab.T
+            src_n = src_n @ rot_ab.T if src_n is not None else None
         else:
             tgt = tgt @ rot_ab.T
             rot = rot_ab @ rot
             trans = rot_ab @ trans
-    src_n = _normals(rng, src)
-    tgt_n = _normals(rng, tgt)
+            tgt_n = tgt_n @ rot_ab.T if tgt_n is not None else None
+    if normals == "random":
+        src_n = _normals(rng, src)
+        tgt_n = _normals(rng, tgt)
     f32 = np.float32
     return {
         "src_points": np.ascontiguousarray(src, f32),

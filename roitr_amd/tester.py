@@ -6,14 +6,15 @@ Differences by design: pairs are sharded over ranks by their GLOBAL index (pair 
 keeps the global index -- the reference's DDP test mode would overwrite files), several
 pairs go through the engine per forward (`pairs_per_forward`), and checkpoints load through the same
 'module.'-stripping rule as lib/trainer.py:94-130.  At the end of the run ONE collective (shard.gather_result_records:
-a gather of the fixed-size per-pair records {pair id, #correspondences, IR, PIR, match scores} over RCCL) brings every
-rank's results to rank 0; `Tester.records` holds them there.
+a gather of the per-pair records {pair id, #correspondences, IR, PIR, match scores}, packed into one fixed-size block per
+rank, over RCCL) brings every rank's results to rank 0; `Tester.records` holds them there.  `test()` returns the per-rank
+correspondence counts on rank 0 and None on every other rank (only rank 0 receives the records).
 """
 import os
 
 import torch
 
-from .shard import gather_result_records, pairs_for_rank, slots_per_rank
+from .shard import assemble_block, gather_result_records, pairs_for_rank, slots_per_rank
 
 
 def load_pretrain(model, path):
@@ -105,12 +106,16 @@ class Tester:
                         data["metric_index_list"] = it["metric_index"]
                     torch.save(data, os.path.join(out_dir, f"{idx}.pth"))
         # ---- the one collective of the run: every rank's records -> rank 0 (RCCL over xGMI under torch.distributed.run)
-        max_scores = self.model.max_scores_per_pair()
-        from .shard import empty_records
-        mine_block = torch.cat(blocks, 0) if blocks else empty_records(0, max_scores, device)
-        self.records = gather_result_records(mine_block, slots_per_rank(n, self.world), max_scores)
+        per_pair = self.model.record_scores_per_pair()
+        self.records = gather_result_records(assemble_block(blocks, slots_per_rank(n, self.world), per_pair, device),
+                                             slots_per_rank(n, self.world), per_pair)
         if self.records is None:     # ranks other than 0
             return None
+        if self.records.truncated:
+            import warnings
+            warnings.warn(f"result records: the score pool of a rank was full, the scores of {len(self.records.truncated)} pair(s) were "
+                          f"cut (first: {self.records.truncated[:8]}); raise config key record_scores_per_pair (now {per_pair}). "
+                          "The .pth files on disk are complete.")
         counts = [0] * self.world
         for pid, cnt in self.records.n_scores.items():
             counts[pid % self.world] += cnt

@@ -41,8 +41,46 @@ def hashed_uniform(key, numel):
     return (bits >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
 
 
-def closed_form_param(key, shape):
-    """float32 array for the parameter called `key` with `shape`."""
+# ---- the "selective" variant --------------------------------------------------------------------------------------------
+# With the plain initialiser-sized weights every descriptor is dominated by one common vector (constant input features,
+# biases): all superpoint descriptors of a cloud agree to cos > 0.97, so the 4DMatch similarity threshold (0.75,
+# model/RIGA_v2.py:27) admits EVERY node pair and no fine-matching score clears 0.05.  The selective variant keeps the same
+# hash but (a) raises the gain of the geometry-dependent inputs -- the local PPF embeddings (x8), the two projections of the
+# geometric structure embedding (x4) -- and of the point-descriptor head `fine_proj` (x4: the patch scores are quadratic in
+# it), and (b) moves `coarse_proj.bias` by -W c, where c is a fixed per-width vector (configs/selective_centre.npz: the mean
+# global-transformer output on one synthetic calibration pair of the bench size, scaled so that a few percent of the node
+# pairs fall under the threshold there; written by tests/golden/calibrate_selective.py).  It is still a pure function of
+# (key, shape) plus that committed constant, so the reference model, the oracle and the engine agree on it bit for bit.
+SELECTIVE_GAIN = {".embedding.proj.weight": 8.0, ".embedding.proj_d.weight": 4.0, ".embedding.proj_a.weight": 4.0,
+                  "fine_proj.weight": 4.0, "fine_proj.bias": 4.0}
+_CENTRE = None
+
+
+def selective_centre(width):
+    """The committed centring vector for descriptor width `width` (256: 3DMatch, 512: 4DMatch)."""
+    global _CENTRE
+    if _CENTRE is None:
+        import os
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "configs", "selective_centre.npz")
+        with np.load(path) as z:
+            _CENTRE = {int(k[1:]): z[k].astype(np.float64) for k in z.files}
+    return _CENTRE[int(width)]
+
+
+def closed_form_param(key, shape, variant="plain"):
+    """float32 array for the parameter called `key` with `shape`; variant: 'plain' | 'selective' (see above)."""
+    if variant == "selective":
+        base = closed_form_param(key, shape).astype(np.float64)
+        for suffix, gain in SELECTIVE_GAIN.items():
+            if key.endswith(suffix):
+                base = base * gain
+        if key == "coarse_proj.bias":
+            n = int(shape[0])
+            w = closed_form_param("coarse_proj.weight", (n, n)).astype(np.float64)
+            base = base - w @ selective_centre(n)
+        return base.astype(np.float32)
+    if variant != "plain":
+        raise ValueError(f"unknown weight variant {variant!r}")
     shape = tuple(int(s) for s in shape)
     numel = int(np.prod(shape)) if len(shape) else 1
     u = hashed_uniform(key, numel) * 2.0 - 1.0  # [-1, 1)
@@ -60,6 +98,6 @@ def closed_form_param(key, shape):
     return np.asarray(v, dtype=np.float64).reshape(shape).astype(np.float32)
 
 
-def closed_form_state(layout):
+def closed_form_state(layout, variant="plain"):
     """layout: iterable of (key, shape) -> dict key -> float32 ndarray."""
-    return {k: closed_form_param(k, s) for k, s in layout}
+    return {k: closed_form_param(k, s, variant) for k, s in layout}

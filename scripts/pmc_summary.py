@@ -1,6 +1,8 @@
 """HBM traffic per launch from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE), per kernel family.
 
-    python scripts/pmc_summary.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json> [pairs_per_step]
+    python scripts/pmc_summary.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json> [pairs_per_step] [steps] [config]
+
+`steps` = engine forwards the profiled command ran (warm-up included): `total_hbm_bytes_per_step` = every kernel's bytes / steps.
 
 Units / corrections follow /opt/skills/guides/MI355X_MICROARCH.md "HBM [CDNA4]": FETCH_SIZE and WRITE_SIZE are
 reported in KiB-ish units of 1024 B; on gfx950 FETCH_SIZE tallies 128-B requests at 64 B, so it is DOUBLED for wide
@@ -20,7 +22,9 @@ def load(path, counter):
 
 f, fn = load(sys.argv[1], "FETCH_SIZE")
 w, wn = load(sys.argv[2], "WRITE_SIZE")
-out = {"pairs_per_step": int(sys.argv[4]) if len(sys.argv) > 4 else None,
+steps = int(sys.argv[5]) if len(sys.argv) > 5 else None
+out = {"pairs_per_step": int(sys.argv[4]) if len(sys.argv) > 4 else None, "baseline_config": int(sys.argv[6]) if len(sys.argv) > 6 else 2,
+       "forwards_profiled": steps,
        "note": "bytes per launch; fetch = FETCH_SIZE*1024*2 (gfx950 half-count correction), write = WRITE_SIZE*1024", "kernels": {}}
 for k in sorted(f, key=lambda k: -f[k]):
     if k.startswith("__amd") or "at::" in k:
@@ -29,6 +33,9 @@ for k in sorted(f, key=lambda k: -f[k]):
     wb = w.get(k, 0.0) * 1024 / max(wn.get(k, 1), 1)
     out["kernels"][k] = {"launches": fn[k], "fetch_bytes_per_launch": round(fb), "write_bytes_per_launch": round(wb),
                          "hbm_bytes_per_launch": round(fb + wb)}
+if steps:
+    tot = sum(v * 1024 * 2 for k, v in f.items() if not k.startswith("__amd")) + sum(v * 1024 for k, v in w.items() if not k.startswith("__amd"))
+    out["total_hbm_bytes_per_step"] = round(tot / steps)
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 for k, v in list(out["kernels"].items())[:14]:
     print(f"{k:28s} launches {v['launches']:5d}  fetch {v['fetch_bytes_per_launch']/1e6:9.2f} MB  write {v['write_bytes_per_launch']/1e6:9.2f} MB")

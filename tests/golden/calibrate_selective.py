@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""Writes roitr_amd/configs/selective_centre.npz: the constant vectors of the 'selective' closed-form weight variant
+(roitr_amd/weights.py).  Test / bench-workload tooling, run once in the authoring container; the result is committed.
+
+For each descriptor width (256: 3DMatch settings, 512: 4DMatch settings) one synthetic calibration pair of the bench size
+(N = 5000 / 8000, field normals, seed config 7) goes through the CPU oracle with the selective gains and a ZERO centre; c is
+the mean global-transformer output over the superpoints of both clouds.  3DMatch: the full mean (top-256 selection is scale
+free).  4DMatch: lambda * mean with the largest lambda on a 0.01 grid that leaves at least 3 % of the calibration pair's node
+pairs under the 0.75 feature-distance threshold of AdaptiveSuperPointMatching (model/RIGA_v2.py:27) -- so the threshold branch
+of the adaptive matching is what the full-size tests and `bench.py --config 4` exercise, on a few hundred patches per pair
+instead of all 15 625.
+
+Usage: python tests/golden/calibrate_selective.py
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+
+from oracle import roitr_ref as R  # noqa: E402
+from roitr_amd import weights as Wt  # noqa: E402
+from roitr_amd.synthetic import make_pair  # noqa: E402
+
+
+def node_distances(sd, g0, g1, c):
+    W, b = sd["coarse_proj.weight"].astype(np.float64), sd["coarse_proj.bias"].astype(np.float64)
+
+    def nf(g):
+        y = g.astype(np.float64) @ W.T + (b - W @ c)
+        return y / np.linalg.norm(y, axis=1, keepdims=True)
+    return np.sqrt(np.maximum(2.0 - 2.0 * (nf(g1) @ nf(g0).T), 0.0))
+
+
+def main():
+    Wt._CENTRE = {256: np.zeros(256), 512: np.zeros(512)}
+    cores = len(os.sched_getaffinity(0))
+    out = {}
+    for factor, n, cfg in ((1, 5000, None), (2, 8000, dict(R.FDMATCH_CFG))):
+        sd = R.closed_form_state(factor, "selective")
+        pair = make_pair(n, config=7, pair_index=factor, normals="field")
+        taps = {}
+        R.forward(sd, pair, cfg=cfg, threads=cores, taps=taps)
+        g0, g1 = taps["geo.out"]
+        mean = np.concatenate([g0, g1]).astype(np.float64).mean(0)
+        lam = 1.0
+        if factor == 2:
+            for lam in np.arange(1.0, 0.0, -0.01):
+                frac = float((node_distances(sd, g0, g1, lam * mean) <= 0.75).mean())
+                if frac >= 0.03:
+                    break
+        d = node_distances(sd, g0, g1, lam * mean)
+        print(f"factor {factor}: N = {n}, {g0.shape[0]} + {g1.shape[0]} nodes, lambda = {lam:.2f}, node pairs under 0.75: "
+              f"{float((d <= 0.75).mean()):.4f}, distance min / mean {d.min():.3f} / {d.mean():.3f}")
+        out[f"c{256 * factor}"] = (lam * mean).astype(np.float32)
+    path = os.path.join(ROOT, "roitr_amd", "configs", "selective_centre.npz")
+    np.savez(path, **out)
+    print("wrote", path)
+
+
+if __name__ == "__main__":
+    main()

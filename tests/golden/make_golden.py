@@ -78,14 +78,14 @@ def load_ref_config(benchmark="3DMatch"):
     return EasyDict(flat)
 
 
-def build_reference_model(benchmark="3DMatch"):
+def build_reference_model(benchmark="3DMatch", variant="plain"):
     from model.RIGA_v2 import create_model
     cfg = load_ref_config(benchmark)
     cfg["mode"] = "test"
     model = create_model(cfg)
     with torch.no_grad():
         for k, p in model.named_parameters():
-            p.copy_(torch.from_numpy(closed_form_param(k, tuple(p.shape))))
+            p.copy_(torch.from_numpy(closed_form_param(k, tuple(p.shape), variant)))
     model.eval()
     return model, cfg
 
@@ -100,20 +100,24 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--n", type=int, default=1024)
     ap.add_argument("--config", type=int, default=1)
+    ap.add_argument("--selective", action="store_true",
+                    help="the 'selective' weight variant (roitr_amd/weights.py) on a pair with field normals -> pair_sel_n<N>.npz: the "
+                         "golden whose forward ends in a NON-EMPTY correspondence set (end-to-end values, not only stage taps)")
     args = ap.parse_args()
     install_stubs()
     torch.manual_seed(0)
     torch.set_num_threads(8)
-    model, cfg = build_reference_model()
+    model, cfg = build_reference_model(variant="selective" if args.selective else "plain")
 
-    # ---- state_dict layout (keys + shapes), for the engine's name-compatible shells
-    layout = [(k, list(v.shape), "buffer" if k.endswith("div_term") else "param")
-              for k, v in model.state_dict().items()]
-    with open(os.path.join(HERE, "state_dict_layout.json"), "w") as f:
-        json.dump(layout, f, indent=0)
-    print("state_dict entries:", len(layout), "params:", sum(p.numel() for p in model.parameters()))
+    if not args.selective:
+        # ---- state_dict layout (keys + shapes), for the engine's name-compatible shells
+        layout = [(k, list(v.shape), "buffer" if k.endswith("div_term") else "param")
+                  for k, v in model.state_dict().items()]
+        with open(os.path.join(HERE, "state_dict_layout.json"), "w") as f:
+            json.dump(layout, f, indent=0)
+        print("state_dict entries:", len(layout), "params:", sum(p.numel() for p in model.parameters()))
 
-    pair = make_pair(args.n, config=args.config, pair_index=0)
+    pair = make_pair(args.n, config=args.config, pair_index=1 if args.selective else 0, normals="field" if args.selective else "random")
     rec = {}
 
     # ---- record native-op calls and calc_ppf in call order
@@ -245,7 +249,16 @@ def main():
     rec["out.matching_scores.every4"] = ms[::4].copy()
     rec["out.matching_scores.rowsum"] = ms.astype(np.float64).sum(axis=(1, 2)).astype(np.float64)
 
-    path = os.path.join(HERE, f"pair_n{args.n}.npz")
+    if args.selective:
+        # the per-call / per-stage taps are pinned by the plain golden already: keep the inputs, the end-to-end outputs, the coarse
+        # stage and the last backbone taps of this weight regime (peaked local attention, amplified embeddings)
+        keep = ("in.", "out.", "coarse.", "part.", "feat.dec1.1", "feat.geo.out", "feat.enc4.2", "feat.geo.layer5")
+        rec = {k: v for k, v in rec.items() if k.startswith(keep)}
+        for k in ("out.src_point_feats", "out.tgt_point_feats"):
+            rec[k + ".every4"] = rec.pop(k)[::4].copy()
+        for k in ("out.src_node_corr_knn_points", "out.tgt_node_corr_knn_points", "out.src_points", "out.tgt_points"):
+            rec.pop(k, None)   # gathers of the inputs by indices that are kept
+    path = os.path.join(HERE, f"pair_sel_n{args.n}.npz" if args.selective else f"pair_n{args.n}.npz")
     np.savez_compressed(path, **rec)
     print("wrote", path, "%.2f MB" % (os.path.getsize(path) / 1e6), "keys:", len(rec))
     for k in sorted(rec):
@@ -253,7 +266,8 @@ def main():
             print(" ", k, rec[k].shape, rec[k].dtype)
     print("knn nsample per call:", knn_meta)
     print("corr count:", rec["out.corr_scores"].shape)
-    stage_goldens(model)
+    if not args.selective:
+        stage_goldens(model)
 
 
 def stage_goldens(model):
@@ -372,9 +386,11 @@ def stage_goldens(model):
 
 
 def fdmatch_golden(n=1024):
-    """4DMatch settings (factor 2, AdaptiveSuperPointMatching, top-2 fine matching): end-to-end outputs only."""
-    model, cfg = build_reference_model("4DMatch")
-    pair = make_pair(n, config=4, pair_index=0)
+    """4DMatch settings (factor 2, AdaptiveSuperPointMatching, top-2 fine matching): end-to-end outputs only.  Selective weight
+    variant + field normals (round 3): with the plain weights every node pair passed the 0.75 threshold, so nothing downstream
+    of the coarse matching could fail a test."""
+    model, cfg = build_reference_model("4DMatch", "selective")
+    pair = make_pair(n, config=4, pair_index=0, normals="field")
     T = {k: torch.from_numpy(v) for k, v in pair.items()}
     with torch.no_grad():
         out = model.forward(T["src_points"], T["tgt_points"], T["src_feats"], T["tgt_feats"], T["src_normals"], T["tgt_normals"],

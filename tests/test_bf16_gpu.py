@@ -116,11 +116,9 @@ def test_geo_embed_bf16_against_float64():
 
 @pytest.fixture(scope="module")
 def fd8000():
-    from oracle import roitr_ref as R  # checker only
-    from roitr_amd.synthetic import make_pair
-    pair = make_pair(8000, config=4, pair_index=2)
-    ref = R.forward(R.closed_form_state(2), pair, cfg=dict(R.FDMATCH_CFG), threads=CORES)
-    model = build_model("4DMatch", operand_dtype="bf16")
+    from conftest import oracle_forward
+    pair, ref = oracle_forward("4DMatch", 8000, 4, 2)      # selective weights, field normals (shared with test_correspondences_gpu)
+    model = build_model("4DMatch", operand_dtype="bf16", weights="selective")
     with torch.no_grad():
         out = model.forward(**pair_to_device(pair))
     return out, ref

@@ -138,7 +138,7 @@ def test_oracle_4dmatch_forward_matches_reference_golden():
     GPU tests (tests/test_fullsize_gpu.py) rely on."""
     import os
     g = np.load(os.path.join(os.path.dirname(__file__), "golden", "pair_4dmatch_n1024.npz"))
-    out = R.forward(R.closed_form_state(2), inputs(g), cfg=dict(R.FDMATCH_CFG), threads=4)
+    out = R.forward(R.closed_form_state(2, "selective"), inputs(g), cfg=dict(R.FDMATCH_CFG), threads=4)
     for k in ("src_nodes", "tgt_nodes"):
         assert np.array_equal(out[k], g["out." + k])
     for k in ("src_node_feats", "tgt_node_feats"):
@@ -151,5 +151,41 @@ def test_oracle_4dmatch_forward_matches_reference_golden():
     tm = np.concatenate([out["tgt_node_corr_knn_masks"][::8], np.ones((ref.shape[0], 1), bool)], 1)
     sm = np.concatenate([out["src_node_corr_knn_masks"][::8], np.ones((ref.shape[0], 1), bool)], 1)
     valid = tm[:, :, None] & sm[:, None, :]
-    assert np.abs(ms - ref)[valid].max() < 1e-4
-    assert out["corr_scores"].shape[0] == g["out.corr_scores"].shape[0]
+    big = np.maximum(1.0, np.abs(ref))   # log-space entries reach -200 with the selective weights: relative there
+    assert (np.abs(ms - ref) / big)[valid].max() < 1e-4
+    _check_correspondences(out, g)
+
+
+def _check_correspondences(out, g, min_common=0.995):
+    """End-to-end VALUES against the reference: the (tgt point, src point) multiset and the scores of the common entries; the
+    inlier ratio (lib/loss.py:195-206) of both sets within 0.1 pp.  A handful of entries sit on a discrete boundary (the 0.05
+    confidence threshold, a top-k tie) where numpy and torch-CPU rounding may fall on different sides."""
+    from corr_util import compare_correspondences, inlier_ratio
+    ref = {k: g["out." + k] for k in ("tgt_corr_points", "src_corr_points", "corr_scores")}
+    assert ref["corr_scores"].shape[0] > 1000          # a non-trivial set: the golden is not the `0 == 0` of the plain weights
+    frac, err, common = compare_correspondences(out, ref)
+    assert frac >= min_common, (frac, out["corr_scores"].shape, ref["corr_scores"].shape)
+    assert err < 1e-4, err
+    ir_o, ir_r = inlier_ratio(out, g["in.rot"], g["in.trans"]), inlier_ratio(ref, g["in.rot"], g["in.trans"])
+    assert abs(ir_o - ir_r) <= 1e-3, (ir_o, ir_r)
+
+
+def test_oracle_selective_forward_matches_reference_golden():
+    """3DMatch settings with the 'selective' weight variant on a pair with field normals (tests/golden/pair_sel_n1024.npz,
+    captured from the reference): the golden whose forward ends in 5 814 correspondences -- compares what the tester saves."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "pair_sel_n1024.npz"))
+    taps = {}
+    out = R.forward(R.closed_form_state(1, "selective"), inputs(g), taps=taps, threads=4)
+    for k in ("src_nodes", "tgt_nodes"):
+        assert np.array_equal(out[k], g["out." + k])
+    for j, tag in enumerate(("src", "tgt")):
+        for stage in ("enc4.2", "dec1.1"):
+            assert np.abs(taps[f"{tag}.{stage}"] - g[f"feat.{stage}.{j}"]).max() < ATOL, (tag, stage)
+    for k in ("src_node_feats", "tgt_node_feats"):
+        assert np.abs(out[k] - g["out." + k]).max() < ATOL
+    for k in ("src_point_feats", "tgt_point_feats"):   # |values| up to 11 (fine_proj gain 4)
+        assert np.abs(out[k][::4] - g[f"out.{k}.every4"]).max() < 5e-5
+    assert np.array_equal(out["tgt_node_corr_indices"], g["out.tgt_node_corr_indices"])
+    assert np.array_equal(out["src_node_corr_indices"], g["out.src_node_corr_indices"])
+    _check_correspondences(out, g)
