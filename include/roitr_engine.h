@@ -138,6 +138,26 @@ typedef struct RoitrLocalAttn {
 int roitr_local_attention(const RoitrLocalAttn* a, roitr_stream_t stream);
 int roitr_build_pfold(int H, int heads, const float* wpe, const float* bpe, float* pfold, roitr_stream_t stream);
 
+/* The block form of the local PPF transformer in ONE launch (csrc/local_block.hip), for the 64- / 128-wide levels:
+ *   out = relu( bn2( out_proj( LN( linear(att) + in_proj(x) ) ) ) + x )     model/model.py:131-142, ppftransformer.py:227-253
+ * with att = local PPF attention of q = x Wq^T + bq over the neighbours' k | v rows.  The caller supplies kv (M, 2H) = the k | v
+ * projections of EVERY point (one plain GEMM) and the folded weights: wq / bq = proj_q o in_proj, wcat (H, 2H) = [W_linear | W_in],
+ * bcat = b_linear + b_in, wpe / bpe / wvpe / bvpe = the folded positional branch (see RoitrLocalAttn).  fp32, heads = 4,
+ * H in {64, 128}, K in {8, 16}; everything 16-byte aligned. */
+typedef struct RoitrLocalBlock {
+    int M, K, H;
+    const float* x; const float* kv; const int* group_idx; const float* ppf;
+    const void* node_order;   /* optional float4[M] (x,y,z,index-as-bits): visiting order */
+    const float* wq; const float* bq;
+    const float* wpe; const float* bpe; const float* wvpe; const float* bvpe;
+    const float* wcat; const float* bcat; const float* norm_w; const float* norm_b;
+    const float* wout; const float* bout; const float* bn2_w; const float* bn2_b;
+    float scale, eps;
+    float* out;
+} RoitrLocalBlock;
+int roitr_local_block(const RoitrLocalBlock* a, roitr_stream_t stream);
+int roitr_local_block_supported(int H, int K);
+
 /* ------------------------------------------------------------------ global geometric transformer */
 /* positional_encoding.py:110-137 get_embedding_indices for a batch of clouds.  pts (rows,3) = all nodes,
  * offset (b) cumulative, cloud_of_row (rows), eoff (b) = element offset of cloud c's (n_c, n_c) block.

@@ -384,6 +384,23 @@ int local_transformer(Engine& E, hipStream_t st, const LocalT& L, int N_in, cons
     // block transformer in fp32 with folded projections: f = in_proj(x) is never formed -- q|k|v come from x, and the residual
     // of the LayerNorm rides in the `linear` GEMM as the second K-half of [att | x]
     const bool catf = node_idx == nullptr && L.wcat != nullptr && L.wqkv_x != nullptr;
+    // the 64- / 128-wide block transformers (levels 1-2, where the separate launches are HBM-shaped): one fused launch behind
+    // a plain k | v GEMM over all points (csrc/local_block.hip)
+    if (catf && bn2_res == x && M == N_in && roitr_local_block_supported(H, K)) {
+        const int I = L.in_dim;
+        float* kv = A.get<float>((size_t)N_in * 2 * H);
+        if (A.fail) return ROITR_ERR_ARG;
+        CHK(gemm(st, N_in, 2 * H, I, x, I, L.wqkv_x + (size_t)(H + NQ) * I, I, L.bqkv_x + H + NQ, kv, 2 * H));
+        RoitrLocalBlock b;
+        memset(&b, 0, sizeof(b));
+        b.M = M; b.K = K; b.H = H; b.x = x; b.kv = kv; b.group_idx = group; b.ppf = ppf; b.node_order = order;
+        b.wq = L.wqkv_x; b.bq = L.bqkv_x; b.wpe = L.wpe; b.bpe = L.bpe; b.wvpe = L.wvpe; b.bvpe = L.bvpe;
+        b.wcat = L.wcat; b.bcat = L.bcat; b.norm_w = L.norm_w; b.norm_b = L.norm_b; b.wout = L.out_proj.w; b.bout = L.out_proj.b;
+        b.bn2_w = L.bn2_w; b.bn2_b = L.bn2_b; b.scale = 1.0f / sqrtf((float)(H / HEADS)); b.eps = 1e-5f; b.out = out;
+        CHK(roitr_local_block(&b, st));
+        A.off = mark;
+        return 0;
+    }
     float* f = catf ? nullptr : A.get<float>((size_t)(folded ? M : N_in) * H);
     if (catf) {}
     else if (folded) CHK(gemm(st, M, x, L.in_proj, f, false, node_idx));
@@ -846,7 +863,9 @@ extern "C" int roitr_engine_forward(void* h, const RoitrForwardIO* io, hipStream
             ppf_self[l] = A.get<float>((size_t)V.T[l] * K * 4);
             if (A.fail) break;
             if (grid[l]) {
-                CHK(roitr_knn_build_grid(NC, V.T[l], mcap, p[l], D.off[l], knn_ws[l], st));
+                // mean points per cell: the prefilter kNN kernel wants the sphere of one cell size to hold ~2 (k + 2) points
+                // (4.19 rho): 6 at level 1 (k = 8), 9 from level 2 on (k = 16)
+                CHK(roitr_knn_build_grid_ex(NC, V.T[l], mcap, p[l], D.off[l], knn_ws[l], l == 0 ? 6.0f : 9.0f, st));
                 order[l] = roitr_knn_sorted_points(NC, V.T[l], mcap, knn_ws[l]);
             }
             CHK(roitr_knnquery_ex(NC, V.T[l], V.T[l], K + 1, p[l], p[l], D.off[l], D.off[l], nullptr, nullptr, g_self[l], ppf_self[l], nrm[l],

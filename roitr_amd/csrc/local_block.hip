@@ -1,0 +1,339 @@
+// One launch for the block form of the local PPF transformer at the HBM-shaped hierarchy levels (64- and 128-wide):
+//
+//     out = relu( bn2( out_proj( LN( linear(att) + in_proj(x) ) ) ) + x ),   att = local PPF attention of q = proj_q(in_proj(x))
+//
+// Reference: RIPointTransformerBlock.forward (model/model.py:131-142) around LocalPPFTransformer.forward
+// (model/transformer/ppftransformer.py:227-253) with LocalRPEAttentionLayer (attention.py:152-200, 298-320).
+//
+// Why: at levels 1-2 (5.1 M / 1.3 M rows per 512-pair step, 64 / 128 channels) the separate launches -- [q|k|v] GEMM, attention,
+// `linear` + LayerNorm, `out_proj` + LayerNorm -- each stream the (M, H) activations through HBM: ~3.9 KB per row and transformer
+// at H = 64 for 49 kFLOP.  Here a workgroup keeps a tile of TM nodes on chip from x to out: the q projection, the attention
+// (gathering the neighbours' k | v rows, which a plain GEMM over ALL points produced before: they belong to other tiles), the
+// K-concatenated `linear` GEMM with its LayerNorm, and `out_proj` with bn2 + residual + ReLU.  HBM per row: x in, out out, the
+// gathered k | v rows, ppf and indices -- ~2.1 KB with the k | v GEMM included.
+//
+// Matrix work: v_mfma_f32_16x16x4_f32 (exact fp32 FMA chains, the fp32 vector rate).  A wave owns a 32 x 32 region = 2 x 2 tiles
+// of the TM x H output (TM = 64 at H = 64: 2 x 2 regions; TM = 32 at H = 128: 1 x 4 regions).  Activation images live row-major in
+// LDS (pitch H + 4 floats: the 16 rows a ds_read_b128 fragment load touches fall on 16 different 16-byte slots); weights stream
+// through a (H rows x 32 k) slab, row-major with pitch 36.  Lane (i = l & 15, g = l >> 4) reads ONE float4 = k 16c+4g .. +3 of its row
+// per operand and 16-k chunk and feeds component s to the s-th MFMA of the chunk: the MFMA sums k over g, the four steps over s --
+// every k once, A and B agreeing by construction.  A row's result depends on its own operands only, in a fixed order: a node's
+// output does not depend on the tile or batch it is in.
+//
+// Attention: LPN = H / 4 lanes per node (a lane owns 4 consecutive channels, a head = LPN / 4 lanes), 64 / LPN nodes per wave at a
+// time; q comes from the LDS tile, the result goes back into the same slots (each wave reads and writes only its own rows).
+// Formulas as csrc/local_attn.hip (folded positional branch).
+#include "common.h"
+#include "prof.h"
+#include "roitr_engine.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int WP = 36;   // weight-slab pitch (floats): 32 k + 4
+
+template <int CTRL> __device__ __forceinline__ float dpp_mov(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+// sum over the HL lanes of a head (HL = 4: a DPP quad; HL = 8: two quads = half a DPP row), result in every lane of the head
+template <int HL> __device__ __forceinline__ float head_allsum(float v)
+{
+    v += dpp_mov<0xB1>(v);    // quad_perm [1,0,3,2]
+    v += dpp_mov<0x4E>(v);    // quad_perm [2,3,0,1]
+    if (HL == 8) v += dpp_mov<0x141>(v);   // row_half_mirror: lane i <-> 7 - i of the 8-lane half row
+    return v;
+}
+
+struct Acc { f32x4 t[2][2]; };
+
+__device__ __forceinline__ void acc_zero(Acc& a)
+{
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) a.t[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+}
+
+// acc += A[r0 .. r0+31][0 .. Ka) @ W[c0 .. c0+31][k_w0 .. k_w0 + Ka)^T for this wave's region; all 256 threads stage the slabs.
+// A: LDS image (pitch AP); W: global (H rows, leading dimension ldw).
+template <int H, int AP>
+__device__ __forceinline__ void gemm_phase(Acc& acc, const float* __restrict__ A, int Ka, const float* __restrict__ W, int ldw, int k_w0,
+                                           float* __restrict__ WS, int r0, int c0, int tid)
+{
+    constexpr int NL = H / 32;                 // float4 loads per thread and slab (H rows x 8 float4)
+    const int lane = tid & 63, i = lane & 15, g = lane >> 4;
+    const int srow = tid >> 3, scol = (tid & 7) * 4;
+    float4 wreg[NL];
+#pragma unroll
+    for (int j = 0; j < NL; ++j) wreg[j] = *reinterpret_cast<const float4*>(W + (size_t)(srow + 32 * j) * ldw + k_w0 + scol);
+    for (int k0 = 0; k0 < Ka; k0 += 32) {
+        __syncthreads();                        // every wave is done with the previous slab
+#pragma unroll
+        for (int j = 0; j < NL; ++j) *reinterpret_cast<float4*>(WS + (srow + 32 * j) * WP + scol) = wreg[j];
+        __syncthreads();
+        if (k0 + 32 < Ka) {
+#pragma unroll
+            for (int j = 0; j < NL; ++j) wreg[j] = *reinterpret_cast<const float4*>(W + (size_t)(srow + 32 * j) * ldw + k_w0 + k0 + 32 + scol);
+        }
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const float4 a0 = *reinterpret_cast<const float4*>(A + (r0 + i) * AP + k0 + 16 * c + 4 * g);
+            const float4 a1 = *reinterpret_cast<const float4*>(A + (r0 + 16 + i) * AP + k0 + 16 * c + 4 * g);
+            const float4 b0 = *reinterpret_cast<const float4*>(WS + (c0 + i) * WP + 16 * c + 4 * g);
+            const float4 b1 = *reinterpret_cast<const float4*>(WS + (c0 + 16 + i) * WP + 16 * c + 4 * g);
+#define LB_STEP(S)                                                                                        \
+            acc.t[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.S, b0.S, acc.t[0][0], 0, 0, 0);          \
+            acc.t[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.S, b1.S, acc.t[0][1], 0, 0, 0);          \
+            acc.t[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.S, b0.S, acc.t[1][0], 0, 0, 0);          \
+            acc.t[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.S, b1.S, acc.t[1][1], 0, 0, 0)
+            LB_STEP(x); LB_STEP(y); LB_STEP(z); LB_STEP(w);
+#undef LB_STEP
+        }
+    }
+}
+
+// D[row][col] = acc + bias[col] into a row-major LDS tile (pitch DP); 16x16 C/D map: col = lane & 15, row = 4 (lane >> 4) + reg
+template <int DP>
+__device__ __forceinline__ void acc_store(const Acc& acc, const float* __restrict__ bias, float* __restrict__ D, int r0, int c0, int lane)
+{
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+        const int col = c0 + 16 * n + (lane & 15);
+        const float bv = bias[col];
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) D[(r0 + 16 * m + 4 * (lane >> 4) + r) * DP + col] = acc.t[m][n][r] + bv;
+    }
+}
+
+// DBG (tuning only, scripts/bench_local_block.py): 0 = the kernel; 1 = without the attention phase; 2 = attention only
+template <int H, int K, int TM, int DBG = 0>
+__global__ __launch_bounds__(256) void local_block_kernel(RoitrLocalBlock a)
+{
+    constexpr int AP = H + 4;                 // activation image pitch
+    constexpr int LPN = H / 4;                // lanes per node in the attention
+    constexpr int NPW = 64 / LPN;             // nodes per wave at a time
+    constexpr int HL = LPN / 4;               // lanes per head
+    constexpr int HV = H / 64;                // row elements per lane in the LayerNorm passes
+    __shared__ __attribute__((aligned(16))) float R1[TM * AP];   // x image, later the LayerNorm-ed y image
+    __shared__ __attribute__((aligned(16))) float R2[TM * AP];   // q rows -> attention rows -> row-major staging of the two epilogues
+    __shared__ __attribute__((aligned(16))) float WS[H * WP];
+    __shared__ int ids[TM];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ntiles = (a.M + TM - 1) / TM;
+    const int tile = xcd_block_id(ntiles);
+    if (tile >= ntiles) return;
+    const int s0 = tile * TM;
+    // ---- P0: node ids of the tile (cell order when given), x rows -> R1
+    if (tid < TM) {
+        const int sl = s0 + tid < a.M ? s0 + tid : s0;          // a dead slot recomputes the tile's first node and stores nothing
+        ids[tid] = a.node_order ? __float_as_int(reinterpret_cast<const float4*>(a.node_order)[sl].w) : sl;
+    }
+    __syncthreads();
+    {
+        constexpr int F4 = H / 4;             // float4 per row
+#pragma unroll
+        for (int e = tid; e < TM * F4; e += 256) {
+            const int r = e / F4, c4 = e % F4;
+            *reinterpret_cast<float4*>(R1 + r * AP + 4 * c4) = *reinterpret_cast<const float4*>(a.x + (size_t)ids[r] * H + 4 * c4);
+        }
+    }
+    const int r0 = TM == 64 ? (wave >> 1) * 32 : 0;
+    const int c0 = TM == 64 ? (wave & 1) * 32 : wave * 32;
+    Acc acc;
+    // ---- P1: q = x Wq^T + bq -> R2   (gemm_phase opens with a barrier: R1 is complete)
+    acc_zero(acc);
+    if (DBG != 2) gemm_phase<H, AP>(acc, R1, H, a.wq, H, 0, WS, r0, c0, tid);
+    acc_store<AP>(acc, a.bq, R2, r0, c0, lane);
+    __syncthreads();
+    // ---- P2: attention, in place on R2 (a wave touches only the rows of its own nodes)
+    if (DBG != 1) {
+        const int ns = lane / LPN, j = lane % LPN, jq = j % HL;
+        const int t4 = jq & 3;                                    // PPF component this lane carries
+        // per-lane constants of the folded positional branch
+        float4 wpe4[4]; float bpe4[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { wpe4[i] = reinterpret_cast<const float4*>(a.wpe)[4 * j + i]; bpe4[i] = a.bpe[4 * j + i]; }
+        for (int rd = 0; rd < TM / (4 * NPW); ++rd) {
+            const int row = (rd * 4 + wave) * NPW + ns;            // tile row of this lane's node
+            const int node = ids[row];
+            int gi[K];
+            {
+                const int4* gp = reinterpret_cast<const int4*>(a.group_idx + (size_t)node * K);
+#pragma unroll
+                for (int q4 = 0; q4 < K / 4; ++q4) { const int4 t = gp[q4]; gi[4 * q4] = t.x; gi[4 * q4 + 1] = t.y; gi[4 * q4 + 2] = t.z; gi[4 * q4 + 3] = t.w; }
+            }
+            float pv[K];
+            {
+                const float* pf = a.ppf + (size_t)node * K * 4 + t4;
+#pragma unroll
+                for (int kk = 0; kk < K; ++kk) pv[kk] = pf[kk * 4];
+            }
+            float4 kr[K];
+#pragma unroll
+            for (int kk = 0; kk < K; ++kk) kr[kk] = *reinterpret_cast<const float4*>(a.kv + (size_t)gi[kk] * (2 * H) + 4 * j);
+            float4 qv = *reinterpret_cast<const float4*>(R2 + row * AP + 4 * j);
+            // qp[h] = [Wpe_h^T q_h, q_h . bpe_h]
+            float ec, c4;
+            {
+                float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f, p4 = 0.f;
+                const float qs[4] = {qv.x, qv.y, qv.z, qv.w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    p0 = fmaf(wpe4[i].x, qs[i], p0); p1 = fmaf(wpe4[i].y, qs[i], p1); p2 = fmaf(wpe4[i].z, qs[i], p2);
+                    p3 = fmaf(wpe4[i].w, qs[i], p3); p4 = fmaf(bpe4[i], qs[i], p4);
+                }
+                p0 = head_allsum<HL>(p0); p1 = head_allsum<HL>(p1); p2 = head_allsum<HL>(p2); p3 = head_allsum<HL>(p3); p4 = head_allsum<HL>(p4);
+                // each PPF coefficient enters the head's score reduction exactly once: lanes jq = 0..3 carry t = jq, lane 0 the constant
+                ec = jq < 4 ? (jq == 0 ? p0 : (jq == 1 ? p1 : (jq == 2 ? p2 : p3))) * a.scale : 0.f;
+                c4 = jq == 0 ? p4 * a.scale : 0.f;
+            }
+            qv.x *= a.scale; qv.y *= a.scale; qv.z *= a.scale; qv.w *= a.scale;
+            float sc[K];
+            float mx = -INFINITY;
+#pragma unroll
+            for (int kk = 0; kk < K; ++kk) {
+                float d = fmaf(ec, pv[kk], c4);
+                d = fmaf(qv.x, kr[kk].x, d); d = fmaf(qv.y, kr[kk].y, d); d = fmaf(qv.z, kr[kk].z, d); d = fmaf(qv.w, kr[kk].w, d);
+                d = head_allsum<HL>(d);
+                sc[kk] = d;
+                mx = fmaxf(mx, d);
+            }
+            // value rows: requested after the scores (the key registers are dead), softmax overlaps their flight
+            float4 vr[K];
+#pragma unroll
+            for (int kk = 0; kk < K; ++kk) vr[kk] = *reinterpret_cast<const float4*>(a.kv + (size_t)gi[kk] * (2 * H) + H + 4 * j);
+            float sum = 0.f;
+#pragma unroll
+            for (int kk = 0; kk < K; ++kk) { sc[kk] = expf(sc[kk] - mx); sum += sc[kk]; }   // accurate exp: the reference softmax is libm-exact
+            float pb = 0.f;
+            float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int kk = 0; kk < K; ++kk) {
+                const float p = sc[kk] / sum;
+                pb = fmaf(p, pv[kk], pb);                          // pbar[h][t4]: every quad of the head holds its own copy
+                o.x = fmaf(p, vr[kk].x, o.x); o.y = fmaf(p, vr[kk].y, o.y); o.z = fmaf(p, vr[kk].z, o.z); o.w = fmaf(p, vr[kk].w, o.w);
+            }
+            const float b0 = dpp_mov<0x00>(pb), b1 = dpp_mov<0x55>(pb), b2 = dpp_mov<0xAA>(pb), b3 = dpp_mov<0xFF>(pb);   // quad broadcasts
+            const float4 bias = *reinterpret_cast<const float4*>(a.bvpe + 4 * j);
+            const float4 w0 = reinterpret_cast<const float4*>(a.wvpe)[4 * j], w1 = reinterpret_cast<const float4*>(a.wvpe)[4 * j + 1];
+            const float4 w2 = reinterpret_cast<const float4*>(a.wvpe)[4 * j + 2], w3 = reinterpret_cast<const float4*>(a.wvpe)[4 * j + 3];
+            o.x += w0.x * b0 + w0.y * b1 + w0.z * b2 + w0.w * b3 + bias.x;
+            o.y += w1.x * b0 + w1.y * b1 + w1.z * b2 + w1.w * b3 + bias.y;
+            o.z += w2.x * b0 + w2.y * b1 + w2.z * b2 + w2.w * b3 + bias.z;
+            o.w += w3.x * b0 + w3.y * b1 + w3.z * b2 + w3.w * b3 + bias.w;
+            *reinterpret_cast<float4*>(R2 + row * AP + 4 * j) = o;
+        }
+    }
+    // ---- P3: y = LN([att | x] Wcat^T + bcat)   (the opening barrier of gemm_phase publishes the attention rows)
+    acc_zero(acc);
+    if (DBG != 2) {
+    gemm_phase<H, AP>(acc, R2, H, a.wcat, 2 * H, 0, WS, r0, c0, tid);
+    gemm_phase<H, AP>(acc, R1, H, a.wcat, 2 * H, H, WS, r0, c0, tid);
+    }
+    __syncthreads();                                              // every wave is done reading R1 / R2
+    acc_store<AP>(acc, a.bcat, R2, r0, c0, lane);
+    __syncthreads();
+    {
+        float gam[HV], bet[HV];
+#pragma unroll
+        for (int i = 0; i < HV; ++i) { gam[i] = a.norm_w[lane + 64 * i]; bet[i] = a.norm_b[lane + 64 * i]; }
+        for (int rl = wave; rl < TM; rl += 4) {
+            float t[HV];
+            float s_ = 0.f;
+#pragma unroll
+            for (int i = 0; i < HV; ++i) { t[i] = R2[rl * AP + lane + 64 * i]; s_ += t[i]; }
+            const float mean = wave_sum(s_) / (float)H;
+            float q_ = 0.f;
+#pragma unroll
+            for (int i = 0; i < HV; ++i) { const float d = t[i] - mean; q_ += d * d; }
+            const float rstd = 1.0f / sqrtf(wave_sum(q_) / (float)H + a.eps);
+#pragma unroll
+            for (int i = 0; i < HV; ++i) R1[rl * AP + lane + 64 * i] = (t[i] - mean) * rstd * gam[i] + bet[i];
+        }
+    }
+    // ---- P4: out = relu(LN_bn2(y Wout^T + bout) + x)
+    acc_zero(acc);
+    if (DBG != 2) gemm_phase<H, AP>(acc, R1, H, a.wout, H, 0, WS, r0, c0, tid);
+    __syncthreads();                                              // R2's LayerNorm reads are long done; this one orders the MFMA reads of WS / R1
+    acc_store<AP>(acc, a.bout, R2, r0, c0, lane);
+    __syncthreads();
+    {
+        float gam[HV], bet[HV];
+#pragma unroll
+        for (int i = 0; i < HV; ++i) { gam[i] = a.bn2_w[lane + 64 * i]; bet[i] = a.bn2_b[lane + 64 * i]; }
+        for (int rl = wave; rl < TM; rl += 4) {
+            if (s0 + rl >= a.M) break;                            // wave-uniform; rows are in slot order
+            const size_t node = (size_t)ids[rl];
+            float t[HV];
+            float s_ = 0.f;
+#pragma unroll
+            for (int i = 0; i < HV; ++i) { t[i] = R2[rl * AP + lane + 64 * i]; s_ += t[i]; }
+            const float mean = wave_sum(s_) / (float)H;
+            float q_ = 0.f;
+#pragma unroll
+            for (int i = 0; i < HV; ++i) { const float d = t[i] - mean; q_ += d * d; }
+            const float rstd = 1.0f / sqrtf(wave_sum(q_) / (float)H + a.eps);
+#pragma unroll
+            for (int i = 0; i < HV; ++i) {
+                const float y = (t[i] - mean) * rstd * gam[i] + bet[i] + a.x[node * H + lane + 64 * i];
+                a.out[node * H + lane + 64 * i] = fmaxf(y, 0.f);
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int roitr_local_block_supported(int H, int K)
+{
+    return ((H == 64 && K == 8) || (H == 64 && K == 16) || (H == 128 && K == 16) || (H == 128 && K == 8)) ? 1 : 0;
+}
+
+// tuning hook of scripts/bench_local_block.py (not part of include/*.h): the kernel with a phase left out
+extern "C" int roitr_local_block_dbg(const RoitrLocalBlock* a, int variant, hipStream_t stream)
+{
+    if (a->M <= 0 || !roitr_local_block_supported(a->H, a->K)) return ROITR_ERR_UNSUPPORTED;
+    const int grid = xcd_grid(div_up(a->M, a->H == 64 ? 64 : 32));
+#define LB_DBG(HH, KK, TT)                                                                     \
+    do {                                                                                       \
+        if (variant == 1) local_block_kernel<HH, KK, TT, 1><<<grid, 256, 0, stream>>>(*a);     \
+        else if (variant == 2) local_block_kernel<HH, KK, TT, 2><<<grid, 256, 0, stream>>>(*a); \
+        else local_block_kernel<HH, KK, TT, 0><<<grid, 256, 0, stream>>>(*a);                  \
+    } while (0)
+    if (a->H == 64 && a->K == 8) LB_DBG(64, 8, 64);
+    else if (a->H == 128 && a->K == 16) LB_DBG(128, 16, 32);
+    else return ROITR_ERR_UNSUPPORTED;
+#undef LB_DBG
+    ROITR_LAUNCH_CHECK();
+    return ROITR_OK;
+}
+
+extern "C" int roitr_local_block(const RoitrLocalBlock* a, hipStream_t stream)
+{
+    if (a->M <= 0) return ROITR_OK;
+    if (!roitr_local_block_supported(a->H, a->K)) return ROITR_ERR_UNSUPPORTED;
+    if ((((uintptr_t)a->x | (uintptr_t)a->kv | (uintptr_t)a->group_idx | (uintptr_t)a->ppf | (uintptr_t)a->out | (uintptr_t)a->wq | (uintptr_t)a->wcat |
+          (uintptr_t)a->wout | (uintptr_t)a->wpe | (uintptr_t)a->wvpe | (uintptr_t)a->bvpe) & 15) != 0) {
+        roitr_set_error("roitr_local_block: operands must be 16-byte aligned", __FILE__, __LINE__);
+        return ROITR_ERR_ARG;
+    }
+    // algorithmic bytes: x in, out out, K gathered k | v rows, ppf + indices per node; FLOPs of the three on-chip GEMMs ride in aux
+    const double H = a->H, K = a->K;
+    roitr_prof_begin2(ROITR_PROF_LOCAL_BLOCK, (double)a->M * (2.0 * H * 4 + K * (2.0 * H * 4 + 20.0)), 2.0 * a->M * H * H * 4.0, stream);
+    if (a->H == 64) {
+        const int grid = xcd_grid(div_up(a->M, 64));
+        if (a->K == 8) local_block_kernel<64, 8, 64><<<grid, 256, 0, stream>>>(*a);
+        else local_block_kernel<64, 16, 64><<<grid, 256, 0, stream>>>(*a);
+    } else {
+        const int grid = xcd_grid(div_up(a->M, 32));
+        if (a->K == 8) local_block_kernel<128, 8, 32><<<grid, 256, 0, stream>>>(*a);
+        else local_block_kernel<128, 16, 32><<<grid, 256, 0, stream>>>(*a);
+    }
+    roitr_prof_end(ROITR_PROF_LOCAL_BLOCK, stream);
+    ROITR_LAUNCH_CHECK();
+    return ROITR_OK;
+}

@@ -406,6 +406,7 @@ __global__ void patch_gather_kernel(RoitrPatch a)
 // Masked rows/cols carry mu = 0 / K' = 0 exactly (the reference's -1e6 entries underflow to 0 in its logsumexp too).
 // The loop stops early only when b reproduced itself bit for bit (then every later iterate is identical).
 constexpr int OTN = 65;
+constexpr float OT_FAST_SPREAD = 30.f;   // widest score range of a row (dustbin included) the exponential form takes
 // ACC += KV * (B of lane (row, (col - N) & 15)): the DPP row rotate rides as a source modifier of the FMA (hipcc emits a
 // separate v_mov_b32_dpp per term from the builtin, which doubles the VALU work of the loop).  B is always written
 // several instructions before its first use here (the three ds_bpermute sit in between), which covers the
@@ -456,11 +457,23 @@ __global__ __launch_bounds__(64) void ot_kernel(RoitrOT a, unsigned long long* s
     // row view: lane = row l.  m_l = row max over the 65 entries (masked entries are -1e6, the dustbin is alpha)
     float KR[64], KC[64];
     float m = rml ? alpha : -1e6f;
+    float lo = alpha;
 #pragma unroll
     for (int j = 0; j < 64; ++j) {
-        const float v = (rml && ((cbits >> j) & 1)) ? T[lane][j] : -1e6f;
+        const bool ok = rml && ((cbits >> j) & 1);
+        const float v = ok ? T[lane][j] : -1e6f;
         KR[j] = v;
         m = fmaxf(m, v);
+        lo = ok ? fminf(lo, v) : lo;
+    }
+    // The exponential form keeps e^{v_j}, e^{u_i + m_i} and exp(S_ij - m_i) in fp32: it is exact-equivalent to the reference's
+    // log-domain iteration only while those stay inside the fp32 range, i.e. while the scores of a row (dustbin score alpha
+    // included) span a few tens -- what a network trained WITH this layer produces (alpha is learned against the scores).
+    // Scores hundreds above alpha (every row wants the dustbin column to carry e^{200}) are left to ot_log_kernel: the corner
+    // out[64][64] = NaN marks the patch (also set when the iteration ends non-finite after all).
+    if (__ballot(rml && m - lo > OT_FAST_SPREAD) != 0) {
+        if (lane == 0) out[64 * OTN + 64] = __int_as_float(0x7fc00000);
+        return;
     }
 #pragma unroll
     for (int j = 0; j < 64; ++j) {
@@ -501,6 +514,14 @@ __global__ __launch_bounds__(64) void ot_kernel(RoitrOT a, unsigned long long* s
         if (same) { if (stats && lane == 0) atomicAdd(stats + 1, (unsigned long long)(a.num_iter - 1 - it)); break; }
     }
     if (stats && lane == 0) atomicAdd(stats, 1ull);
+    {   // a patch whose duals left the fp32 range after all goes to the log-domain kernel
+        const bool bad = (rml && !(al > 0.f && al < INFINITY)) || (cml && !(bl > 0.f && bl < INFINITY)) || !(a64 > 0.f && a64 < INFINITY) ||
+                         !(b64 > 0.f && b64 < INFINITY);
+        if (__ballot(bad) != 0) {
+            if (lane == 0) out[64 * OTN + 64] = __int_as_float(0x7fc00000);
+            return;
+        }
+    }
     // outputs = S + u + v - norm  with u_i = log(a~_i) - m_i, v_j = log(b_j)  (modules.py:27,66-67)
     __syncthreads();
     const float ul = rml ? logf(al) - m : 0.f, vl = cml ? logf(bl) : 0.f;
@@ -514,6 +535,110 @@ __global__ __launch_bounds__(64) void ot_kernel(RoitrOT a, unsigned long long* s
     }
     out[64 * OTN + lane] = (cml ? alpha : -1e6f) + u64 + vl - norm;
     out[lane * OTN + 64] = (rml ? alpha : -1e6f) + ul + v64 - norm;
+    if (lane == 0) out[64 * OTN + 64] = alpha + u64 + v64 - norm;
+}
+
+// The reference's iteration verbatim, in the log domain (modules.py:21-27): u = log_mu - logsumexp_j(S + v), v = log_nu -
+// logsumexp_i(S + u), masked entries and masked log_mu / log_nu at -1e6 like the reference, logsumexp = max + log(sum exp(. - max))
+// in fp32.  Serves the patches ot_kernel declined (NaN in the corner of their output): any score range, ~20x the cost of the
+// exponential form (130 exp per lane and iteration).  Same wave-per-patch layout and the same rotated register order, so the
+// vector operand reaches the adds through DPP row rotations + three ds_bpermute row-block shifts.
+#define OTL_ROT(X, N_) __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(X), 0x120 + (N_), 0xf, 0xf, false))
+#define OTL_LOAD16(XA, SARR, VB, T_)                                                                                         \
+    XA[(T_) * 16] = SARR[(T_) * 16] + VB;                                                                                     \
+    XA[(T_) * 16 + 1] = SARR[(T_) * 16 + 1] + OTL_ROT(VB, 1);   XA[(T_) * 16 + 2] = SARR[(T_) * 16 + 2] + OTL_ROT(VB, 2);     \
+    XA[(T_) * 16 + 3] = SARR[(T_) * 16 + 3] + OTL_ROT(VB, 3);   XA[(T_) * 16 + 4] = SARR[(T_) * 16 + 4] + OTL_ROT(VB, 4);     \
+    XA[(T_) * 16 + 5] = SARR[(T_) * 16 + 5] + OTL_ROT(VB, 5);   XA[(T_) * 16 + 6] = SARR[(T_) * 16 + 6] + OTL_ROT(VB, 6);     \
+    XA[(T_) * 16 + 7] = SARR[(T_) * 16 + 7] + OTL_ROT(VB, 7);   XA[(T_) * 16 + 8] = SARR[(T_) * 16 + 8] + OTL_ROT(VB, 8);     \
+    XA[(T_) * 16 + 9] = SARR[(T_) * 16 + 9] + OTL_ROT(VB, 9);   XA[(T_) * 16 + 10] = SARR[(T_) * 16 + 10] + OTL_ROT(VB, 10); \
+    XA[(T_) * 16 + 11] = SARR[(T_) * 16 + 11] + OTL_ROT(VB, 11); XA[(T_) * 16 + 12] = SARR[(T_) * 16 + 12] + OTL_ROT(VB, 12); \
+    XA[(T_) * 16 + 13] = SARR[(T_) * 16 + 13] + OTL_ROT(VB, 13); XA[(T_) * 16 + 14] = SARR[(T_) * 16 + 14] + OTL_ROT(VB, 14); \
+    XA[(T_) * 16 + 15] = SARR[(T_) * 16 + 15] + OTL_ROT(VB, 15)
+// logsumexp over the 64 lane-distributed entries x (lane j holds element j) added to this lane's 64 scores SARR (rotated
+// order), plus one extra term `extra`
+__device__ __forceinline__ float ot_lse65(const float (&SARR)[64], float x, float extra, int lane)
+{
+    const float x1 = __int_as_float(__builtin_amdgcn_ds_bpermute(((lane + 16) & 63) << 2, __float_as_int(x)));
+    const float x2 = __int_as_float(__builtin_amdgcn_ds_bpermute(((lane + 32) & 63) << 2, __float_as_int(x)));
+    const float x3 = __int_as_float(__builtin_amdgcn_ds_bpermute(((lane + 48) & 63) << 2, __float_as_int(x)));
+    float X[64];
+    OTL_LOAD16(X, SARR, x, 0);
+    OTL_LOAD16(X, SARR, x1, 1);
+    OTL_LOAD16(X, SARR, x2, 2);
+    OTL_LOAD16(X, SARR, x3, 3);
+    float mx = extra;
+#pragma unroll
+    for (int i = 0; i < 64; ++i) mx = fmaxf(mx, X[i]);
+    float s0 = __expf(extra - mx), s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 64; i += 4) {
+        s0 += __expf(X[i] - mx); s1 += __expf(X[i + 1] - mx); s2 += __expf(X[i + 2] - mx); s3 += __expf(X[i + 3] - mx);
+    }
+    return mx + __logf((s0 + s1) + (s2 + s3));
+}
+// logsumexp of one value per lane (64 lanes) and one extra term
+__device__ __forceinline__ float ot_lse_wave(float x, float extra)
+{
+    const float mx = fmaxf(wave_max(x), extra);
+    return mx + __logf(wave_sum(__expf(x - mx)) + __expf(extra - mx));
+}
+
+__global__ __launch_bounds__(64) void ot_log_kernel(RoitrOT a)
+{
+    __shared__ float T[64][65];
+    const int patch = blockIdx.x;
+    const int pair = patch / a.num_corr, p = patch % a.num_corr;
+    const int lane = threadIdx.x;
+    if (p >= a.n_corr[pair]) return;
+    float* out = a.out + (size_t)patch * OTN * OTN;
+    {
+        const float corner = out[64 * OTN + 64];
+        if (corner == corner) return;   // ot_kernel served this patch
+    }
+    const float alpha = *a.alpha;
+    const float NINF = -1e6f;
+    const float* sc = a.scores + (size_t)patch * 64 * 64;
+    const bool rml = a.row_masks[(size_t)patch * 64 + lane] != 0, cml = a.col_masks[(size_t)patch * 64 + lane] != 0;
+    const unsigned long long rbits = __ballot(rml), cbits = __ballot(cml);
+    const int nvr = __popcll(rbits), nvc = __popcll(cbits);
+    const float norm = -logf((float)nvr + (float)nvc);
+#pragma unroll 8
+    for (int i = 0; i < 64; ++i) T[i][lane] = (cml && ((rbits >> i) & 1)) ? sc[i * 64 + lane] : NINF;   // padded_scores (modules.py:46-50)
+    __syncthreads();
+    float SR[64], SC[64];
+    {
+        const int R = lane >> 4, c = lane & 15;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int n = 0; n < 16; ++n) {
+                const int e = ((R + t) & 3) * 16 + ((c - n) & 15);
+                SR[t * 16 + n] = T[lane][e];
+                SC[t * 16 + n] = T[e][lane];
+            }
+    }
+    const float srd = rml ? alpha : NINF;    // S[l][64]
+    const float sdr = cml ? alpha : NINF;    // S[64][l]
+    const float lmu = rml ? norm : NINF, lnu = cml ? norm : NINF;
+    const float lmu64 = logf((float)nvc) + norm, lnu64 = logf((float)nvr) + norm;
+    float ul = 0.f, u64 = 0.f, vl = 0.f, v64 = 0.f;
+    for (int it = 0; it < a.num_iter; ++it) {
+        ul = lmu - ot_lse65(SR, vl, srd + v64, lane);
+        u64 = lmu64 - ot_lse_wave(sdr + vl, alpha + v64);
+        const float vn = lnu - ot_lse65(SC, ul, sdr + u64, lane);
+        v64 = lnu64 - ot_lse_wave(srd + ul, alpha + u64);
+        vl = vn;
+    }
+    __syncthreads();
+    T[0][lane] = ul;   // row 0 of the tile is free now: u by row index
+    __syncthreads();
+#pragma unroll 8
+    for (int i = 0; i < 64; ++i) {
+        const float sv = (cml && ((rbits >> i) & 1)) ? sc[i * 64 + lane] : NINF;
+        out[i * OTN + lane] = sv + T[0][i] + vl - norm;
+    }
+    out[64 * OTN + lane] = sdr + u64 + vl - norm;
+    out[lane * OTN + 64] = srd + ul + v64 - norm;
     if (lane == 0) out[64 * OTN + 64] = alpha + u64 + v64 - norm;
 }
 
@@ -754,6 +879,7 @@ extern "C" int roitr_optimal_transport(const RoitrOT* a, hipStream_t stream)
     };
     static Stats stats;
     ot_kernel<<<a->pairs * a->num_corr, 64, 0, stream>>>(*a, stats.d);
+    ot_log_kernel<<<a->pairs * a->num_corr, 64, 0, stream>>>(*a);   // the patches the exponential form declined; the others leave at once
     roitr_prof_end(ROITR_PROF_OT, stream);
     ROITR_LAUNCH_CHECK();
     return ROITR_OK;

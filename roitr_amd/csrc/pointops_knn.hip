@@ -981,6 +981,167 @@ __global__ __launch_bounds__(1024) void sort_queries_kernel(const float* __restr
     for (int k = start + tid; k < end; k += 1024) qorder[start + atomicAdd(&cnt[cell_of(k)], 1)] = k;
 }
 
+// ---------------------------------------------------------------- lane-per-query kernels: result rows of one lane
+template <int L>
+__device__ __forceinline__ void lane_emit(const KnnOut& o, int q, int nsample, const float (&d)[L], const int (&id)[L], bool tie,
+                                          const float* __restrict__ xyz, float qx, float qy, float qz)
+{
+    if (tie) {
+        const int slot = atomicAdd(o.tie_count, 1);
+        o.tie_list[slot] = q;
+        return;
+    }
+#pragma unroll
+    for (int j = 0; j < L; ++j) {
+        if (j < nsample) {
+            if (o.idx) o.idx[(size_t)q * nsample + j] = id[j];
+            if (o.dist2) o.dist2[(size_t)q * nsample + j] = d[j];
+            if (j >= 1 && o.group_idx) o.group_idx[(size_t)q * (nsample - 1) + j - 1] = id[j];
+        }
+    }
+    if (o.ppf) {  // neighbour indices are read back from the row this lane just wrote
+        const float* qn = o.query_normals + (size_t)q * 3;
+        const float nx = qn[0], ny = qn[1], nz = qn[2];
+        for (int j = 0; j < nsample - 1; ++j) {
+            const int gi = o.group_idx[(size_t)q * (nsample - 1) + j];
+            const float* pp = xyz + (size_t)gi * 3;
+            const float* pn = o.ref_normals + (size_t)gi * 3;
+            reinterpret_cast<float4*>(o.ppf)[(size_t)q * (nsample - 1) + j] =
+                ppf4(qx, qy, qz, nx, ny, nz, pp[0], pp[1], pp[2], pn[0], pn[1], pn[2]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------- small k, one LANE per query, distance prefilter (round 3)
+// The ring-expanding lane kernel below spends its time in the sorted-insertion chain: L compare / select pairs per list slot, and
+// the whole wave runs it whenever ANY lane accepts a candidate -- with 64 lists filling at once that is every candidate of the
+// 27-cell neighbourhood (17 k / 37 k VALU instructions per wave at L = 10 / 18, SQ pass of round 2).  Here the scan over the
+// 3 x 3 x 3 box only FILTERS: a candidate survives if its distance is below tau^2, tau = min(guarantee radius of the box, the
+// radius expected to hold ~2 (nsample + 1) points at the box's own density), and its position in the sorted array is appended
+// to the lane's column of an LDS table ([slot][thread]: conflict-free).  Everything within the guarantee radius lies inside
+// the box, so with at least nsample + 1 survivors the nsample + 1 nearest points of the cloud are among them: the insertion
+// chain then runs once per SURVIVOR (~2 (nsample + 1)) instead of once per candidate (13 (nsample + 1)), on lanes that all have
+// work.  Same distances, same list, same tie rule -> bit-identical results.  A lane with too few (sparse box, cloud border) or
+// too many survivors (CAP) hands its query to the ring-expanding kernel through the retry list.  Blocks take contiguous
+// ranges of the cell order per XCD (one L2 serves a neighbourhood: the round-2 launches fetched every cell 4.5 x).
+template <int L, int CAP>
+__global__ __launch_bounds__(256) void knn_prefilter_kernel(int m, int nsample, int b, const float* __restrict__ xyz,
+                                                            const float* __restrict__ new_xyz, const int* __restrict__ offset,
+                                                            const int* __restrict__ new_offset, const RoitrGrid* __restrict__ grids,
+                                                            const int* __restrict__ cell_start, const float4* __restrict__ sorted, KnnOut o,
+                                                            int self_sorted, const int* __restrict__ qorder, int* __restrict__ retry_count,
+                                                            int* __restrict__ retry_list)
+{
+    __shared__ int surv[CAP][256];
+    const int nblk = (m + 255) >> 8;
+    const int blk = xcd_block_id(nblk);
+    if (blk >= nblk) return;
+    const int tid = threadIdx.x;
+    const int t = blk * 256 + tid;
+    if (t >= m) return;
+    const int q = self_sorted ? __float_as_int(sorted[t].w) : (qorder ? qorder[t] : t);
+    const int seg = segment_of(q, new_offset, b);
+    const int start = seg == 0 ? 0 : offset[seg - 1];
+    const RoitrGrid g = grids[seg];
+    const int* cs = cell_start + (size_t)seg * (GRID_MAX_CELLS + 1);
+    const float qx = new_xyz[(size_t)q * 3], qy = new_xyz[(size_t)q * 3 + 1], qz = new_xyz[(size_t)q * 3 + 2];
+    int c0[3];
+    {
+        const float tq[3] = {(qx - g.ox) * g.inv_h, (qy - g.oy) * g.inv_h, (qz - g.oz) * g.inv_h};
+        const int dim[3] = {g.nx, g.ny, g.nz};
+#pragma unroll
+        for (int a = 0; a < 3; ++a) c0[a] = (int)fminf(fmaxf(tq[a], 0.f), (float)(dim[a] - 1));
+    }
+    const int x0 = max(c0[0] - 1, 0), x1 = min(c0[0] + 1, g.nx - 1);
+    const int y0 = max(c0[1] - 1, 0), y1 = min(c0[1] + 1, g.ny - 1);
+    const int z0 = max(c0[2] - 1, 0), z1 = min(c0[2] + 1, g.nz - 1);
+    // guarantee radius: distance to the nearest face of the box with unseen cells behind it (the ring kernel's stop rule)
+    float dmin = INFINITY;
+    if (x0 > 0) dmin = fminf(dmin, qx - __fmaf_rn((float)x0, g.h, g.ox));
+    if (x1 < g.nx - 1) dmin = fminf(dmin, __fmaf_rn((float)(x1 + 1), g.h, g.ox) - qx);
+    if (y0 > 0) dmin = fminf(dmin, qy - __fmaf_rn((float)y0, g.h, g.oy));
+    if (y1 < g.ny - 1) dmin = fminf(dmin, __fmaf_rn((float)(y1 + 1), g.h, g.oy) - qy);
+    if (z0 > 0) dmin = fminf(dmin, qz - __fmaf_rn((float)z0, g.h, g.oz));
+    if (z1 < g.nz - 1) dmin = fminf(dmin, __fmaf_rn((float)(z1 + 1), g.h, g.oz) - qz);
+    const float dm = dmin - 2e-4f * g.h;
+    // points in the box (from the cell index alone) -> the radius expected to hold ~2 (nsample + 1) of them
+    int nbox = 0;
+    for (int cz = z0; cz <= z1; ++cz)
+        for (int cy = y0; cy <= y1; ++cy) {
+            const int rowbase = (cz * g.ny + cy) * g.nx;
+            nbox += cs[rowbase + x1 + 1] - cs[rowbase + x0];
+        }
+    const float vbox = (float)((x1 - x0 + 1) * (y1 - y0 + 1) * (z1 - z0 + 1)) * g.h * g.h * g.h;
+    const float want = fmaxf(2.0f * (float)(nsample + 1), (float)(nsample + 9));
+    const float r0 = cbrtf(want * vbox * 0.2387324f / (float)max(nbox, 1));   // 3 / (4 pi)
+    // near the faces of the cloud's bounding box part of the sphere is empty space: grow the radius by the spherical caps cut
+    // off (two fixed-point steps; overlapping caps at edges / corners are subtracted twice -> a larger radius, never a wrong one)
+    const float fd[6] = {qx - g.ox, g.ox + (float)g.nx * g.h - qx, qy - g.oy, g.oy + (float)g.ny * g.h - qy, qz - g.oz, g.oz + (float)g.nz * g.h - qz};
+    float r_est = r0;
+#pragma unroll
+    for (int itr = 0; itr < 2; ++itr) {
+        float inside = 1.0f;
+#pragma unroll
+        for (int f = 0; f < 6; ++f) {
+            const float hc = r_est - fmaxf(fd[f], 0.f);
+            if (hc > 0.f) inside -= hc * hc * (3.0f * r_est - hc) / (4.0f * r_est * r_est * r_est);
+        }
+        r_est = r0 * rcbrtf(fmaxf(inside, 0.125f));
+    }
+    const float tau = dm > 0.f ? fminf(dm, r_est) : 0.f;
+    const float tau2 = tau * tau;
+    int cnt = 0;
+    for (int cz = z0; cz <= z1; ++cz)
+        for (int cy = y0; cy <= y1; ++cy) {
+            const int rowbase = (cz * g.ny + cy) * g.nx;
+            const int s = cs[rowbase + x0], e = cs[rowbase + x1 + 1];
+            constexpr int NF = 8;
+            for (int p = s; p < e; p += NF) {
+                float4 c[NF];
+#pragma unroll
+                for (int u = 0; u < NF; ++u) c[u] = sorted[min(p + u, e - 1)];
+#pragma unroll
+                for (int u = 0; u < NF; ++u) {
+                    const float dd = sqdist3(qx, qy, qz, c[u].x, c[u].y, c[u].z);
+                    if (p + u < e && dd < tau2) {
+                        if (cnt < CAP) surv[cnt][tid] = p + u;
+                        ++cnt;
+                    }
+                }
+            }
+        }
+    if (cnt < nsample + 1 || cnt > CAP) {
+        // too few: the (nsample + 1)-th neighbour may lie outside the radius; too many: the table column is full.
+        // A box that covers its whole cloud has dm = inf: every point is a survivor, `too few` then means the cloud itself has
+        // fewer than nsample + 1 points -- the ring kernel fills the tail like the reference (KNN_FILL, segment start).
+        const int slot = atomicAdd(retry_count, 1);
+        retry_list[slot] = q;
+        return;
+    }
+    float d[L]; int id[L];
+#pragma unroll
+    for (int j = 0; j < L; ++j) { d[j] = KNN_FILL; id[j] = start; }
+    for (int j = 0; j < cnt; ++j) {
+        const float4 c = sorted[surv[j][tid]];
+        const float dd = sqdist3(qx, qy, qz, c.x, c.y, c.z);
+        const int ci = __float_as_int(c.w);
+        if (dd < d[L - 1]) {
+#pragma unroll
+            for (int u = L - 1; u > 0; --u) {
+                const bool sh = d[u - 1] > dd, here = d[u] > dd;
+                d[u] = sh ? d[u - 1] : (here ? dd : d[u]);
+                id[u] = sh ? id[u - 1] : (here ? ci : id[u]);
+            }
+            const bool h0 = d[0] > dd;
+            d[0] = h0 ? dd : d[0]; id[0] = h0 ? ci : id[0];
+        }
+    }
+    bool tie = false;
+#pragma unroll
+    for (int j = 0; j + 1 < L; ++j) tie |= (j < nsample) && (d[j] == d[j + 1]) && (d[j] < KNN_FILL);
+    lane_emit<L>(o, q, nsample, d, id, tie, xyz, qx, qy, qz);
+}
+
 // ---------------------------------------------------------------- grid query, one LANE per query
 // For large query counts (tens of thousands and up: every level-1/2 call of a multi-pair batch) a wave per query
 // spends ~40x more instructions than the arithmetic needs.  Here every lane owns a query and its own sorted list in
@@ -993,11 +1154,13 @@ __global__ __launch_bounds__(256) void knn_lane_kernel(int m, int nsample, int b
                                                        const float* __restrict__ new_xyz, const int* __restrict__ offset,
                                                        const int* __restrict__ new_offset, const RoitrGrid* __restrict__ grids,
                                                        const int* __restrict__ cell_start, const float4* __restrict__ sorted, KnnOut o,
-                                                       int self_sorted, const int* __restrict__ qorder, float cap2)
+                                                       int self_sorted, const int* __restrict__ qorder, float cap2,
+                                                       const int* __restrict__ list, const int* __restrict__ list_count)
 {
-    const int t = blockIdx.x * 256 + threadIdx.x;
-    if (t >= m) return;
-    const int q = self_sorted ? __float_as_int(sorted[t].w) : (qorder ? qorder[t] : t);
+  // list mode (list != nullptr): the queries knn_prefilter_kernel could not decide, *list_count of them, grid-stride
+  const int total = list ? *list_count : m;
+  for (int t = blockIdx.x * 256 + threadIdx.x; t < total; t += gridDim.x * 256) {
+    const int q = list ? list[t] : (self_sorted ? __float_as_int(sorted[t].w) : (qorder ? qorder[t] : t));
     int lo = 0, hi = b - 1;
     while (lo < hi) { const int mid = (lo + hi) >> 1; if (q < new_offset[mid]) hi = mid; else lo = mid + 1; }
     const int seg = lo;
@@ -1079,30 +1242,8 @@ __global__ __launch_bounds__(256) void knn_lane_kernel(int m, int nsample, int b
     bool tie = false;
 #pragma unroll
     for (int j = 0; j + 1 < L; ++j) tie |= (j < nsample) && (d[j] == d[j + 1]) && (d[j] < KNN_FILL);
-    if (tie) {
-        const int slot = atomicAdd(o.tie_count, 1);
-        o.tie_list[slot] = q;
-        return;
-    }
-#pragma unroll
-    for (int j = 0; j < L; ++j) {
-        if (j < nsample) {
-            if (o.idx) o.idx[(size_t)q * nsample + j] = id[j];
-            if (o.dist2) o.dist2[(size_t)q * nsample + j] = d[j];
-            if (j >= 1 && o.group_idx) o.group_idx[(size_t)q * (nsample - 1) + j - 1] = id[j];
-        }
-    }
-    if (o.ppf) {  // neighbour indices are read back from the row this lane just wrote
-        const float* qn = o.query_normals + (size_t)q * 3;
-        const float nx = qn[0], ny = qn[1], nz = qn[2];
-        for (int j = 0; j < nsample - 1; ++j) {
-            const int gi = o.group_idx[(size_t)q * (nsample - 1) + j];
-            const float* pp = xyz + (size_t)gi * 3;
-            const float* pn = o.ref_normals + (size_t)gi * 3;
-            reinterpret_cast<float4*>(o.ppf)[(size_t)q * (nsample - 1) + j] =
-                ppf4(qx, qy, qz, nx, ny, nz, pp[0], pp[1], pp[2], pn[0], pn[1], pn[2]);
-        }
-    }
+    lane_emit<L>(o, q, nsample, d, id, tie, xyz, qx, qy, qz);
+  }
 }
 
 // ---------------------------------------------------------------- lane-per-query, small clouds (no grid)
@@ -1171,30 +1312,7 @@ __global__ __launch_bounds__(64) void knn_lane_brute_kernel(int m, int nsample, 
     bool tie = false;
 #pragma unroll
     for (int j = 0; j + 1 < L; ++j) tie |= (j < nsample) && (d[j] == d[j + 1]) && (d[j] < KNN_FILL);
-    if (tie) {
-        const int slot = atomicAdd(o.tie_count, 1);
-        o.tie_list[slot] = q;
-        return;
-    }
-#pragma unroll
-    for (int j = 0; j < L; ++j) {
-        if (j < nsample) {
-            if (o.idx) o.idx[(size_t)q * nsample + j] = id[j];
-            if (o.dist2) o.dist2[(size_t)q * nsample + j] = d[j];
-            if (j >= 1 && o.group_idx) o.group_idx[(size_t)q * (nsample - 1) + j - 1] = id[j];
-        }
-    }
-    if (o.ppf) {  // neighbour indices are read back from the row this lane just wrote
-        const float* qn = o.query_normals + (size_t)q * 3;
-        const float nx = qn[0], ny = qn[1], nz = qn[2];
-        for (int j = 0; j < nsample - 1; ++j) {
-            const int gi = o.group_idx[(size_t)q * (nsample - 1) + j];
-            const float* pp = xyz + (size_t)gi * 3;
-            const float* pn = o.ref_normals + (size_t)gi * 3;
-            reinterpret_cast<float4*>(o.ppf)[(size_t)q * (nsample - 1) + j] =
-                ppf4(qx, qy, qz, nx, ny, nz, pp[0], pp[1], pp[2], pn[0], pn[1], pn[2]);
-        }
-    }
+    lane_emit<L>(o, q, nsample, d, id, tie, xyz, qx, qy, qz);
 }
 
 // ---------------------------------------------------------------- exact replay of tied queries
@@ -1312,12 +1430,13 @@ extern "C" size_t roitr_knn_workspace_bytes(int b, int n, int m)
     ints = (ints + 3) & ~(size_t)3;
     ints += (size_t)n * 4;
     ints += (size_t)m;  // query order (lane kernel, non-self queries)
+    ints += (size_t)m;  // retry list (queries the prefilter kernel hands to the ring-expanding one)
     return ints * 4 + 64;
 }
 
 namespace {
 struct WsView {
-    int* tie_count; int* tie_list; RoitrGrid* grids; int* cell_start; float4* sorted; int* qorder;
+    int* tie_count; int* tie_list; RoitrGrid* grids; int* cell_start; float4* sorted; int* qorder; int* retry;
 };
 WsView carve(void* ws, int b, int n, int m)
 {
@@ -1332,6 +1451,7 @@ WsView carve(void* ws, int b, int n, int m)
     v.sorted = (float4*)(p + ints);
     ints += (size_t)n * 4;
     v.qorder = (b > 0 && n > 0) ? p + ints : nullptr;
+    v.retry = v.qorder ? v.qorder + m : nullptr;
     return v;
 }
 }  // namespace
@@ -1405,11 +1525,25 @@ int knnquery_impl(int b, int n, int m, int nsample, const float* xyz, const floa
     }
 #define LANE_CASE(LC)                                                                                                        \
     knn_lane_kernel<LC><<<div_up(m, 256), 256, 0, stream>>>(m, nsample, b, xyz, new_xyz, offset, new_offset, v.grids, v.cell_start, \
-                                                             v.sorted, o, self_sorted, qorder, cap2)
+                                                             v.sorted, o, self_sorted, qorder, cap2, nullptr, nullptr)
+    // prefilter kernel + the ring-expanding kernel in list mode for what it hands over (a fixed grid-stride launch: the count
+    // lives on the device)
+#define PREF_CASE(LC, CAPC)                                                                                                  \
+    do {                                                                                                                     \
+        int* retry_count = v.tie_count + 1;                                                                                  \
+        knn_prefilter_kernel<LC, CAPC><<<xcd_grid(div_up(m, 256)), 256, 0, stream>>>(m, nsample, b, xyz, new_xyz, offset, new_offset, v.grids, \
+                                                                                    v.cell_start, v.sorted, o, self_sorted, qorder, retry_count, v.retry); \
+        knn_lane_kernel<LC><<<min(div_up(m, 256), 1024), 256, 0, stream>>>(m, nsample, b, xyz, new_xyz, offset, new_offset, v.grids, v.cell_start, \
+                                                                           v.sorted, o, self_sorted, qorder, cap2, v.retry, retry_count);   \
+    } while (0)
     if (lane_ok && nsample + 1 <= 34) {   // from nsample + 1 = 35 the selection kernels take over
         const int need = nsample + 1;
-        if (need <= 2) LANE_CASE(2); else if (need <= 4) LANE_CASE(4); else if (need <= 10) LANE_CASE(10);
-        else if (need <= 18) LANE_CASE(18); else LANE_CASE(34);
+        const bool exact_k = cap2 == INFINITY && v.retry != nullptr;   // roitr_knn_within (cap2 < inf) stops on the radius: ring kernel
+        if (need <= 2) LANE_CASE(2);
+        else if (need <= 4) { if (exact_k) PREF_CASE(4, 24); else LANE_CASE(4); }
+        else if (need <= 10) { if (exact_k) PREF_CASE(10, 40); else LANE_CASE(10); }
+        else if (need <= 18) { if (exact_k) PREF_CASE(18, 52); else LANE_CASE(18); }
+        else LANE_CASE(34);
     } else if (use_grid && self_sorted && b > 0 && v.qorder && nsample - 1 <= 64) {
         // large k, self queries: workgroup per cell over the LDS-staged neighbourhood; what it cannot decide goes through the
         // retry list to the general selection kernel
@@ -1424,6 +1558,7 @@ int knnquery_impl(int b, int n, int m, int nsample, const float* xyz, const floa
         if (nsample + 1 <= 66) LANE_CASE(66); else LANE_CASE(101);
     } else
 #undef LANE_CASE
+#undef PREF_CASE
     if (!use_grid && nsample + 1 <= 34 && (!ppf || group_idx) && m >= lane_brute_min) {
 #define LB_CASE(LC) knn_lane_brute_kernel<LC><<<div_up(m, 64), 64, 0, stream>>>(m, nsample, b, xyz, new_xyz, offset, new_offset, o)
         const int need = nsample + 1;

@@ -124,6 +124,7 @@ void roitr_prof_begin2(int cls, double bytes, double aux, hipStream_t st)
         for (auto& o : g_open)
             if (o.cls >= ROITR_PROF_PH_GEOM && o.cls <= ROITR_PROF_PH_FORWARD) {
                 if (mfma) { o.bytes += r.bytes; o.aux += r.aux; }
+                else if (cls == ROITR_PROF_LOCAL_BLOCK) { o.bytes += r.aux; o.aux += r.bytes; }   // HBM bytes in `bytes`, FLOPs in `aux`
                 else o.aux += r.bytes;
             }
     (void)hipEventRecord(r.a, st);

@@ -21,7 +21,8 @@ enum {
     ROITR_PROF_MHA = 13,       // mha_kernel
     ROITR_PROF_GEO_EMBED = 14, // geo_embed_kernel (GEMM form): "bytes" carries FLOPs
     ROITR_PROF_GEO_TABLE = 15, // geo_table_kernel: HBM bytes
-    ROITR_PROF_GEO_ALGO = 16   // no time: the FLOPs the GEMM form of the embedding would have spent on the rows geo_table_kernel served
+    ROITR_PROF_GEO_ALGO = 16,  // no time: the FLOPs the GEMM form of the embedding would have spent on the rows geo_table_kernel served
+    ROITR_PROF_LOCAL_BLOCK = 17 // local_block_kernel: "bytes" = HBM bytes, aux = the FLOPs of its three on-chip GEMMs
 };
 
 void roitr_prof_begin(int cls, double bytes, hipStream_t st);

@@ -303,3 +303,41 @@ def geo_embed(d_idx, a_idx, div_term, w_d, b_d, w_a, b_a, split=False, bf16=Fals
         L.check(lib.roitr_geo_embed(ctypes.c_long(rows), C, k, L.ptr(d_idx), L.ptr(a_idx), L.ptr(div_term), L.ptr(w_d), L.ptr(b_d),
                                     L.ptr(w_a), L.ptr(b_a), L.ptr(out), L.stream_ptr()), "geo_embed")
     return out
+
+
+class _LocalBlock(ctypes.Structure):
+    _fields_ = [("M", ctypes.c_int), ("K", ctypes.c_int), ("H", ctypes.c_int),
+                ("x", ctypes.c_void_p), ("kv", ctypes.c_void_p), ("group_idx", ctypes.c_void_p), ("ppf", ctypes.c_void_p),
+                ("node_order", ctypes.c_void_p), ("wq", ctypes.c_void_p), ("bq", ctypes.c_void_p),
+                ("wpe", ctypes.c_void_p), ("bpe", ctypes.c_void_p), ("wvpe", ctypes.c_void_p), ("bvpe", ctypes.c_void_p),
+                ("wcat", ctypes.c_void_p), ("bcat", ctypes.c_void_p), ("norm_w", ctypes.c_void_p), ("norm_b", ctypes.c_void_p),
+                ("wout", ctypes.c_void_p), ("bout", ctypes.c_void_p), ("bn2_w", ctypes.c_void_p), ("bn2_b", ctypes.c_void_p),
+                ("scale", ctypes.c_float), ("eps", ctypes.c_float), ("out", ctypes.c_void_p)]
+
+
+def local_block(x, kv, group_idx, ppf, w, node_order=None, variant=None):
+    """The block form of the local PPF transformer in one launch (csrc/local_block.hip; model/model.py:131-142 around
+    ppftransformer.py:227-253).  x (M, H), kv (M, 2H) = k | v rows of every point, group_idx (M, K) int32, ppf (M, K, 4);
+    w: dict of the FOLDED weights (include/roitr_engine.h RoitrLocalBlock): wq (H,H) bq, wpe (H,4) bpe, wvpe (H,4) bvpe,
+    wcat (H,2H) bcat, norm_w norm_b, wout (H,H) bout, bn2_w bn2_b.  node_order: optional (M, 4) float32 whose last column
+    holds the node index bits (the grid's sorted-point array).  variant: tuning hook (1: no attention, 2: attention only)."""
+    M, H = int(x.shape[0]), int(x.shape[1])
+    K = int(group_idx.shape[1])
+    f = lambda t: t.contiguous().float()
+    x, kv, ppf = f(x), f(kv), f(ppf)
+    group_idx = _i32c(group_idx)
+    keep = {k: f(v) for k, v in w.items()}
+    out = torch.empty((M, H), dtype=torch.float32, device=x.device)
+    a = _LocalBlock()
+    a.M, a.K, a.H = M, K, H
+    a.x, a.kv, a.group_idx, a.ppf = L.ptr(x), L.ptr(kv), L.ptr(group_idx), L.ptr(ppf)
+    no = f(node_order) if node_order is not None else None
+    a.node_order = L.ptr(no)
+    for k in ("wq", "bq", "wpe", "bpe", "wvpe", "bvpe", "wcat", "bcat", "norm_w", "norm_b", "wout", "bout", "bn2_w", "bn2_b"):
+        setattr(a, k, L.ptr(keep[k]))
+    a.scale, a.eps, a.out = 1.0 / float(H // 4) ** 0.5, 1e-5, L.ptr(out)
+    if variant is None:
+        L.check(L.lib().roitr_local_block(ctypes.byref(a), L.stream_ptr()), "local_block")
+    else:
+        L.check(L.lib().roitr_local_block_dbg(ctypes.byref(a), int(variant), L.stream_ptr()), "local_block_dbg")
+    return out

@@ -270,7 +270,7 @@ class RIGA_v2(nn.Module):
     PROF_CLASSES = {"fps_kernel": 0, "knn_query_kernel": 1, "grid_build_kernel": 2, "knn_replay_kernel": 3, "phase.geometry": 4,
                     "phase.encoder": 5, "phase.global_transformer": 6, "phase.decoder": 7, "phase.matching": 8,
                     "phase.forward": 9, "ot_kernel": 10, "local_attn_kernel": 11, "gemm_kernel": 12, "mha_kernel": 13,
-                    "geo_embed_kernel": 14, "geo_table_kernel": 15, "geo_embed_reference_flops": 16}
+                    "geo_embed_kernel": 14, "geo_table_kernel": 15, "geo_embed_reference_flops": 16, "local_block_kernel": 17}
 
     @staticmethod
     def profile_reset(enable=True):

@@ -56,35 +56,34 @@ def gather_counts(value):
 
 
 class RecordBatch:
-    """The records of one engine batch before they are laid into the rank's block: `headers` (B, 4) int32 and the batch's
-    scores (n,) float32, pair after pair -- both on the device the scores came from."""
+    """The records of one engine batch before they are laid into the rank's block: `headers` (B, 4) int32 ON THE HOST (pair id,
+    true score count, 0, 0), `aux` an optional (B, 2) float tensor (device or host) for the two aux words, and the batch's scores
+    (n,) float32, pair after pair, on the device the engine wrote them to.  Nothing here waits for the device."""
 
-    def __init__(self, headers, scores):
-        self.headers, self.scores = headers, scores
+    def __init__(self, headers, scores, aux=None):
+        self.headers, self.scores, self.aux = headers, scores, aux
 
     def __len__(self):
         return int(self.headers.shape[0])
 
 
 def pack_records(pair_ids, starts, scores_flat, aux=None):
-    """Records of one engine batch.  No per-pair work: the engine already emits the scores of a batch pair after pair, so the
-    pool part is ONE contiguous slice of its `out_scores` (copied, so that the 100 MB output buffer is not kept alive), and the
-    header is built on the host from numbers finish_batch() holds there anyway.
+    """Records of one engine batch.  No per-pair work and no host <-> device traffic: the engine already emits the scores of a
+    batch pair after pair, so the pool part is ONE contiguous slice of its `out_scores` (copied on the stream, so that the 100 MB
+    output buffer is not kept alive), and the header is built on the host from numbers finish_batch() holds there anyway -- it
+    travels to the device with the block, at the end.  (A host-to-device copy here would queue behind the NEXT batch's forward,
+    which is already on the stream, and stall the host for its whole duration.)
 
     pair_ids: B global pair indices; starts: B+1 row offsets into `scores_flat` (the engine's fine_offsets + n_out);
-    aux: optional (B, 2) float tensor (device)."""
-    dev = scores_flat.device
+    aux: optional (B, 2) float tensor."""
     B = len(pair_ids)
     head = torch.zeros((B, HEADER), dtype=torch.int32)
     if B:
         st = torch.as_tensor(list(starts), dtype=torch.int64)
         head[:, 0] = torch.as_tensor(list(pair_ids), dtype=torch.int32)
         head[:, 1] = (st[1:] - st[:-1]).to(torch.int32)
-    head = head.to(dev)
-    if aux is not None and B:
-        head[:, 2:4] = aux.to(device=dev, dtype=torch.float32).contiguous().view(torch.int32)
     lo, hi = (int(starts[0]), int(starts[-1])) if B else (0, 0)
-    return RecordBatch(head, scores_flat[lo:hi].to(torch.float32).clone())
+    return RecordBatch(head, scores_flat[lo:hi].to(torch.float32).clone(), aux if B else None)
 
 
 def records_from_list(records):
@@ -96,14 +95,14 @@ def records_from_list(records):
         if len(rec) > 2:
             head[i, 2:4] = torch.tensor(list(rec[2]), dtype=torch.float32).view(torch.int32)
     scores = torch.cat([r[1].detach().to(device, torch.float32).reshape(-1) for r in records]) if records else torch.zeros(0)
-    return RecordBatch(head.to(device), scores)
+    return RecordBatch(head, scores)
 
 
 def assemble_block(batches, slots, scores_per_pair=DEFAULT_SCORES_PER_PAIR, device=None):
     """Lay the RecordBatches of a rank (in order) into its fixed-size block; unused slots get pair_id -1."""
     batches = list(batches)
     if device is None:
-        device = batches[0].headers.device if batches else "cpu"
+        device = batches[0].scores.device if batches else "cpu"
     n = sum(len(b) for b in batches)
     if n > slots:
         raise ValueError(f"{n} records for {slots} slots")
@@ -112,7 +111,12 @@ def assemble_block(batches, slots, scores_per_pair=DEFAULT_SCORES_PER_PAIR, devi
     heads = block[:slots * HEADER].view(slots, HEADER)
     heads[n:, 0] = -1
     if n:
-        heads[:n] = torch.cat([b.headers.to(device) for b in batches], 0)
+        heads[:n] = torch.cat([b.headers for b in batches], 0).to(device)
+        row = 0
+        for b in batches:
+            if b.aux is not None:
+                heads[row:row + len(b), 2:4] = b.aux.to(device=device, dtype=torch.float32).contiguous().view(torch.int32)
+            row += len(b)
         sc = torch.cat([b.scores.to(device) for b in batches])
         k = min(int(sc.numel()), pool)
         block[slots * HEADER:slots * HEADER + k] = sc[:k].contiguous().view(torch.int32)

@@ -47,37 +47,43 @@ def hashed_uniform(key, numel):
 # model/RIGA_v2.py:27) admits EVERY node pair and no fine-matching score clears 0.05.  The selective variant keeps the same
 # hash but (a) raises the gain of the geometry-dependent inputs -- the local PPF embeddings (x8), the two projections of the
 # geometric structure embedding (x4) -- and of the point-descriptor head `fine_proj` (x4: the patch scores are quadratic in
-# it), and (b) moves `coarse_proj.bias` by -W c, where c is a fixed per-width vector (configs/selective_centre.npz: the mean
-# global-transformer output on one synthetic calibration pair of the bench size, scaled so that a few percent of the node
-# pairs fall under the threshold there; written by tests/golden/calibrate_selective.py).  It is still a pure function of
+# it), and (b) moves `coarse_proj.bias` by -W c and `fine_proj.bias` by -W p, where c / p are fixed per-width vectors
+# (configs/selective_centre.npz: the mean global-transformer output resp. the mean input of fine_proj on one synthetic
+# calibration pair of the bench size, c scaled so that a few percent of the node pairs fall under the threshold there;
+# written by tests/golden/calibrate_selective.py) -- descriptors then vary around zero like a trained network's.  It is still a pure function of
 # (key, shape) plus that committed constant, so the reference model, the oracle and the engine agree on it bit for bit.
 SELECTIVE_GAIN = {".embedding.proj.weight": 8.0, ".embedding.proj_d.weight": 4.0, ".embedding.proj_a.weight": 4.0,
                   "fine_proj.weight": 4.0, "fine_proj.bias": 4.0}
 _CENTRE = None
 
 
-def selective_centre(width):
-    """The committed centring vector for descriptor width `width` (256: 3DMatch, 512: 4DMatch)."""
+def selective_centre(name):
+    """A committed centring vector: 'c256' / 'c512' (input of coarse_proj, 3DMatch / 4DMatch widths), 'p64' / 'p128' (input of
+    fine_proj)."""
     global _CENTRE
     if _CENTRE is None:
         import os
         path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "configs", "selective_centre.npz")
         with np.load(path) as z:
-            _CENTRE = {int(k[1:]): z[k].astype(np.float64) for k in z.files}
-    return _CENTRE[int(width)]
+            _CENTRE = {k: z[k].astype(np.float64) for k in z.files}
+    return np.asarray(_CENTRE[name], np.float64)
 
 
 def closed_form_param(key, shape, variant="plain"):
     """float32 array for the parameter called `key` with `shape`; variant: 'plain' | 'selective' (see above)."""
     if variant == "selective":
         base = closed_form_param(key, shape).astype(np.float64)
-        for suffix, gain in SELECTIVE_GAIN.items():
-            if key.endswith(suffix):
-                base = base * gain
         if key == "coarse_proj.bias":
             n = int(shape[0])
             w = closed_form_param("coarse_proj.weight", (n, n)).astype(np.float64)
-            base = base - w @ selective_centre(n)
+            base = base - w @ selective_centre(f"c{n}")
+        if key == "fine_proj.bias":
+            n = int(shape[0])
+            w = closed_form_param("fine_proj.weight", (n, n // 4)).astype(np.float64)
+            base = base - w @ selective_centre(f"p{n // 4}")
+        for suffix, gain in SELECTIVE_GAIN.items():
+            if key.endswith(suffix):
+                base = base * gain
         return base.astype(np.float32)
     if variant != "plain":
         raise ValueError(f"unknown weight variant {variant!r}")

@@ -8,7 +8,9 @@ the mean global-transformer output over the superpoints of both clouds.  3DMatch
 free).  4DMatch: lambda * mean with the largest lambda on a 0.01 grid that leaves at least 3 % of the calibration pair's node
 pairs under the 0.75 feature-distance threshold of AdaptiveSuperPointMatching (model/RIGA_v2.py:27) -- so the threshold branch
 of the adaptive matching is what the full-size tests and `bench.py --config 4` exercise, on a few hundred patches per pair
-instead of all 15 625.
+instead of all 15 625.  p64 / p128: the mean input row of `fine_proj` on the same pairs; the variant subtracts W p from the
+head's bias, so the patch scores lose their common offset (|c|^2 g^2 / 16 ~ 200 with the gains) and sit around the dustbin
+score alpha like a trained network's do -- the regime the optimal-transport kernel's fast path is built for.
 
 Usage: python tests/golden/calibrate_selective.py
 """
@@ -35,7 +37,7 @@ def node_distances(sd, g0, g1, c):
 
 
 def main():
-    Wt._CENTRE = {256: np.zeros(256), 512: np.zeros(512)}
+    Wt._CENTRE = {"c256": np.zeros(256), "c512": np.zeros(512), "p64": np.zeros(64), "p128": np.zeros(128)}
     cores = len(os.sched_getaffinity(0))
     out = {}
     for factor, n, cfg in ((1, 5000, None), (2, 8000, dict(R.FDMATCH_CFG))):
@@ -55,6 +57,8 @@ def main():
         print(f"factor {factor}: N = {n}, {g0.shape[0]} + {g1.shape[0]} nodes, lambda = {lam:.2f}, node pairs under 0.75: "
               f"{float((d <= 0.75).mean()):.4f}, distance min / mean {d.min():.3f} / {d.mean():.3f}")
         out[f"c{256 * factor}"] = (lam * mean).astype(np.float32)
+        # point-descriptor head: the mean input of fine_proj (the last decoder block's output) over both clouds
+        out[f"p{64 * factor}"] = np.concatenate([taps["src.dec1.1"], taps["tgt.dec1.1"]]).astype(np.float64).mean(0).astype(np.float32)
     path = os.path.join(ROOT, "roitr_amd", "configs", "selective_centre.npz")
     np.savez(path, **out)
     print("wrote", path)

@@ -465,8 +465,46 @@ def prep_eval_golden():
     print("wrote", path, "%.2f MB" % (os.path.getsize(path) / 1e6), {k: float(v) for k, v in rec.items() if k.endswith(("IR", "PIR", "IR_bu"))})
 
 
+def ot_wide_golden():
+    """LearnableLogOptimalTransport (model/modules.py:10-72) of the reference on score patches whose range leaves what an
+    exponential-domain Sinkhorn can hold in fp32 (scores hundreds above / below the dustbin score alpha, planted +150 peaks, N(0, 30)
+    noise) next to ordinary ones -> ot_wide.npz.  Pins the log-domain path of csrc/matching.hip (ot_log_kernel) and the oracle."""
+    from model.modules import LearnableLogOptimalTransport
+    rng = np.random.default_rng(4242)
+    f32 = np.float32
+    B, K = 10, 64
+    scores = rng.normal(0, 1.0, (B, K, K)).astype(f32)
+    scores[1] += 200.0                                         # everything far above alpha: the dustbin column needs e^200
+    scores[2] = rng.normal(0, 30.0, (K, K))                    # wide noise
+    hit = rng.random(K) < 0.7
+    scores[3, np.arange(K)[hit], rng.permutation(K)[hit]] += 150.0   # planted peaks
+    scores[4] -= 300.0                                         # everything far below alpha
+    scores[5] = rng.uniform(-14.0, 15.5, (K, K))               # a row range just under the fast-path limit (alpha ~ 1 inside it)
+    scores[6] = rng.uniform(-15.0, 16.5, (K, K))               # ... and just above it
+    scores[7] = rng.normal(0, 30.0, (K, K))
+    scores[8] = rng.normal(100, 40.0, (K, K))
+    row_masks = rng.random((B, K)) < 0.9
+    col_masks = rng.random((B, K)) < 0.9
+    row_masks[0] = True; col_masks[0] = True
+    row_masks[7, 3:] = False                                   # three valid rows
+    col_masks[8, 1:] = False                                   # one valid column
+    ot = LearnableLogOptimalTransport(100)
+    with torch.no_grad():
+        ot.alpha.fill_(float(closed_form_param("optimal_transport.alpha", ())))
+        out = ot(torch.from_numpy(scores), torch.from_numpy(row_masks), torch.from_numpy(col_masks))
+    rec = {"scores": scores, "row_masks": row_masks, "col_masks": col_masks, "alpha": t2n(ot.alpha).astype(f32), "out": t2n(out)}
+    path = os.path.join(HERE, "ot_wide.npz")
+    np.savez_compressed(path, **rec)
+    print("wrote", path, "%.2f MB" % (os.path.getsize(path) / 1e6), "finite:", bool(np.isfinite(rec["out"]).all()),
+          "range", float(rec["out"].min()), float(rec["out"].max()))
+
+
 if __name__ == "__main__":
-    if "--prep-eval" in sys.argv:
+    if "--ot-wide" in sys.argv:
+        install_stubs()
+        torch.manual_seed(0)
+        ot_wide_golden()
+    elif "--prep-eval" in sys.argv:
         install_stubs()
         torch.manual_seed(0)
         prep_eval_golden()

@@ -124,6 +124,26 @@ def test_ot_and_fine_stage(golden_stages):
         np.testing.assert_allclose(sc, s[tag + ".scores"], rtol=1e-5)
 
 
+def _ot_wide_check(ot, g, tol):
+    B = g["scores"].shape[0]
+    rm = np.concatenate([g["row_masks"], np.ones((B, 1), bool)], 1)
+    cm = np.concatenate([g["col_masks"], np.ones((B, 1), bool)], 1)
+    valid = rm[:, :, None] & cm[:, None, :]
+    assert np.isfinite(ot[valid]).all()
+    for b in range(B):
+        err = (np.abs(ot[b] - g["out"][b]) / np.maximum(1.0, np.abs(g["out"][b])))[valid[b]].max()
+        assert err < tol, (b, float(err))
+
+
+def test_ot_wide_score_ranges():
+    """Optimal transport on patches whose scores sit hundreds above / below the dustbin score or span +-100 (tests/golden/
+    ot_wide.npz, captured from the reference's log-domain layer): the regime an exponential-domain Sinkhorn cannot hold in fp32."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "ot_wide.npz"))
+    ot = R.optimal_transport(g["scores"], g["row_masks"], g["col_masks"], float(g["alpha"]))
+    _ot_wide_check(ot, g, 2e-5)
+
+
 def test_adaptive_matching_stage(golden_stages):
     s = golden_stages
     for tag, mn in (("adaptive", 128), ("adaptive_nz", 32)):

@@ -34,7 +34,7 @@ WORKER = textwrap.dedent("""
            "meta": None if merged is None else {"n": {str(k): v for k, v in merged.n_scores.items()}, "trunc": merged.truncated,
                                                 "ranks": merged.ranks_seen, "backend": merged.backend,
                                                 "aux": {str(k): [a if a == a else None for a in v] for k, v in merged.aux.items()}}}
-    print("RESULT " + json.dumps(out), flush=True)
+    open(os.path.join(os.environ["RESULT_DIR"], f"rank{rank}.json"), "w").write(json.dumps(out))
     dist.destroy_process_group()
 """) % ROOT
 
@@ -51,12 +51,14 @@ def test_pairs_for_rank_partition():
 
 
 def _torchrun(script, port):
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    # every rank writes its result to its own file (two ranks printing to one pipe can interleave their lines)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1", RESULT_DIR=str(script.parent))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), str(script)]
     r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=240)
     assert r.returncode == 0, r.stderr[-2000:]
-    return {x["rank"]: x for x in (json.loads(l.split("RESULT ", 1)[1]) for l in r.stdout.splitlines() if "RESULT " in l)}
+    res = [json.load(open(script.parent / f"rank{k}.json")) for k in (0, 1)]
+    return {x["rank"]: x for x in res}
 
 
 def test_two_process_gather_gloo(tmp_path):
@@ -137,7 +139,7 @@ BENCH_WORKER = textwrap.dedent("""
         out["recs"] = {"ids": sorted(recs.keys()), "n": {str(k): v for k, v in recs.n_scores.items()}, "ranks": recs.ranks_seen,
                        "summary": benchloop.gather_summary(recs, B, STEPS, 8),
                        "scores": {str(k): v.tolist() for k, v in recs.items()}}
-    print("RESULT " + json.dumps(out), flush=True)
+    open(os.path.join(os.environ["RESULT_DIR"], f"rank{rank}.json"), "w").write(json.dumps(out))
     dist.destroy_process_group()
 """) % ROOT
 

@@ -49,6 +49,26 @@ def test_optimal_transport_stage(golden_stages):
     assert (ot[~valid] < -1e5).all()
 
 
+def test_optimal_transport_wide_score_ranges():
+    """Patches the exponential-domain kernel cannot hold in fp32 (scores hundreds above / below the dustbin score, +150 peaks,
+    N(0, 30) noise; tests/golden/ot_wide.npz from the reference's log-domain layer) are served by ot_log_kernel; patches 0, 5 and
+    9 stay on the fast path (row range <= 30), patch 6 sits just above the limit.  Same tolerance as the ordinary OT stage,
+    relative above magnitude 1 (entries reach -300)."""
+    import os
+    from roitr_amd import ops
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "ot_wide.npz"))
+    ot = ops.optimal_transport(dev(g["scores"]), dev(g["row_masks"]), dev(g["col_masks"]), float(g["alpha"])).cpu().numpy()
+    B = ot.shape[0]
+    rm = np.concatenate([g["row_masks"], np.ones((B, 1), bool)], 1)
+    cm = np.concatenate([g["col_masks"], np.ones((B, 1), bool)], 1)
+    valid = rm[:, :, None] & cm[:, None, :]
+    assert np.isfinite(ot[valid]).all()
+    for b in range(B):
+        err = (np.abs(ot[b] - g["out"][b]) / np.maximum(1.0, np.abs(g["out"][b])))[valid[b]].max()
+        assert err < 1e-4, (b, float(err))
+    assert (ot[~valid] < -1e5).all()
+
+
 @pytest.mark.parametrize("k,mutual", [(3, True), (2, True), (3, False)])
 def test_fine_matching_stage(golden_stages, k, mutual):
     from roitr_amd import ops
@@ -380,3 +400,49 @@ def test_gemm_k_concatenated_operand(N, K, Kc):
         assert torch.equal(ops.linear_layernorm(x, w, b, gam, bet, x_cat=xc), ops.linear_layernorm(xx, w, b, gam, bet))
     ref = (xx[:2048].double() @ w.double().T + b.double()).clamp_min(0)
     assert (ops.linear(x, w, b, relu=True, x_cat=xc)[:2048].double() - ref).abs().max().item() < 1e-4
+
+
+@pytest.mark.parametrize("H,K,M,order", [(64, 8, 1000, True), (64, 16, 333, False), (128, 16, 777, True), (128, 8, 65, False)])
+def test_local_block_against_float64(H, K, M, order):
+    """csrc/local_block.hip (the fused block transformer of levels 1-2) against a float64 restatement of its formulas from the
+    same folded weights: tiles that are not full (M % 64, M % 32 != 0), a visiting order, both widths and neighbour counts."""
+    from roitr_amd import ops
+    rng = np.random.default_rng(H + K + M)
+    f32 = np.float32
+    r = lambda *s: (rng.standard_normal(s) / np.sqrt(s[-1])).astype(f32)
+    x = rng.standard_normal((M, H)).astype(f32)
+    kv = rng.standard_normal((M, 2 * H)).astype(f32)
+    grp = rng.integers(0, M, (M, K)).astype(np.int32)
+    ppf = rng.random((M, K, 4)).astype(f32)
+    w = dict(wq=r(H, H), bq=r(H), wpe=r(H, 4), bpe=r(H), wvpe=r(H, 4), bvpe=r(H), wcat=r(H, 2 * H), bcat=r(H),
+             norm_w=(1 + 0.1 * r(H)).astype(f32), norm_b=(0.1 * r(H)).astype(f32), wout=r(H, H), bout=r(H),
+             bn2_w=(1 + 0.1 * r(H)).astype(f32), bn2_b=(0.1 * r(H)).astype(f32))
+    node_order = None
+    if order:
+        perm = rng.permutation(M).astype(np.int32)
+        node_order = np.zeros((M, 4), f32)
+        node_order[:, 3] = perm.view(f32)
+    got = ops.local_block(dev(x), dev(kv), dev(grp), dev(ppf), {k: dev(v) for k, v in w.items()},
+                          node_order=dev(node_order) if order else None).cpu().numpy()
+    D = {k: v.astype(np.float64) for k, v in w.items()}
+    X, KV, P = x.astype(np.float64), kv.astype(np.float64), ppf.astype(np.float64)
+    c = H // 4
+    q = X @ D["wq"].T + D["bq"]
+    kg, vg = KV[grp][:, :, :H], KV[grp][:, :, H:]                                   # (M, K, H)
+    qh = q.reshape(M, 4, c)
+    s_k = np.einsum("mhc,mkhc->mhk", qh, kg.reshape(M, K, 4, c))
+    qp = np.einsum("mhc,hct->mht", qh, D["wpe"].reshape(4, c, 4))                    # Wpe_h^T q_h
+    qb = np.einsum("mhc,hc->mh", qh, D["bpe"].reshape(4, c))
+    s = (s_k + np.einsum("mht,mkt->mhk", qp, P) + qb[:, :, None]) / np.sqrt(c)
+    a = np.exp(s - s.max(-1, keepdims=True)); a /= a.sum(-1, keepdims=True)
+    att = np.einsum("mhk,mkhc->mhc", a, vg.reshape(M, K, 4, c)).reshape(M, H)
+    pbar = np.einsum("mhk,mkt->mht", a, P)                                           # (M, 4, 4)
+    att = att + np.einsum("hct,mht->mhc", D["wvpe"].reshape(4, c, 4), pbar).reshape(M, H) + D["bvpe"]
+
+    def ln(t, g_, b_):
+        mu = t.mean(1, keepdims=True)
+        return (t - mu) / np.sqrt(((t - mu) ** 2).mean(1, keepdims=True) + 1e-5) * g_ + b_
+    y = ln(np.concatenate([att, X], 1) @ D["wcat"].T + D["bcat"], D["norm_w"], D["norm_b"])
+    ref = np.maximum(ln(y @ D["wout"].T + D["bout"], D["bn2_w"], D["bn2_b"]) + X, 0.0)
+    err = np.abs(got - ref).max()
+    assert err < 3e-5, err
