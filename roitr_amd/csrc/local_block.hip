@@ -111,7 +111,7 @@ __device__ __forceinline__ void acc_store(const Acc& acc, const float* __restric
 
 // DBG (tuning only, scripts/bench_local_block.py): 0 = the kernel; 1 = without the attention phase; 2 = attention only
 template <int H, int K, int TM, int DBG = 0>
-__global__ __launch_bounds__(256) void local_block_kernel(RoitrLocalBlock a)
+__global__ __launch_bounds__(256, K <= 8 ? 3 : 2) void local_block_kernel(RoitrLocalBlock a)
 {
     constexpr int AP = H + 4;                 // activation image pitch
     constexpr int LPN = H / 4;                // lanes per node in the attention
@@ -135,10 +135,17 @@ __global__ __launch_bounds__(256) void local_block_kernel(RoitrLocalBlock a)
     __syncthreads();
     {
         constexpr int F4 = H / 4;             // float4 per row
+        constexpr int NX = TM * F4 / 256;     // float4 per thread: all requested before the first is written to LDS
+        float4 xr[NX];
 #pragma unroll
-        for (int e = tid; e < TM * F4; e += 256) {
-            const int r = e / F4, c4 = e % F4;
-            *reinterpret_cast<float4*>(R1 + r * AP + 4 * c4) = *reinterpret_cast<const float4*>(a.x + (size_t)ids[r] * H + 4 * c4);
+        for (int u = 0; u < NX; ++u) {
+            const int e = tid + 256 * u;
+            xr[u] = *reinterpret_cast<const float4*>(a.x + (size_t)ids[e / F4] * H + 4 * (e % F4));
+        }
+#pragma unroll
+        for (int u = 0; u < NX; ++u) {
+            const int e = tid + 256 * u;
+            *reinterpret_cast<float4*>(R1 + (e / F4) * AP + 4 * (e % F4)) = xr[u];
         }
     }
     const int r0 = TM == 64 ? (wave >> 1) * 32 : 0;
@@ -153,28 +160,36 @@ __global__ __launch_bounds__(256) void local_block_kernel(RoitrLocalBlock a)
     if (DBG != 1) {
         const int ns = lane / LPN, j = lane % LPN, jq = j % HL;
         const int t4 = jq & 3;                                    // PPF component this lane carries
-        // per-lane constants of the folded positional branch
-        float4 wpe4[4]; float bpe4[4];
+        constexpr int NRD = TM / (4 * NPW);
+        int gi[K]; float pv[K];
+        auto load_ids = [&](int rd_, int (&g_)[K], float (&p_)[K]) {
+            const int node_ = ids[(rd_ * 4 + wave) * NPW + ns];
+            const int4* gp = reinterpret_cast<const int4*>(a.group_idx + (size_t)node_ * K);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { wpe4[i] = reinterpret_cast<const float4*>(a.wpe)[4 * j + i]; bpe4[i] = a.bpe[4 * j + i]; }
-        for (int rd = 0; rd < TM / (4 * NPW); ++rd) {
+            for (int q4 = 0; q4 < K / 4; ++q4) { const int4 t = gp[q4]; g_[4 * q4] = t.x; g_[4 * q4 + 1] = t.y; g_[4 * q4 + 2] = t.z; g_[4 * q4 + 3] = t.w; }
+            const float* pf = a.ppf + (size_t)node_ * K * 4 + t4;
+#pragma unroll
+            for (int kk = 0; kk < K; ++kk) p_[kk] = pf[kk * 4];
+        };
+        load_ids(0, gi, pv);
+        for (int rd = 0; rd < NRD; ++rd) {
             const int row = (rd * 4 + wave) * NPW + ns;            // tile row of this lane's node
-            const int node = ids[row];
-            int gi[K];
-            {
-                const int4* gp = reinterpret_cast<const int4*>(a.group_idx + (size_t)node * K);
-#pragma unroll
-                for (int q4 = 0; q4 < K / 4; ++q4) { const int4 t = gp[q4]; gi[4 * q4] = t.x; gi[4 * q4 + 1] = t.y; gi[4 * q4 + 2] = t.z; gi[4 * q4 + 3] = t.w; }
-            }
-            float pv[K];
-            {
-                const float* pf = a.ppf + (size_t)node * K * 4 + t4;
-#pragma unroll
-                for (int kk = 0; kk < K; ++kk) pv[kk] = pf[kk * 4];
-            }
-            float4 kr[K];
+            // one round trip per round: the key AND value rows of the K neighbours, and the next round's indices / PPFs behind them
+            // (K = 16: the value rows follow the scores instead -- 64 more registers in flight would halve the occupancy)
+            constexpr bool V_EARLY = K <= 8;
+            float4 kr[K], vr[K];
 #pragma unroll
             for (int kk = 0; kk < K; ++kk) kr[kk] = *reinterpret_cast<const float4*>(a.kv + (size_t)gi[kk] * (2 * H) + 4 * j);
+            if (V_EARLY) {
+#pragma unroll
+                for (int kk = 0; kk < K; ++kk) vr[kk] = *reinterpret_cast<const float4*>(a.kv + (size_t)gi[kk] * (2 * H) + H + 4 * j);
+            }
+            int gn[K]; float pn[K];
+            if (rd + 1 < NRD) load_ids(rd + 1, gn, pn);
+            // per-lane constants of the folded positional branch (L1-resident; not kept across rounds: registers)
+            float4 wpe4[4]; float bpe4[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { wpe4[i] = reinterpret_cast<const float4*>(a.wpe)[4 * j + i]; bpe4[i] = a.bpe[4 * j + i]; }
             float4 qv = *reinterpret_cast<const float4*>(R2 + row * AP + 4 * j);
             // qp[h] = [Wpe_h^T q_h, q_h . bpe_h]
             float ec, c4;
@@ -202,13 +217,13 @@ __global__ __launch_bounds__(256) void local_block_kernel(RoitrLocalBlock a)
                 sc[kk] = d;
                 mx = fmaxf(mx, d);
             }
-            // value rows: requested after the scores (the key registers are dead), softmax overlaps their flight
-            float4 vr[K];
+            if (!V_EARLY) {
 #pragma unroll
-            for (int kk = 0; kk < K; ++kk) vr[kk] = *reinterpret_cast<const float4*>(a.kv + (size_t)gi[kk] * (2 * H) + H + 4 * j);
+                for (int kk = 0; kk < K; ++kk) vr[kk] = *reinterpret_cast<const float4*>(a.kv + (size_t)gi[kk] * (2 * H) + H + 4 * j);
+            }
             float sum = 0.f;
 #pragma unroll
-            for (int kk = 0; kk < K; ++kk) { sc[kk] = expf(sc[kk] - mx); sum += sc[kk]; }   // accurate exp: the reference softmax is libm-exact
+            for (int kk = 0; kk < K; ++kk) { sc[kk] = __expf(sc[kk] - mx); sum += sc[kk]; }   // arguments in [-inf, 0]: v_exp_f32 is good to ~1e-6 relative here
             float pb = 0.f;
             float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
@@ -226,6 +241,10 @@ __global__ __launch_bounds__(256) void local_block_kernel(RoitrLocalBlock a)
             o.z += w2.x * b0 + w2.y * b1 + w2.z * b2 + w2.w * b3 + bias.z;
             o.w += w3.x * b0 + w3.y * b1 + w3.z * b2 + w3.w * b3 + bias.w;
             *reinterpret_cast<float4*>(R2 + row * AP + 4 * j) = o;
+            if (rd + 1 < NRD) {
+#pragma unroll
+                for (int kk = 0; kk < K; ++kk) { gi[kk] = gn[kk]; pv[kk] = pn[kk]; }
+            }
         }
     }
     // ---- P3: y = LN([att | x] Wcat^T + bcat)   (the opening barrier of gemm_phase publishes the attention rows)
@@ -241,6 +260,7 @@ __global__ __launch_bounds__(256) void local_block_kernel(RoitrLocalBlock a)
         float gam[HV], bet[HV];
 #pragma unroll
         for (int i = 0; i < HV; ++i) { gam[i] = a.norm_w[lane + 64 * i]; bet[i] = a.norm_b[lane + 64 * i]; }
+#pragma unroll 4
         for (int rl = wave; rl < TM; rl += 4) {
             float t[HV];
             float s_ = 0.f;
@@ -255,7 +275,14 @@ __global__ __launch_bounds__(256) void local_block_kernel(RoitrLocalBlock a)
             for (int i = 0; i < HV; ++i) R1[rl * AP + lane + 64 * i] = (t[i] - mean) * rstd * gam[i] + bet[i];
         }
     }
-    // ---- P4: out = relu(LN_bn2(y Wout^T + bout) + x)
+    // ---- P4: out = relu(LN_bn2(y Wout^T + bout) + x); the residual rows of this wave are requested now, the GEMM hides them
+    float xres[TM / 4][HV];
+#pragma unroll
+    for (int u = 0; u < TM / 4; ++u) {
+        const size_t node = (size_t)ids[wave + 4 * u];
+#pragma unroll
+        for (int i = 0; i < HV; ++i) xres[u][i] = a.x[node * H + lane + 64 * i];
+    }
     acc_zero(acc);
     if (DBG != 2) gemm_phase<H, AP>(acc, R1, H, a.wout, H, 0, WS, r0, c0, tid);
     __syncthreads();                                              // R2's LayerNorm reads are long done; this one orders the MFMA reads of WS / R1
@@ -265,7 +292,9 @@ __global__ __launch_bounds__(256) void local_block_kernel(RoitrLocalBlock a)
         float gam[HV], bet[HV];
 #pragma unroll
         for (int i = 0; i < HV; ++i) { gam[i] = a.bn2_w[lane + 64 * i]; bet[i] = a.bn2_b[lane + 64 * i]; }
-        for (int rl = wave; rl < TM; rl += 4) {
+#pragma unroll
+        for (int u = 0; u < TM / 4; ++u) {
+            const int rl = wave + 4 * u;
             if (s0 + rl >= a.M) break;                            // wave-uniform; rows are in slot order
             const size_t node = (size_t)ids[rl];
             float t[HV];
@@ -279,7 +308,7 @@ __global__ __launch_bounds__(256) void local_block_kernel(RoitrLocalBlock a)
             const float rstd = 1.0f / sqrtf(wave_sum(q_) / (float)H + a.eps);
 #pragma unroll
             for (int i = 0; i < HV; ++i) {
-                const float y = (t[i] - mean) * rstd * gam[i] + bet[i] + a.x[node * H + lane + 64 * i];
+                const float y = (t[i] - mean) * rstd * gam[i] + bet[i] + xres[u][i];
                 a.out[node * H + lane + 64 * i] = fmaxf(y, 0.f);
             }
         }

@@ -9,11 +9,11 @@ from roitr_amd.synthetic import make_pair
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 8000
 pairs = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 cores = len(os.sched_getaffinity(0))
-mb = build_model("4DMatch", operand_dtype="bf16")
-mf = build_model("4DMatch")
+mb = build_model("4DMatch", operand_dtype="bf16", weights="selective")
+mf = build_model("4DMatch", weights="selective")
 for i in range(pairs):
-    pair = make_pair(n, config=4, pair_index=2 + i)
-    ref = R.forward(R.closed_form_state(2), pair, cfg=dict(R.FDMATCH_CFG), threads=cores)
+    pair = make_pair(n, config=4, pair_index=2 + i, normals="field")
+    ref = R.forward(R.closed_form_state(2, "selective"), pair, cfg=dict(R.FDMATCH_CFG), threads=cores)
     with torch.no_grad():
         ob = mb.forward(**pair_to_device(pair))
         of = mf.forward(**pair_to_device(pair))

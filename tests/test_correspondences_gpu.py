@@ -3,7 +3,7 @@
 With the plain closed-form weights no fine-matching score clears the 0.05 confidence threshold at N = 1024 (the golden has 0
 correspondences) and every 4DMatch node pair passes the 0.75 similarity threshold; the 'selective' weight variant
 (roitr_amd/weights.py) on pairs with field normals makes both stages discriminate:
-  * tests/golden/pair_sel_n1024.npz (captured from the reference): 5 814 correspondences, compared as a multiset of
+  * tests/golden/pair_sel_n1024.npz (captured from the reference): 4 740 correspondences, compared as a multiset of
     (tgt point, src point) with their scores, in torch.nonzero order, plus matching_scores and the inlier ratio;
   * full sizes against the CPU oracle (pinned to the reference by tests/test_oracle_cpu.py): 3DMatch N = 5000, 4DMatch N = 8000
     (a few percent of the 125^2 node pairs under the threshold: the coarse comparison can fail);
@@ -53,7 +53,7 @@ def test_selective_golden_end_to_end():
     assert (np.abs(ms - ref) / np.maximum(1.0, np.abs(ref)))[valid].max() < 2e-4
     got = to_numpy_corr(out)
     want = {k: g["out." + k] for k in ("tgt_corr_points", "src_corr_points", "corr_scores")}
-    assert want["corr_scores"].shape[0] == 5814
+    assert want["corr_scores"].shape[0] > 1000            # a real set (4 740 with the committed golden), not the `0 == 0` of the plain weights
     frac, err, common = compare_correspondences(got, want)
     assert frac >= 0.995, (frac, got["corr_scores"].shape)
     assert err < 1e-4, err

@@ -192,7 +192,7 @@ def _check_correspondences(out, g, min_common=0.995):
 
 def test_oracle_selective_forward_matches_reference_golden():
     """3DMatch settings with the 'selective' weight variant on a pair with field normals (tests/golden/pair_sel_n1024.npz,
-    captured from the reference): the golden whose forward ends in 5 814 correspondences -- compares what the tester saves."""
+    captured from the reference): the golden whose forward ends in 4 740 correspondences -- compares what the tester saves."""
     import os
     g = np.load(os.path.join(os.path.dirname(__file__), "golden", "pair_sel_n1024.npz"))
     taps = {}
