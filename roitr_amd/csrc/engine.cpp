@@ -863,9 +863,9 @@ extern "C" int roitr_engine_forward(void* h, const RoitrForwardIO* io, hipStream
             ppf_self[l] = A.get<float>((size_t)V.T[l] * K * 4);
             if (A.fail) break;
             if (grid[l]) {
-                // mean points per cell: the prefilter kNN kernel wants the sphere of one cell size to hold ~2 (k + 2) points
-                // (4.19 rho): 6 at level 1 (k = 8), 9 from level 2 on (k = 16)
-                CHK(roitr_knn_build_grid_ex(NC, V.T[l], mcap, p[l], D.off[l], knn_ws[l], l == 0 ? 6.0f : 9.0f, st));
+                // 6 points per cell on average: at level 1 (k = 8) the sphere of one cell size then holds ~2.5 (k + 2) points, what
+                // the prefilter kNN kernel's radius rule needs
+                CHK(roitr_knn_build_grid_ex(NC, V.T[l], mcap, p[l], D.off[l], knn_ws[l], 6.0f, st));
                 order[l] = roitr_knn_sorted_points(NC, V.T[l], mcap, knn_ws[l]);
             }
             CHK(roitr_knnquery_ex(NC, V.T[l], V.T[l], K + 1, p[l], p[l], D.off[l], D.off[l], nullptr, nullptr, g_self[l], ppf_self[l], nrm[l],

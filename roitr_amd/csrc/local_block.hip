@@ -226,9 +226,10 @@ __global__ __launch_bounds__(256, K <= 8 ? 3 : 2) void local_block_kernel(RoitrL
             for (int kk = 0; kk < K; ++kk) { sc[kk] = __expf(sc[kk] - mx); sum += sc[kk]; }   // arguments in [-inf, 0]: v_exp_f32 is good to ~1e-6 relative here
             float pb = 0.f;
             float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+            const float inv = 1.0f / sum;
 #pragma unroll
             for (int kk = 0; kk < K; ++kk) {
-                const float p = sc[kk] / sum;
+                const float p = sc[kk] * inv;
                 pb = fmaf(p, pv[kk], pb);                          // pbar[h][t4]: every quad of the head holds its own copy
                 o.x = fmaf(p, vr[kk].x, o.x); o.y = fmaf(p, vr[kk].y, o.y); o.z = fmaf(p, vr[kk].z, o.z); o.w = fmaf(p, vr[kk].w, o.w);
             }
@@ -257,31 +258,46 @@ __global__ __launch_bounds__(256, K <= 8 ? 3 : 2) void local_block_kernel(RoitrL
     acc_store<AP>(acc, a.bcat, R2, r0, c0, lane);
     __syncthreads();
     {
-        float gam[HV], bet[HV];
+        // LayerNorm over the H channels of a row: 16 lanes per row (HV float4 per lane), four rows per wave at a time -- the row
+        // sums are 4 DPP steps inside the 16-lane row instead of a 64-lane wave reduction per row
+        const int lr = lane >> 4, lc = lane & 15;
+        float4 gam[HV], bet[HV];
 #pragma unroll
-        for (int i = 0; i < HV; ++i) { gam[i] = a.norm_w[lane + 64 * i]; bet[i] = a.norm_b[lane + 64 * i]; }
-#pragma unroll 4
-        for (int rl = wave; rl < TM; rl += 4) {
-            float t[HV];
+        for (int i = 0; i < HV; ++i) { gam[i] = reinterpret_cast<const float4*>(a.norm_w)[lc + 16 * i]; bet[i] = reinterpret_cast<const float4*>(a.norm_b)[lc + 16 * i]; }
+#pragma unroll
+        for (int u = 0; u < TM / 16; ++u) {
+            const int rl = (u * 4 + wave) * 4 + lr;
+            float4 t[HV];
             float s_ = 0.f;
 #pragma unroll
-            for (int i = 0; i < HV; ++i) { t[i] = R2[rl * AP + lane + 64 * i]; s_ += t[i]; }
-            const float mean = wave_sum(s_) / (float)H;
+            for (int i = 0; i < HV; ++i) { t[i] = *reinterpret_cast<const float4*>(R2 + rl * AP + 4 * (lc + 16 * i)); s_ += (t[i].x + t[i].y) + (t[i].z + t[i].w); }
+            const float mean = row_allsum(s_) / (float)H;
             float q_ = 0.f;
 #pragma unroll
-            for (int i = 0; i < HV; ++i) { const float d = t[i] - mean; q_ += d * d; }
-            const float rstd = 1.0f / sqrtf(wave_sum(q_) / (float)H + a.eps);
+            for (int i = 0; i < HV; ++i) {
+                const float dx = t[i].x - mean, dy = t[i].y - mean, dz = t[i].z - mean, dw = t[i].w - mean;
+                q_ += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+            }
+            const float rstd = 1.0f / sqrtf(row_allsum(q_) / (float)H + a.eps);
 #pragma unroll
-            for (int i = 0; i < HV; ++i) R1[rl * AP + lane + 64 * i] = (t[i] - mean) * rstd * gam[i] + bet[i];
+            for (int i = 0; i < HV; ++i) {
+                float4 y;
+                y.x = (t[i].x - mean) * rstd * gam[i].x + bet[i].x; y.y = (t[i].y - mean) * rstd * gam[i].y + bet[i].y;
+                y.z = (t[i].z - mean) * rstd * gam[i].z + bet[i].z; y.w = (t[i].w - mean) * rstd * gam[i].w + bet[i].w;
+                *reinterpret_cast<float4*>(R1 + rl * AP + 4 * (lc + 16 * i)) = y;
+            }
         }
     }
     // ---- P4: out = relu(LN_bn2(y Wout^T + bout) + x); the residual rows of this wave are requested now, the GEMM hides them
-    float xres[TM / 4][HV];
+    float4 xres[TM / 16][HV];
+    {
+        const int lr = lane >> 4, lc = lane & 15;
 #pragma unroll
-    for (int u = 0; u < TM / 4; ++u) {
-        const size_t node = (size_t)ids[wave + 4 * u];
+        for (int u = 0; u < TM / 16; ++u) {
+            const size_t node = (size_t)ids[(u * 4 + wave) * 4 + lr];
 #pragma unroll
-        for (int i = 0; i < HV; ++i) xres[u][i] = a.x[node * H + lane + 64 * i];
+            for (int i = 0; i < HV; ++i) xres[u][i] = *reinterpret_cast<const float4*>(a.x + node * H + 4 * (lc + 16 * i));
+        }
     }
     acc_zero(acc);
     if (DBG != 2) gemm_phase<H, AP>(acc, R1, H, a.wout, H, 0, WS, r0, c0, tid);
@@ -289,27 +305,36 @@ __global__ __launch_bounds__(256, K <= 8 ? 3 : 2) void local_block_kernel(RoitrL
     acc_store<AP>(acc, a.bout, R2, r0, c0, lane);
     __syncthreads();
     {
-        float gam[HV], bet[HV];
+        const int lr = lane >> 4, lc = lane & 15;
+        float4 gam[HV], bet[HV];
 #pragma unroll
-        for (int i = 0; i < HV; ++i) { gam[i] = a.bn2_w[lane + 64 * i]; bet[i] = a.bn2_b[lane + 64 * i]; }
+        for (int i = 0; i < HV; ++i) { gam[i] = reinterpret_cast<const float4*>(a.bn2_w)[lc + 16 * i]; bet[i] = reinterpret_cast<const float4*>(a.bn2_b)[lc + 16 * i]; }
 #pragma unroll
-        for (int u = 0; u < TM / 4; ++u) {
-            const int rl = wave + 4 * u;
-            if (s0 + rl >= a.M) break;                            // wave-uniform; rows are in slot order
-            const size_t node = (size_t)ids[rl];
-            float t[HV];
+        for (int u = 0; u < TM / 16; ++u) {
+            const int rl = (u * 4 + wave) * 4 + lr;
+            float4 t[HV];
             float s_ = 0.f;
 #pragma unroll
-            for (int i = 0; i < HV; ++i) { t[i] = R2[rl * AP + lane + 64 * i]; s_ += t[i]; }
-            const float mean = wave_sum(s_) / (float)H;
+            for (int i = 0; i < HV; ++i) { t[i] = *reinterpret_cast<const float4*>(R2 + rl * AP + 4 * (lc + 16 * i)); s_ += (t[i].x + t[i].y) + (t[i].z + t[i].w); }
+            const float mean = row_allsum(s_) / (float)H;
             float q_ = 0.f;
 #pragma unroll
-            for (int i = 0; i < HV; ++i) { const float d = t[i] - mean; q_ += d * d; }
-            const float rstd = 1.0f / sqrtf(wave_sum(q_) / (float)H + a.eps);
-#pragma unroll
             for (int i = 0; i < HV; ++i) {
-                const float y = (t[i] - mean) * rstd * gam[i] + bet[i] + xres[u][i];
-                a.out[node * H + lane + 64 * i] = fmaxf(y, 0.f);
+                const float dx = t[i].x - mean, dy = t[i].y - mean, dz = t[i].z - mean, dw = t[i].w - mean;
+                q_ += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+            }
+            const float rstd = 1.0f / sqrtf(row_allsum(q_) / (float)H + a.eps);
+            if (s0 + rl < a.M) {                                  // rows of dead slots (last tile) are not stored
+                const size_t node = (size_t)ids[rl];
+#pragma unroll
+                for (int i = 0; i < HV; ++i) {
+                    float4 y;
+                    y.x = fmaxf((t[i].x - mean) * rstd * gam[i].x + bet[i].x + xres[u][i].x, 0.f);
+                    y.y = fmaxf((t[i].y - mean) * rstd * gam[i].y + bet[i].y + xres[u][i].y, 0.f);
+                    y.z = fmaxf((t[i].z - mean) * rstd * gam[i].z + bet[i].z + xres[u][i].z, 0.f);
+                    y.w = fmaxf((t[i].w - mean) * rstd * gam[i].w + bet[i].w + xres[u][i].w, 0.f);
+                    *reinterpret_cast<float4*>(a.out + node * H + 4 * (lc + 16 * i)) = y;
+                }
             }
         }
     }
@@ -346,7 +371,8 @@ extern "C" int roitr_local_block(const RoitrLocalBlock* a, hipStream_t stream)
     if (a->M <= 0) return ROITR_OK;
     if (!roitr_local_block_supported(a->H, a->K)) return ROITR_ERR_UNSUPPORTED;
     if ((((uintptr_t)a->x | (uintptr_t)a->kv | (uintptr_t)a->group_idx | (uintptr_t)a->ppf | (uintptr_t)a->out | (uintptr_t)a->wq | (uintptr_t)a->wcat |
-          (uintptr_t)a->wout | (uintptr_t)a->wpe | (uintptr_t)a->wvpe | (uintptr_t)a->bvpe) & 15) != 0) {
+          (uintptr_t)a->wout | (uintptr_t)a->wpe | (uintptr_t)a->wvpe | (uintptr_t)a->bvpe | (uintptr_t)a->norm_w | (uintptr_t)a->norm_b |
+          (uintptr_t)a->bn2_w | (uintptr_t)a->bn2_b) & 15) != 0) {
         roitr_set_error("roitr_local_block: operands must be 16-byte aligned", __FILE__, __LINE__);
         return ROITR_ERR_ARG;
     }

@@ -1547,10 +1547,15 @@ int knnquery_impl(int b, int n, int m, int nsample, const float* xyz, const floa
     if (lane_ok && nsample + 1 <= 34) {   // from nsample + 1 = 35 the selection kernels take over
         const int need = nsample + 1;
         const bool exact_k = cap2 == INFINITY && v.retry != nullptr;   // roitr_knn_within (cap2 < inf) stops on the radius: ring kernel
+        // Measured per call at 512 pairs (round 3, rocprofv3 kernel trace): the prefilter form wins where the insertion chain
+        // dominated and the grid is fine enough for the radius rule -- the level-1 self query (need 10, 6 points per cell: 3.56 ->
+        // 2.24 ms) -- and loses on the 3-NN interpolation queries (need 4: the 4-deep chain was never the cost, 0.84 -> 4.0 ms)
+        // and, with grids of 6 points per cell, on need 18 (the sphere of one cell size holds 25 points: most lanes would hand
+        // their query over; with 9 per cell 3 x 1.0 -> 3 x (2.1 + 0.45) ms).  So: need 5..10 only.
         if (need <= 2) LANE_CASE(2);
-        else if (need <= 4) { if (exact_k) PREF_CASE(4, 24); else LANE_CASE(4); }
+        else if (need <= 4) LANE_CASE(4);
         else if (need <= 10) { if (exact_k) PREF_CASE(10, 40); else LANE_CASE(10); }
-        else if (need <= 18) { if (exact_k) PREF_CASE(18, 52); else LANE_CASE(18); }
+        else if (need <= 18) LANE_CASE(18);
         else LANE_CASE(34);
     } else if (use_grid && self_sorted && b > 0 && v.qorder && nsample - 1 <= 64) {
         // large k, self queries: workgroup per cell over the LDS-staged neighbourhood; what it cannot decide goes through the

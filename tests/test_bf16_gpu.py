@@ -7,11 +7,15 @@ everything that does not pass through a dense layer (FPS nodes, point-to-node pa
 within the STATED bf16 tolerance, coarse correspondences overlap.
 
 Stated tolerances (bf16 has 8 mantissa bits: 2^-9 = 2e-3 relative rounding per operand; the network is ~40 layers deep with
-LayerNorm re-normalising every block).  Measured on two N = 8000 pairs (scripts/bf16_report.py, profiles/r02_bf16_error.json):
-L2-normalised node descriptors (entries ~0.035): max abs error 1.6e-3, cosine >= 0.99996; point descriptors (|x| ~ 0.7): max abs
-error 2.2e-2, mean 3.1e-3; the fp32 engine on the same pairs: 2.8e-7 / 3.1e-6.  The tests allow ~3x the measured error:
-node descriptors max abs 5e-3 and cosine >= 0.9998 per node; point descriptors max abs 6e-2, mean 1e-2; coarse matching:
->= 90 % of the fp32 oracle's node correspondences selected.
+LayerNorm re-normalising every block).  Round 3: the pair and the weights are the 'selective' ones (roitr_amd/weights.py: x8 / x4
+gains on the geometry inputs and the point head, centred heads), whose coarse matching actually selects (1 033 of 15 625 node
+pairs for this pair) -- a harder case for bf16 than the plain weights: the centred descriptors are the small difference of two
+bf16-rounded quantities.  Measured on this N = 8000 pair (scripts/bf16_report.py, profiles/r03_bf16_error.json): L2-normalised
+node descriptors (entries ~0.035): max abs error 3.3e-3, cosine >= 0.99978; point descriptors (|x| ~ 0.30): max abs error 7.7e-2,
+mean 1.2e-2; coarse matching: 1 023 of the oracle's 1 033 node pairs found, 68 extra ones just over the 0.75 threshold; the fp32
+engine on the same pair: 8e-7 / 1.4e-5 and identical sets.  The tests allow ~3x the measured error: node descriptors max abs
+1e-2 and cosine >= 0.9993 per node; point descriptors max abs 0.25, mean 3.5e-2; coarse matching: >= 90 % of the fp32 oracle's
+node correspondences selected and at most 15 % more than it selects.
 """
 import os
 
@@ -137,18 +141,20 @@ def test_bf16_forward_descriptors_within_stated_tolerance(fd8000):
     out, ref = fd8000
     for k in ("src_node_feats", "tgt_node_feats"):
         a, b = out[k].cpu().numpy(), ref[k]
-        assert np.abs(a - b).max() < 5e-3, (k, float(np.abs(a - b).max()))
+        assert np.abs(a - b).max() < 1e-2, (k, float(np.abs(a - b).max()))
         cos = (a * b).sum(1) / (np.linalg.norm(a, axis=1) * np.linalg.norm(b, axis=1))
-        assert cos.min() > 0.9998, (k, float(cos.min()))
+        assert cos.min() > 0.9993, (k, float(cos.min()))
     for k in ("src_point_feats", "tgt_point_feats"):
         e = np.abs(out[k].cpu().numpy() - ref[k])
-        assert e.max() < 6e-2 and e.mean() < 1e-2, (k, float(e.max()), float(e.mean()))
+        assert e.max() < 0.25 and e.mean() < 3.5e-2, (k, float(e.max()), float(e.mean()))
 
 
 def test_bf16_forward_coarse_overlap(fd8000):
     out, ref = fd8000
     got = set(zip(out["tgt_node_corr_indices"].tolist(), out["src_node_corr_indices"].tolist()))
     want = set(zip(ref["tgt_node_corr_indices"].tolist(), ref["src_node_corr_indices"].tolist()))
+    assert 128 < len(want) < 0.5 * 125 * 125                 # the threshold branch, and not every node pair: this check can fail
     assert len(got & want) >= 0.9 * len(want), (len(got & want), len(want), len(got))
+    assert len(got) <= 1.15 * len(want), (len(got), len(want))
     sc = out["corr_scores"].cpu().numpy()
     assert (sc > 0.05).all()
