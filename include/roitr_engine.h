@@ -158,6 +158,21 @@ typedef struct RoitrLocalBlock {
 int roitr_local_block(const RoitrLocalBlock* a, roitr_stream_t stream);
 int roitr_local_block_supported(int H, int K);
 
+/* The first local transformer of the network (in_planes = 1, model/model.py:152): its q | k | v are rank-1 affine in the scalar
+ * input feature, so the whole TransitionDown transformer collapses to per-node scalars + two small on-chip GEMMs
+ * (csrc/local_block.hip local_first_kernel).  x (M,) the scalar feature; H = 64.  Constants (built from the layer's weights, see
+ * csrc/engine.cpp build_local_first): head_consts (4 heads x 16 floats: c1 c2 c3 c4 | P1[4] | P0[4] | d1 d0 | 0 0),
+ * G (64, 32) = the affine map of g = [S(4) | pbar(16) | x | 1 | 0...] to linear(att) + in_proj(x), zero_bias (64 zeros). */
+typedef struct RoitrLocalFirst {
+    int M, K;
+    const float* x; const int* group_idx; const float* ppf; const void* node_order;
+    const float* head_consts; const float* G; const float* zero_bias;
+    const float* norm_w; const float* norm_b; const float* wout; const float* bout;
+    float scale, eps;
+    float* out;
+} RoitrLocalFirst;
+int roitr_local_first(const RoitrLocalFirst* a, roitr_stream_t stream);
+
 /* ------------------------------------------------------------------ global geometric transformer */
 /* positional_encoding.py:110-137 get_embedding_indices for a batch of clouds.  pts (rows,3) = all nodes,
  * offset (b) cumulative, cloud_of_row (rows), eoff (b) = element offset of cloud c's (n_c, n_c) block.

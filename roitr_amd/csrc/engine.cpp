@@ -116,6 +116,8 @@ struct Engine {
     float* geo_tab = nullptr; float geo_tab_h = 0.f; int geo_tab_nd = 0, geo_tab_na = 0; double geo_tab_fit[4] = {0, 0, 0, 0};
     std::vector<GeoLayer> geo;
     const float* ot_alpha = nullptr;
+    // rank-1 form of the first local transformer (in_planes = 1): constants of csrc/local_block.hip local_first_kernel
+    float* first_consts = nullptr;   // head_consts (64) | G (64 x 32) | zero bias (64)
     Arena warena;  // derived weights
     Arena arena;   // per-forward scratch
     static constexpr int RING = 4;   // descriptor staging slots: the host may run RING forwards ahead
@@ -492,6 +494,69 @@ int ffn_apply(Engine& E, hipStream_t st, const Ffn& F, int M, int C, const float
     return 0;
 }
 
+
+// Constants of the first local transformer's rank-1 form (include/roitr_engine.h RoitrLocalFirst), in float64 from the layer's
+// weights: q = x qa + qb etc. with qa = Wq w_in, qb = Wq b_in + bq (ppftransformer.py:244, attention.py:166-168).
+int build_local_first(Engine& E, const LocalT& L, hipStream_t st)
+{
+    const int H = L.H, c = H / HEADS;
+    if (L.in_dim != 1 || H != 64 || E.cfg.operand_dtype != 0) return 0;
+    ROITR_HIP(hipStreamSynchronize(st));
+    auto get = [&](const float* dev, size_t n, std::vector<double>& out) -> int {
+        std::vector<float> h(n);
+        ROITR_HIP(hipMemcpy(h.data(), dev, sizeof(float) * n, hipMemcpyDeviceToHost));
+        out.assign(h.begin(), h.end());
+        return 0;
+    };
+    std::vector<double> win, bin, wq, bq, wk, bk, wv, bv, wpe, bpe, wvpe, bvpe, wl, bl;
+    CHK(get(L.in_proj.w, H, win)); CHK(get(L.in_proj.b, H, bin));
+    CHK(get(L.q.w, (size_t)H * H, wq)); CHK(get(L.q.b, H, bq)); CHK(get(L.k.w, (size_t)H * H, wk)); CHK(get(L.k.b, H, bk));
+    CHK(get(L.v.w, (size_t)H * H, wv)); CHK(get(L.v.b, H, bv));
+    CHK(get(L.wpe, (size_t)H * 4, wpe)); CHK(get(L.bpe, H, bpe)); CHK(get(L.wvpe, (size_t)H * 4, wvpe)); CHK(get(L.bvpe, H, bvpe));
+    CHK(get(L.lin.w, (size_t)H * H, wl)); CHK(get(L.lin.b, H, bl));
+    auto matvec = [&](const std::vector<double>& W, const std::vector<double>& x, const std::vector<double>* b) {
+        std::vector<double> y(H, 0.0);
+        for (int o = 0; o < H; ++o) { double s = b ? (*b)[o] : 0.0; for (int i = 0; i < H; ++i) s += W[(size_t)o * H + i] * x[i]; y[o] = s; }
+        return y;
+    };
+    const std::vector<double> qa = matvec(wq, win, nullptr), qb = matvec(wq, bin, &bq), ka = matvec(wk, win, nullptr), kb = matvec(wk, bin, &bk);
+    const std::vector<double> va = matvec(wv, win, nullptr), vb = matvec(wv, bin, &bv);
+    std::vector<float> hc(64, 0.f), G((size_t)H * 32, 0.f), zb(H, 0.f);
+    for (int h = 0; h < HEADS; ++h) {
+        double c1 = 0, c2 = 0, c3 = 0, c4 = 0, d1 = 0, d0 = 0, P1[4] = {0, 0, 0, 0}, P0[4] = {0, 0, 0, 0};
+        for (int ch = h * c; ch < (h + 1) * c; ++ch) {
+            c1 += qa[ch] * ka[ch]; c2 += qa[ch] * kb[ch]; c3 += qb[ch] * ka[ch]; c4 += qb[ch] * kb[ch];
+            d1 += qa[ch] * bpe[ch]; d0 += qb[ch] * bpe[ch];
+            for (int t = 0; t < 4; ++t) { P1[t] += wpe[(size_t)ch * 4 + t] * qa[ch]; P0[t] += wpe[(size_t)ch * 4 + t] * qb[ch]; }
+        }
+        float* o = hc.data() + h * 16;
+        o[0] = (float)c1; o[1] = (float)c2; o[2] = (float)c3; o[3] = (float)c4;
+        for (int t = 0; t < 4; ++t) { o[4 + t] = (float)P1[t]; o[8 + t] = (float)P0[t]; }
+        o[12] = (float)d1; o[13] = (float)d0;
+    }
+    for (int o = 0; o < H; ++o) {
+        double cst = bl[o] + bin[o];
+        for (int h = 0; h < HEADS; ++h) {
+            double sv = 0, sp[4] = {0, 0, 0, 0};
+            for (int ch = h * c; ch < (h + 1) * c; ++ch) {
+                const double w = wl[(size_t)o * H + ch];
+                sv += w * va[ch];
+                for (int t = 0; t < 4; ++t) sp[t] += w * wvpe[(size_t)ch * 4 + t];
+                cst += w * (vb[ch] + bvpe[ch]);
+            }
+            G[(size_t)o * 32 + h] = (float)sv;
+            for (int t = 0; t < 4; ++t) G[(size_t)o * 32 + 4 + 4 * h + t] = (float)sp[t];
+        }
+        G[(size_t)o * 32 + 20] = (float)win[o];
+        G[(size_t)o * 32 + 21] = (float)cst;
+    }
+    E.first_consts = E.warena.get<float>(64 + (size_t)H * 32 + H);
+    if (E.warena.fail) return ROITR_ERR_ARG;
+    ROITR_HIP(hipMemcpy(E.first_consts, hc.data(), sizeof(float) * 64, hipMemcpyHostToDevice));
+    ROITR_HIP(hipMemcpy(E.first_consts + 64, G.data(), sizeof(float) * G.size(), hipMemcpyHostToDevice));
+    ROITR_HIP(hipMemcpy(E.first_consts + 64 + (size_t)H * 32, zb.data(), sizeof(float) * H, hipMemcpyHostToDevice));
+    return 0;
+}
 }  // namespace
 
 extern "C" void roitr_level_sizes(int n, int* out4)
@@ -638,6 +703,8 @@ extern "C" int roitr_engine_finalize(void* h, hipStream_t st)
         for (int b = 0; b < E.nblocks[l]; ++b) CHK(fold_local(E, E.enc[l][b], st));
         CHK(fold_local(E, E.dec[l], st));
     }
+    E.first_consts = nullptr;
+    CHK(build_local_first(E, E.enc[0][0], st));
     for (auto& L : E.geo) {
         if (L.cross) continue;
         L.wqkv = E.warena.get<float>((size_t)3 * C4 * C4);
@@ -889,6 +956,17 @@ extern "C" int roitr_engine_forward(void* h, const RoitrForwardIO* io, hipStream
             float* b = A.get<float>((size_t)V.T[l] * pl);
             if (A.fail) break;
             const int n_in = l == 0 ? T1 : V.T[l - 1];
+            if (l == 0 && E.first_consts && (K == 8 || K == 16)) {
+                // the first transformer of the network: scalar input feature -> rank-1 q | k | v (csrc/local_block.hip)
+                const LocalT& L0 = E.enc[0][0];
+                RoitrLocalFirst lf;
+                memset(&lf, 0, sizeof(lf));
+                lf.M = T1; lf.K = K; lf.x = xin; lf.group_idx = g_td[0]; lf.ppf = ppf_td[0]; lf.node_order = order[0];
+                lf.head_consts = E.first_consts; lf.G = E.first_consts + 64; lf.zero_bias = E.first_consts + 64 + 64 * 32;
+                lf.norm_w = L0.norm_w; lf.norm_b = L0.norm_b; lf.wout = L0.out_proj.w; lf.bout = L0.out_proj.b;
+                lf.scale = 1.0f / sqrtf((float)(L0.H / HEADS)); lf.eps = 1e-5f; lf.out = a;
+                CHK(roitr_local_first(&lf, st));
+            } else
             CHK(local_transformer(E, st, E.enc[l][0], n_in, xin, V.T[l], l == 0 ? nullptr : down[l], g_td[l], ppf_td[l], K, a, order[l]));
             CHK(tap(E, st, "enc" + std::to_string(l + 1) + ".0", a, sizeof(float) * (size_t)V.T[l] * pl));
             float* cur = a; float* nxt = b;

@@ -239,6 +239,7 @@ __global__ __launch_bounds__(256, R <= 20 ? 3 : 2) void mha_geo_kernel(RoitrMha 
     __shared__ __attribute__((aligned(16))) float sc[NH][NKP];    // scores -> probabilities [head][key]
     __shared__ __attribute__((aligned(16))) float sc2t[NKP * 4];   // diagonal-masked probabilities [key][head]
     __shared__ __attribute__((aligned(16))) float red[4][NH * C];  // per-wave ebar partials
+    __shared__ __attribute__((aligned(16))) float redh[4][C];      // per-wave hidden partials
     // XCD-aware row order: every XCD (private L2) gets a contiguous range of query rows, so the key / value rows of a cloud
     // are fetched into ONE L2 instead of all eight (PMC before: 1.27x the algorithmic bytes on the self layers)
     const int rowi = xcd_block_id(a.q_rows);
@@ -287,6 +288,14 @@ __global__ __launch_bounds__(256, R <= 20 ? 3 : 2) void mha_geo_kernel(RoitrMha 
         const float se = hl == 0 ? se0 : (hl == 1 ? se1 : (hl == 2 ? se2 : se3));
         if (j < nk && (lane & 15) == 0) sc[hl][j] = (sc[hl][j] + (se + qb)) * a.scale;
     }
+    // the first EB of this wave's value rows: in flight across the softmax (more would spill: the E rows stay in registers)
+    constexpr int EB = 4;
+    float4 vfirst[EB];
+#pragma unroll
+    for (int rr = 0; rr < EB; ++rr) {
+        const int j = wave + 4 * rr;
+        vfirst[rr] = reinterpret_cast<const float4*>(a.v + (size_t)(ks + (j < nk ? j : nk - 1)) * a.ldv)[lane];
+    }
     __syncthreads();
     // ---- softmax and the diagonal-masked softmax (geoattention.py:117-134) over the keys: wave = head
     {
@@ -316,21 +325,36 @@ __global__ __launch_bounds__(256, R <= 20 ? 3 : 2) void mha_geo_kernel(RoitrMha 
         }
     }
     __syncthreads();
-    // ---- hidden[ch] = sum_j p[head(ch)][j] v[j][ch]: thread = channel
+    // ---- hidden[ch] = sum_j p[head(ch)][j] v[j][ch].  Round 3: same key split as E (wave w owns keys w, w+4, ...; a lane the
+    // float4 of channels 4*lane.., whose head is its DPP row) -- the value rows arrive as R coalesced 1 KB loads per wave in
+    // a few batches, the first one requested BEFORE the softmax (above), instead of n/8 dependent batches of 8 strided scalar
+    // loads per thread (10 serial L2 round trips per query row: half of the kernel's time at n = 78); partial sums of the four
+    // waves meet in LDS like ebar's.
+    float4 hacc = make_float4(0.f, 0.f, 0.f, 0.f);
     {
-        const int h = tid >> 6;
-        const float* vp = a.v + (size_t)ks * a.ldv + tid;
-        float acc = 0.f;
-        int j = 0;
-        for (; j + 8 <= nk; j += 8) {   // 8 independent loads in flight
-            float vv[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) vv[u] = vp[(size_t)(j + u) * a.ldv];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) acc = fmaf(sc[h][j + u], vv[u], acc);
+        for (int rr = 0; rr < EB; ++rr) {
+            const int j = wave + 4 * rr;
+            const float p = j < nk ? sc[hl][j] : 0.f;
+            hacc.x = fmaf(p, vfirst[rr].x, hacc.x); hacc.y = fmaf(p, vfirst[rr].y, hacc.y); hacc.z = fmaf(p, vfirst[rr].z, hacc.z); hacc.w = fmaf(p, vfirst[rr].w, hacc.w);
         }
-        for (; j < nk; ++j) acc = fmaf(sc[h][j], vp[(size_t)j * a.ldv], acc);
-        a.out[(size_t)row * a.ldo + tid] = acc;
+        constexpr int CH = 8;   // rows per later batch (a real loop: unrolled, the compiler hoists every batch's loads and spills)
+#pragma unroll 1
+        for (int r0 = EB; r0 < R; r0 += CH) {
+            float4 vb[CH];
+#pragma unroll
+            for (int u = 0; u < CH; ++u) {
+                const int j = wave + 4 * (r0 + u);
+                vb[u] = reinterpret_cast<const float4*>(a.v + (size_t)(ks + (j < nk ? j : nk - 1)) * a.ldv)[lane];
+            }
+#pragma unroll
+            for (int u = 0; u < CH; ++u) {
+                const int j = wave + 4 * (r0 + u);
+                const float p = (r0 + u < R && j < nk) ? sc[hl][j] : 0.f;
+                hacc.x = fmaf(p, vb[u].x, hacc.x); hacc.y = fmaf(p, vb[u].y, hacc.y); hacc.z = fmaf(p, vb[u].z, hacc.z); hacc.w = fmaf(p, vb[u].w, hacc.w);
+            }
+        }
+        reinterpret_cast<float4*>(redh[wave])[lane] = hacc;
     }
     // ---- ebar[h][:] = sum_j p2[h][j] E[i][j][:]: this wave's rows out of registers, then the 4 waves through LDS
     float4 acc[NH];
@@ -349,6 +373,7 @@ __global__ __launch_bounds__(256, R <= 20 ? 3 : 2) void mha_geo_kernel(RoitrMha 
 #pragma unroll
     for (int h = 0; h < NH; ++h) reinterpret_cast<float4*>(red[wave])[h * 64 + lane] = acc[h];
     __syncthreads();
+    a.out[(size_t)row * a.ldo + tid] = (redh[0][tid] + redh[1][tid]) + (redh[2][tid] + redh[3][tid]);
 #pragma unroll
     for (int h = 0; h < NH; ++h)
         a.ebar[((size_t)row * NH + h) * C + tid] = (red[0][h * C + tid] + red[1][h * C + tid]) + (red[2][h * C + tid] + red[3][h * C + tid]);

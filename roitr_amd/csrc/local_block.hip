@@ -340,6 +340,123 @@ __global__ __launch_bounds__(256, K <= 8 ? 3 : 2) void local_block_kernel(RoitrL
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// The FIRST local transformer of the network (model/model.py:152,195: TransitionDown with stride 1, in_planes = 1).  Its input
+// feature is ONE scalar x_i per point (dataset/tdmatch.py:128-129 feeds ones, but nothing here relies on the value), so
+// in_proj(x) = x w + b and with it q, k, v are rank-1 affine in that scalar: q_i = x_i qa + qb, k_j = x_j ka + kb, v_j = x_j va + vb
+// with constant H-vectors.  A head's score is then a polynomial in scalars,
+//     q_h . k_hj + q_h . p_hj = x_i x_j c1 + x_i c2 + x_j c3 + c4 + (x_i P1 + P0) . ppf_j + x_i d1 + d0,
+// the attention output is affine in 5 numbers per head (S_h = sum_j a_hj x_j, pbar_h = sum_j a_hj ppf_j), and linear(att) + f_i is an
+// affine map G (H x 22) of g_i = [S (4), pbar (16), x_i, 1].  No q|k|v GEMM, no k / v row gathers (a neighbour contributes 4 + 16
+// bytes instead of 512), no in_proj launch: per node the kernel reads x, K indices, K neighbour scalars and the PPFs, forms g_i
+// (one thread per (node, head)), and finishes with the two on-chip GEMMs of the block kernel: z = G g -> LayerNorm -> out_proj.
+// Constants: RoitrLocalFirst (built by the engine at finalize in float64 from the layer's weights).
+template <int K>
+__global__ __launch_bounds__(256) void local_first_kernel(RoitrLocalFirst a)
+{
+    constexpr int H = 64, TM = 64, AP = H + 4, HV = 1;
+    __shared__ __attribute__((aligned(16))) float R1[TM * AP];   // LayerNorm-ed y image
+    __shared__ __attribute__((aligned(16))) float R2[TM * AP];   // g rows (32 columns used) -> row-major staging of the epilogues
+    __shared__ __attribute__((aligned(16))) float WS[H * WP];
+    __shared__ int ids[TM];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ntiles = (a.M + TM - 1) / TM;
+    const int tile = xcd_block_id(ntiles);
+    if (tile >= ntiles) return;
+    const int s0 = tile * TM;
+    if (tid < TM) {
+        const int sl = s0 + tid < a.M ? s0 + tid : s0;
+        ids[tid] = a.node_order ? __float_as_int(reinterpret_cast<const float4*>(a.node_order)[sl].w) : sl;
+    }
+    __syncthreads();
+    {   // ---- g rows: thread = (node, head)
+        const int row = tid >> 2, h = tid & 3;
+        const int node = ids[row];
+        const float xi = a.x[node];
+        int gi[K];
+        const int4* gp = reinterpret_cast<const int4*>(a.group_idx + (size_t)node * K);
+#pragma unroll
+        for (int q4 = 0; q4 < K / 4; ++q4) { const int4 t = gp[q4]; gi[4 * q4] = t.x; gi[4 * q4 + 1] = t.y; gi[4 * q4 + 2] = t.z; gi[4 * q4 + 3] = t.w; }
+        float4 pf[K]; float xj[K];
+#pragma unroll
+        for (int kk = 0; kk < K; ++kk) { pf[kk] = reinterpret_cast<const float4*>(a.ppf)[(size_t)node * K + kk]; xj[kk] = a.x[gi[kk]]; }
+        const float* hc = a.head_consts + h * 16;      // c1 c2 c3 c4 | P1[4] | P0[4] | d1 d0 | pad
+        const float c1 = hc[0], c2 = hc[1], c3 = hc[2], c4 = hc[3], d1 = hc[12], d0 = hc[13];
+        const float p0 = fmaf(xi, hc[4], hc[8]), p1 = fmaf(xi, hc[5], hc[9]), p2 = fmaf(xi, hc[6], hc[10]), p3 = fmaf(xi, hc[7], hc[11]);
+        const float base = fmaf(xi, c2 + d1, c4 + d0), slope = fmaf(xi, c1, c3);
+        float sc[K];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kk = 0; kk < K; ++kk) {
+            float d = fmaf(slope, xj[kk], base);
+            d = fmaf(p0, pf[kk].x, d); d = fmaf(p1, pf[kk].y, d); d = fmaf(p2, pf[kk].z, d); d = fmaf(p3, pf[kk].w, d);
+            sc[kk] = d * a.scale;
+            mx = fmaxf(mx, sc[kk]);
+        }
+        float sum = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < K; ++kk) { sc[kk] = __expf(sc[kk] - mx); sum += sc[kk]; }
+        const float inv = 1.0f / sum;
+        float S = 0.f;
+        float4 pb = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int kk = 0; kk < K; ++kk) {
+            const float p = sc[kk] * inv;
+            S = fmaf(p, xj[kk], S);
+            pb.x = fmaf(p, pf[kk].x, pb.x); pb.y = fmaf(p, pf[kk].y, pb.y); pb.z = fmaf(p, pf[kk].z, pb.z); pb.w = fmaf(p, pf[kk].w, pb.w);
+        }
+        float* g = R2 + row * AP;
+        g[h] = S;
+        *reinterpret_cast<float4*>(g + 4 + 4 * h) = pb;
+        if (h == 0) {
+            g[20] = xi; g[21] = 1.0f;
+            *reinterpret_cast<float2*>(g + 22) = make_float2(0.f, 0.f);
+            *reinterpret_cast<float4*>(g + 24) = make_float4(0.f, 0.f, 0.f, 0.f);
+            *reinterpret_cast<float4*>(g + 28) = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    const int r0 = (wave >> 1) * 32, c0 = (wave & 1) * 32;
+    Acc acc;
+    // ---- z = G g (K = 32, the bias rides in column 21) -> LayerNorm -> y
+    acc_zero(acc);
+    gemm_phase<H, AP>(acc, R2, 32, a.G, 32, 0, WS, r0, c0, tid);
+    __syncthreads();
+    acc_store<AP>(acc, a.zero_bias, R2, r0, c0, lane);
+    __syncthreads();
+    {
+        const int lr = lane >> 4, lc = lane & 15;
+        const float4 gam = reinterpret_cast<const float4*>(a.norm_w)[lc], bet = reinterpret_cast<const float4*>(a.norm_b)[lc];
+#pragma unroll
+        for (int u = 0; u < TM / 16; ++u) {
+            const int rl = (u * 4 + wave) * 4 + lr;
+            const float4 t = *reinterpret_cast<const float4*>(R2 + rl * AP + 4 * lc);
+            const float mean = row_allsum((t.x + t.y) + (t.z + t.w)) / (float)H;
+            const float dx = t.x - mean, dy = t.y - mean, dz = t.z - mean, dw = t.w - mean;
+            const float rstd = 1.0f / sqrtf(row_allsum((dx * dx + dy * dy) + (dz * dz + dw * dw)) / (float)H + a.eps);
+            float4 y;
+            y.x = dx * rstd * gam.x + bet.x; y.y = dy * rstd * gam.y + bet.y; y.z = dz * rstd * gam.z + bet.z; y.w = dw * rstd * gam.w + bet.w;
+            *reinterpret_cast<float4*>(R1 + rl * AP + 4 * lc) = y;
+        }
+    }
+    // ---- out = y Wout^T + bout
+    acc_zero(acc);
+    gemm_phase<H, AP>(acc, R1, H, a.wout, H, 0, WS, r0, c0, tid);
+    __syncthreads();
+    acc_store<AP>(acc, a.bout, R2, r0, c0, lane);
+    __syncthreads();
+    {
+        const int lr = lane >> 4, lc = lane & 15;
+#pragma unroll
+        for (int u = 0; u < TM / 16; ++u) {
+            const int rl = (u * 4 + wave) * 4 + lr;
+            if (s0 + rl < a.M)
+                *reinterpret_cast<float4*>(a.out + (size_t)ids[rl] * H + 4 * lc) = *reinterpret_cast<const float4*>(R2 + rl * AP + 4 * lc);
+        }
+    }
+    (void)HV;
+}
+
 }  // namespace
 
 extern "C" int roitr_local_block_supported(int H, int K)
@@ -388,6 +505,25 @@ extern "C" int roitr_local_block(const RoitrLocalBlock* a, hipStream_t stream)
         if (a->K == 8) local_block_kernel<128, 8, 32><<<grid, 256, 0, stream>>>(*a);
         else local_block_kernel<128, 16, 32><<<grid, 256, 0, stream>>>(*a);
     }
+    roitr_prof_end(ROITR_PROF_LOCAL_BLOCK, stream);
+    ROITR_LAUNCH_CHECK();
+    return ROITR_OK;
+}
+
+extern "C" int roitr_local_first(const RoitrLocalFirst* a, hipStream_t stream)
+{
+    if (a->M <= 0) return ROITR_OK;
+    if (a->K != 8 && a->K != 16) return ROITR_ERR_UNSUPPORTED;
+    if ((((uintptr_t)a->group_idx | (uintptr_t)a->ppf | (uintptr_t)a->out | (uintptr_t)a->G | (uintptr_t)a->wout | (uintptr_t)a->norm_w |
+          (uintptr_t)a->norm_b | (uintptr_t)a->head_consts) & 15) != 0) {
+        roitr_set_error("roitr_local_first: operands must be 16-byte aligned", __FILE__, __LINE__);
+        return ROITR_ERR_ARG;
+    }
+    // algorithmic bytes: x, K indices, K neighbour scalars (4 B each), the PPFs, one row out; FLOPs of the two on-chip GEMMs in aux
+    roitr_prof_begin2(ROITR_PROF_LOCAL_BLOCK, (double)a->M * (4.0 + a->K * (4.0 + 4.0 + 16.0) + 64.0 * 4), 2.0 * a->M * 64.0 * (32.0 + 64.0), stream);
+    const int grid = xcd_grid(div_up(a->M, 64));
+    if (a->K == 8) local_first_kernel<8><<<grid, 256, 0, stream>>>(*a);
+    else local_first_kernel<16><<<grid, 256, 0, stream>>>(*a);
     roitr_prof_end(ROITR_PROF_LOCAL_BLOCK, stream);
     ROITR_LAUNCH_CHECK();
     return ROITR_OK;
