@@ -232,6 +232,29 @@ __global__ __launch_bounds__(256) void mha_kernel(RoitrMha a)
 // launch at 128 pairs against 0.3-0.4 ms for one pass over E at HBM speed.
 __device__ __forceinline__ float dot4(const float4 a, const float4 b) { return fmaf(a.w, b.w, fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x))); }
 
+// Sum 16 values per lane over the 16 lanes of a DPP row "transposed": lane i ends with the row total of ONE value,
+//     value index  row16_slot(i) = (bit2(i) << 3) | (bit0(i) << 2) | (bit1(i) << 1) | bit3(i),
+// in 15 exchange-and-add steps (8 + 4 + 2 + 1) instead of 16 x 4: a lane keeps the half of its values that matches one of its
+// lane bits and receives the partner's partial sums for that half.  The first exchange uses row_half_mirror (partner = lane ^ 7:
+// nothing is resolved yet, any partner with the other bit 2 will do), then quad_perm lane ^ 1, lane ^ 2 and row_ror:8 (lane ^ 8).
+template <int CTRL> __device__ __forceinline__ float dpp_get(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ int row16_slot(int i) { return ((i >> 2) & 1) << 3 | (i & 1) << 2 | ((i >> 1) & 1) << 1 | ((i >> 3) & 1); }
+__device__ __forceinline__ float row16_transpose_sum(const float (&v)[16], int lane)
+{
+    const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4, b3 = lane & 8;
+    float w[8], u[4], t[2];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) w[m] = (b2 ? v[8 + m] : v[m]) + dpp_get<0x141>(b2 ? v[m] : v[8 + m]);   // row_half_mirror
+#pragma unroll
+    for (int m = 0; m < 4; ++m) u[m] = (b0 ? w[4 + m] : w[m]) + dpp_get<0xB1>(b0 ? w[m] : w[4 + m]);    // quad_perm [1,0,3,2]
+#pragma unroll
+    for (int m = 0; m < 2; ++m) t[m] = (b1 ? u[2 + m] : u[m]) + dpp_get<0x4E>(b1 ? u[m] : u[2 + m]);    // quad_perm [2,3,0,1]
+    return (b3 ? t[1] : t[0]) + dpp_get<0x128>(b3 ? t[0] : t[1]);                                        // row_ror:8
+}
+
 template <int R>   // R = key rows per wave kept in registers: n <= 4 R
 __global__ __launch_bounds__(256, R <= 20 ? 3 : 2) void mha_geo_kernel(RoitrMha a)
 {
@@ -261,7 +284,9 @@ __global__ __launch_bounds__(256, R <= 20 ? 3 : 2) void mha_geo_kernel(RoitrMha 
 #pragma unroll
     for (int h = 0; h < NH; ++h) qt4[h] = reinterpret_cast<const float4*>(a.qt + ((size_t)row * NH + h) * C)[lane];
     const float qb = row_allsum(dot4(qv, reinterpret_cast<const float4*>(a.bp)[lane]));   // q_h . bp_h, h = this lane's row
-    // ---- scores, part 1 (while the E rows are in flight): q_h . k_j from L2-resident key rows, 5 rows per batch
+    // ---- scores, part 1 (while the E rows are in flight): q_h . k_j from L2-resident key rows, 5 rows per batch; after the
+    // 16-lane reduction every lane of DPP row h holds the head-h value of the key row
+    float s1v[R];
 #pragma unroll
     for (int r0 = 0; r0 < R; r0 += 5) {
         float4 kv[5];
@@ -271,22 +296,36 @@ __global__ __launch_bounds__(256, R <= 20 ? 3 : 2) void mha_geo_kernel(RoitrMha 
             kv[u] = reinterpret_cast<const float4*>(a.k + (size_t)(ks + (j < nk ? j : nk - 1)) * a.ldk)[lane];
         }
 #pragma unroll
-        for (int u = 0; u < 5; ++u) {
-            if (r0 + u < R) {
-                const int j = wave + 4 * (r0 + u);
-                const float s1 = row_allsum(dot4(qv, kv[u]));
-                if (j < nk && (lane & 15) == 0) sc[hl][j] = s1;
+        for (int u = 0; u < 5; ++u)
+            if (r0 + u < R) s1v[r0 + u] = row_allsum(dot4(qv, kv[u]));
+    }
+    // ---- scores, part 2: + q~_h . E_ij + q_h . bp_h.  Round 3: the 4 heads x 4 key rows = 16 wave-wide dot products of a group of
+    // rows are reduced TOGETHER (row16_transpose_sum inside the DPP rows, then two cross-row adds) instead of one 64-lane
+    // reduction each -- the kernel was bound by exactly those (SQ pass of round 2: 391 v_add_dpp + 569 hazard nops per wave against
+    // 660 FMAs).  The first lane of DPP row h feeds the head-h terms that do not involve E (q_h . k_j + q_h . bp_h) into the same sum.
+    static_assert(R % 4 == 0, "key rows per wave come in groups of four");
+    {
+        const int i16 = lane & 15;
+        const bool feeder = i16 == 0;                         // lane 16 h: DPP row h
+#pragma unroll
+        for (int g4 = 0; g4 < R / 4; ++g4) {
+            float v[16];
+#pragma unroll
+            for (int h = 0; h < NH; ++h)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float d = dot4(qt4[h], e[4 * g4 + r]);
+                    if (feeder && hl == h) d += s1v[4 * g4 + r] + qb;
+                    v[h * 4 + r] = d;
+                }
+            float tot = row16_transpose_sum(v, lane);
+            tot += __shfl_xor(tot, 16, 64);
+            tot += __shfl_xor(tot, 32, 64);
+            if (lane < 16) {
+                const int slot = row16_slot(i16), h = slot >> 2, j = wave + 4 * (4 * g4 + (slot & 3));
+                if (j < nk) sc[h][j] = tot * a.scale;
             }
         }
-    }
-    // ---- scores, part 2: + q~_h . E_ij + q_h . bp_h  (same lane re-reads its own LDS word: no barrier needed)
-#pragma unroll
-    for (int rr = 0; rr < R; ++rr) {
-        const int j = wave + 4 * rr;
-        const float se0 = wave_sum(dot4(qt4[0], e[rr])), se1 = wave_sum(dot4(qt4[1], e[rr]));
-        const float se2 = wave_sum(dot4(qt4[2], e[rr])), se3 = wave_sum(dot4(qt4[3], e[rr]));
-        const float se = hl == 0 ? se0 : (hl == 1 ? se1 : (hl == 2 ? se2 : se3));
-        if (j < nk && (lane & 15) == 0) sc[hl][j] = (sc[hl][j] + (se + qb)) * a.scale;
     }
     // the first EB of this wave's value rows: in flight across the softmax (more would spill: the E rows stay in registers)
     constexpr int EB = 4;

@@ -111,10 +111,11 @@ __device__ __forceinline__ void acc_store(const Acc& acc, const float* __restric
 
 // DBG (tuning only, scripts/bench_local_block.py): 0 = the kernel; 1 = without the attention phase; 2 = attention only
 template <int H, int K, int TM, int DBG = 0>
-__global__ __launch_bounds__(256, 3) void local_block_kernel(RoitrLocalBlock a)
+__global__ __launch_bounds__(256, K <= 8 ? 3 : 2) void local_block_kernel(RoitrLocalBlock a)
 {
     constexpr int AP = H + 4;                 // activation image pitch
     constexpr int LPN = H / 4;                // lanes per node in the attention
+    constexpr int NPW = 64 / LPN;             // nodes per wave at a time
     constexpr int HL = LPN / 4;               // lanes per head
     constexpr int HV = H / 64;                // row elements per lane in the LayerNorm passes
     __shared__ __attribute__((aligned(16))) float R1[TM * AP];   // x image, later the LayerNorm-ed y image
@@ -155,41 +156,37 @@ __global__ __launch_bounds__(256, 3) void local_block_kernel(RoitrLocalBlock a)
     if (DBG != 2) gemm_phase<H, AP>(acc, R1, H, a.wq, H, 0, WS, r0, c0, tid);
     acc_store<AP>(acc, a.bq, R2, r0, c0, lane);
     __syncthreads();
-    // ---- P2: attention, in place on R2 (a wave touches only the rows of its own nodes).
-    // SPL lane groups share a node's K neighbours (K = 16: two groups of 8 -- a lane then keeps 8 key and 8 value rows in flight
-    // like at K = 8, one memory round trip per round and 3 waves per SIMD, instead of 16 + 16 rows in two trips at 2 waves); the
-    // groups meet in the softmax statistics and the weighted sums through lane ^ (64 / SPL .. ) exchanges.
+    // ---- P2: attention, in place on R2 (a wave touches only the rows of its own nodes)
     if (DBG != 1) {
-        constexpr int SPL = K > 8 ? 2 : 1;                     // lane groups per node
-        constexpr int KL = K / SPL;                            // neighbours per lane
-        constexpr int LN_ = LPN * SPL;                         // lanes per node
-        constexpr int NPR = 64 / LN_;                          // nodes per wave and round
-        static_assert(LN_ <= 64 && 64 % LN_ == 0, "lane layout");
-        const int ns = lane / LN_, grp = (lane / LPN) % SPL, j = lane % LPN, jq = j % HL;
+        const int ns = lane / LPN, j = lane % LPN, jq = j % HL;
         const int t4 = jq & 3;                                    // PPF component this lane carries
-        constexpr int NRD = TM / (4 * NPR);
-        int gi[KL]; float pv[KL];
-        auto load_ids = [&](int rd_, int (&g_)[KL], float (&p_)[KL]) {
-            const int node_ = ids[(rd_ * 4 + wave) * NPR + ns];
-            const int4* gp = reinterpret_cast<const int4*>(a.group_idx + (size_t)node_ * K + grp * KL);
+        constexpr int NRD = TM / (4 * NPW);
+        int gi[K]; float pv[K];
+        auto load_ids = [&](int rd_, int (&g_)[K], float (&p_)[K]) {
+            const int node_ = ids[(rd_ * 4 + wave) * NPW + ns];
+            const int4* gp = reinterpret_cast<const int4*>(a.group_idx + (size_t)node_ * K);
 #pragma unroll
-            for (int q4 = 0; q4 < KL / 4; ++q4) { const int4 t = gp[q4]; g_[4 * q4] = t.x; g_[4 * q4 + 1] = t.y; g_[4 * q4 + 2] = t.z; g_[4 * q4 + 3] = t.w; }
-            const float* pf = a.ppf + ((size_t)node_ * K + grp * KL) * 4 + t4;
+            for (int q4 = 0; q4 < K / 4; ++q4) { const int4 t = gp[q4]; g_[4 * q4] = t.x; g_[4 * q4 + 1] = t.y; g_[4 * q4 + 2] = t.z; g_[4 * q4 + 3] = t.w; }
+            const float* pf = a.ppf + (size_t)node_ * K * 4 + t4;
 #pragma unroll
-            for (int kk = 0; kk < KL; ++kk) p_[kk] = pf[kk * 4];
+            for (int kk = 0; kk < K; ++kk) p_[kk] = pf[kk * 4];
         };
-        // exchange with the lane that holds the other neighbour group of the same node and channels (SPL = 2: lane ^ LPN)
-        auto other = [&](float v) { return SPL == 1 ? v : __shfl_xor(v, LPN, 64); };
         load_ids(0, gi, pv);
         for (int rd = 0; rd < NRD; ++rd) {
-            const int row = (rd * 4 + wave) * NPR + ns;            // tile row of this lane's node
-            // one round trip per round: the key AND value rows of this lane's neighbours, the next round's indices / PPFs behind them
-            float4 kr[KL], vr[KL];
+            const int row = (rd * 4 + wave) * NPW + ns;            // tile row of this lane's node
+            // one round trip per round: the key AND value rows of the K neighbours, and the next round's indices / PPFs behind them
+            // (K = 16: the value rows follow the scores instead -- 64 more registers in flight would halve the occupancy.  Measured
+            //  and dropped for K = 16: the neighbours split over two lane groups of a node, 8 key + 8 value rows per lane in one
+            //  trip at 3 waves per SIMD, joined by five lane ^ 32 exchanges per round: 4.41 vs 4.20 ms per level-2 launch)
+            constexpr bool V_EARLY = K <= 8;
+            float4 kr[K], vr[K];
 #pragma unroll
-            for (int kk = 0; kk < KL; ++kk) kr[kk] = *reinterpret_cast<const float4*>(a.kv + (size_t)gi[kk] * (2 * H) + 4 * j);
+            for (int kk = 0; kk < K; ++kk) kr[kk] = *reinterpret_cast<const float4*>(a.kv + (size_t)gi[kk] * (2 * H) + 4 * j);
+            if (V_EARLY) {
 #pragma unroll
-            for (int kk = 0; kk < KL; ++kk) vr[kk] = *reinterpret_cast<const float4*>(a.kv + (size_t)gi[kk] * (2 * H) + H + 4 * j);
-            int gn[KL]; float pn[KL];
+                for (int kk = 0; kk < K; ++kk) vr[kk] = *reinterpret_cast<const float4*>(a.kv + (size_t)gi[kk] * (2 * H) + H + 4 * j);
+            }
+            int gn[K]; float pn[K];
             if (rd + 1 < NRD) load_ids(rd + 1, gn, pn);
             // per-lane constants of the folded positional branch (L1-resident; not kept across rounds: registers)
             float4 wpe4[4]; float bpe4[4];
@@ -212,31 +209,32 @@ __global__ __launch_bounds__(256, 3) void local_block_kernel(RoitrLocalBlock a)
                 c4 = jq == 0 ? p4 * a.scale : 0.f;
             }
             qv.x *= a.scale; qv.y *= a.scale; qv.z *= a.scale; qv.w *= a.scale;
-            float sc[KL];
+            float sc[K];
             float mx = -INFINITY;
 #pragma unroll
-            for (int kk = 0; kk < KL; ++kk) {
+            for (int kk = 0; kk < K; ++kk) {
                 float d = fmaf(ec, pv[kk], c4);
                 d = fmaf(qv.x, kr[kk].x, d); d = fmaf(qv.y, kr[kk].y, d); d = fmaf(qv.z, kr[kk].z, d); d = fmaf(qv.w, kr[kk].w, d);
                 d = head_allsum<HL>(d);
                 sc[kk] = d;
                 mx = fmaxf(mx, d);
             }
-            mx = fmaxf(mx, other(mx));                               // the softmax runs over all K neighbours
+            if (!V_EARLY) {
+#pragma unroll
+                for (int kk = 0; kk < K; ++kk) vr[kk] = *reinterpret_cast<const float4*>(a.kv + (size_t)gi[kk] * (2 * H) + H + 4 * j);
+            }
             float sum = 0.f;
 #pragma unroll
-            for (int kk = 0; kk < KL; ++kk) { sc[kk] = __expf(sc[kk] - mx); sum += sc[kk]; }   // arguments in [-inf, 0]: v_exp_f32 is good to ~1e-6 relative here
-            sum += other(sum);
+            for (int kk = 0; kk < K; ++kk) { sc[kk] = __expf(sc[kk] - mx); sum += sc[kk]; }   // arguments in [-inf, 0]: v_exp_f32 is good to ~1e-6 relative here
             float pb = 0.f;
             float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
             const float inv = 1.0f / sum;
 #pragma unroll
-            for (int kk = 0; kk < KL; ++kk) {
+            for (int kk = 0; kk < K; ++kk) {
                 const float p = sc[kk] * inv;
                 pb = fmaf(p, pv[kk], pb);                          // pbar[h][t4]: every quad of the head holds its own copy
                 o.x = fmaf(p, vr[kk].x, o.x); o.y = fmaf(p, vr[kk].y, o.y); o.z = fmaf(p, vr[kk].z, o.z); o.w = fmaf(p, vr[kk].w, o.w);
             }
-            if (SPL > 1) { pb += other(pb); o.x += other(o.x); o.y += other(o.y); o.z += other(o.z); o.w += other(o.w); }
             const float b0 = dpp_mov<0x00>(pb), b1 = dpp_mov<0x55>(pb), b2 = dpp_mov<0xAA>(pb), b3 = dpp_mov<0xFF>(pb);   // quad broadcasts
             const float4 bias = *reinterpret_cast<const float4*>(a.bvpe + 4 * j);
             const float4 w0 = reinterpret_cast<const float4*>(a.wvpe)[4 * j], w1 = reinterpret_cast<const float4*>(a.wvpe)[4 * j + 1];
@@ -245,10 +243,10 @@ __global__ __launch_bounds__(256, 3) void local_block_kernel(RoitrLocalBlock a)
             o.y += w1.x * b0 + w1.y * b1 + w1.z * b2 + w1.w * b3 + bias.y;
             o.z += w2.x * b0 + w2.y * b1 + w2.z * b2 + w2.w * b3 + bias.z;
             o.w += w3.x * b0 + w3.y * b1 + w3.z * b2 + w3.w * b3 + bias.w;
-            if (grp == 0) *reinterpret_cast<float4*>(R2 + row * AP + 4 * j) = o;
+            *reinterpret_cast<float4*>(R2 + row * AP + 4 * j) = o;
             if (rd + 1 < NRD) {
 #pragma unroll
-                for (int kk = 0; kk < KL; ++kk) { gi[kk] = gn[kk]; pv[kk] = pn[kk]; }
+                for (int kk = 0; kk < K; ++kk) { gi[kk] = gn[kk]; pv[kk] = pn[kk]; }
             }
         }
     }
