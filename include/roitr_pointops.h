@@ -60,6 +60,14 @@ void aggregation_backward_cuda_launcher(int n, int nsample, int c, int w_c, cons
 
 int roitr_furthestsampling(int b, int n_max, const float* xyz, const int* offset, const int* new_offset, float* tmp,
                            int* idx, roitr_stream_t stream);
+/* The sampling chain of a hierarchy (model/model.py:56-64 called level after level): the next level samples THIS level's picks in
+ * pick order from the same first point, so while every arg-max among this level's first m / track_div picks was attained by
+ * exactly one point, the next level's result is the prefix 0 .. m'-1 of those picks (csrc/pointops_fps.hip).  tie_out (b ints,
+ * device; optional) receives per cloud the first pick index with a shared arg-max (INT_MAX: none in the tracked range);
+ * prev_tie (optional) = the tie_out of the call whose picks this call samples: covered clouds are answered with the prefix
+ * without running the chain, the others run it.  Results are bit-identical to roitr_furthestsampling either way. */
+int roitr_furthestsampling_ex(int b, int n_max, const float* xyz, const int* offset, const int* new_offset, float* tmp, int* idx,
+                              const int* prev_tie, int* tie_out, int track_div, roitr_stream_t stream);
 
 /* Workspace for roitr_knn_build_grid / roitr_knnquery_ex: b clouds, n reference points, at most m queries. */
 size_t roitr_knn_workspace_bytes(int b, int n, int m);

@@ -895,6 +895,7 @@ extern "C" int roitr_engine_forward(void* h, const RoitrForwardIO* io, hipStream
     }
     {
         float* fps_tmp = A.get<float>(T1);
+        int* fps_tie[4] = {nullptr, A.get<int>(NC), A.get<int>(NC), nullptr};   // per cloud: first pick with a shared arg-max
         for (int l = 1; l < 4; ++l) {
             down[l] = A.get<int>(V.T[l]);
             p[l] = A.get<float>((size_t)V.T[l] * 3);
@@ -907,7 +908,10 @@ extern "C" int roitr_engine_forward(void* h, const RoitrForwardIO* io, hipStream
             // tmp = 1e10 (functions/pointops.py:22)
             ROITR_HIP(hipMemsetD32Async((hipDeviceptr_t)fps_tmp, 0x501502F9 /* bits of 1e10f */, V.T[l - 1], E.side));
             roitr_prof_next_bytes(ROITR_PROF_FPS, 12.0 * V.T[l - 1] + 4.0 * V.T[l] + 8.0 * V.T[l - 1]);
-            CHK(roitr_furthestsampling(NC, V.nmax[l - 1], p[l - 1], D.off[l - 1], D.off[l], fps_tmp, down[l], E.side));
+            // levels 2 and 3 sample the previous level's picks in pick order: answered with the prefix while no arg-max was
+            // shared (pointops_fps.hip), the serial chain of 312 + 78 dependent iterations otherwise
+            CHK(roitr_furthestsampling_ex(NC, V.nmax[l - 1], p[l - 1], D.off[l - 1], D.off[l], fps_tmp, down[l], l > 1 ? fps_tie[l - 1] : nullptr,
+                                          l < 3 ? fps_tie[l] : nullptr, 4, E.side));
             CHK(roitr_gather_rows(V.T[l], 3, p[l - 1], down[l], 0, (float*)p[l], E.side));
             CHK(roitr_gather_rows(V.T[l], 3, nrm[l - 1], down[l], 0, (float*)nrm[l], E.side));
             ROITR_HIP(hipEventRecord(E.ev[l], E.side));

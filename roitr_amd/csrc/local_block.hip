@@ -14,8 +14,8 @@
 //
 // Matrix work: v_mfma_f32_16x16x4_f32 (exact fp32 FMA chains, the fp32 vector rate).  A wave owns a 32 x 32 region = 2 x 2 tiles
 // of the TM x H output (TM = 64 at H = 64: 2 x 2 regions; TM = 32 at H = 128: 1 x 4 regions).  Activation images live row-major in
-// LDS (pitch H + 4 floats: the 16 rows a ds_read_b128 fragment load touches fall on 16 different 16-byte slots); weights stream
-// through a (H rows x 32 k) slab, row-major with pitch 36.  Lane (i = l & 15, g = l >> 4) reads ONE float4 = k 16c+4g .. +3 of its row
+// LDS (pitch H + 4 floats: the 16 rows a ds_read_b128 fragment load touches fall on 16 different 16-byte slots); the weight
+// fragments of a wave's 32 output columns come straight from L1 / L2 into registers (no LDS staging).  Lane (i = l & 15, g = l >> 4) reads ONE float4 = k 16c+4g .. +3 of its row
 // per operand and 16-k chunk and feeds component s to the s-th MFMA of the chunk: the MFMA sums k over g, the four steps over s --
 // every k once, A and B agreeing by construction.  A row's result depends on its own operands only, in a fixed order: a node's
 // output does not depend on the tile or batch it is in.
@@ -31,7 +31,6 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int WP = 36;   // weight-slab pitch (floats): 32 k + 4
 
 template <int CTRL> __device__ __forceinline__ float dpp_mov(float v)
 {
@@ -56,33 +55,37 @@ __device__ __forceinline__ void acc_zero(Acc& a)
         for (int n = 0; n < 2; ++n) a.t[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 }
 
-// acc += A[r0 .. r0+31][0 .. Ka) @ W[c0 .. c0+31][k_w0 .. k_w0 + Ka)^T for this wave's region; all 256 threads stage the slabs.
-// A: LDS image (pitch AP); W: global (H rows, leading dimension ldw).
+// acc += A[r0 .. r0+31][0 .. Ka) @ W[c0 .. c0+31][k_w0 .. k_w0 + Ka)^T for this wave's region.
+// A: LDS image (pitch AP), complete before the call (the caller's barrier).  W: global (H rows, leading dimension ldw); a wave's
+// B fragments -- 16-byte pieces of ITS 32 weight rows -- come straight from L1 / L2 into registers, one 32-k slab ahead of the
+// MFMAs: no LDS staging, no barrier inside a phase (round 3: staging every slab through LDS with two barriers each held the
+// on-chip GEMMs at 58 TFLOP/s at H = 128, where a 32-row tile re-streams all 256 KB of weights).
 template <int H, int AP>
 __device__ __forceinline__ void gemm_phase(Acc& acc, const float* __restrict__ A, int Ka, const float* __restrict__ W, int ldw, int k_w0,
-                                           float* __restrict__ WS, int r0, int c0, int tid)
+                                           int r0, int c0, int tid)
 {
-    constexpr int NL = H / 32;                 // float4 loads per thread and slab (H rows x 8 float4)
     const int lane = tid & 63, i = lane & 15, g = lane >> 4;
-    const int srow = tid >> 3, scol = (tid & 7) * 4;
-    float4 wreg[NL];
+    const float* w0 = W + (size_t)(c0 + i) * ldw + k_w0 + 4 * g;
+    const float* w1 = W + (size_t)(c0 + 16 + i) * ldw + k_w0 + 4 * g;
+    float4 bn[2][2];
 #pragma unroll
-    for (int j = 0; j < NL; ++j) wreg[j] = *reinterpret_cast<const float4*>(W + (size_t)(srow + 32 * j) * ldw + k_w0 + scol);
+    for (int c = 0; c < 2; ++c) { bn[c][0] = *reinterpret_cast<const float4*>(w0 + 16 * c); bn[c][1] = *reinterpret_cast<const float4*>(w1 + 16 * c); }
     for (int k0 = 0; k0 < Ka; k0 += 32) {
-        __syncthreads();                        // every wave is done with the previous slab
+        float4 bc[2][2];
 #pragma unroll
-        for (int j = 0; j < NL; ++j) *reinterpret_cast<float4*>(WS + (srow + 32 * j) * WP + scol) = wreg[j];
-        __syncthreads();
+        for (int c = 0; c < 2; ++c) { bc[c][0] = bn[c][0]; bc[c][1] = bn[c][1]; }
         if (k0 + 32 < Ka) {
 #pragma unroll
-            for (int j = 0; j < NL; ++j) wreg[j] = *reinterpret_cast<const float4*>(W + (size_t)(srow + 32 * j) * ldw + k_w0 + k0 + 32 + scol);
+            for (int c = 0; c < 2; ++c) {
+                bn[c][0] = *reinterpret_cast<const float4*>(w0 + k0 + 32 + 16 * c);
+                bn[c][1] = *reinterpret_cast<const float4*>(w1 + k0 + 32 + 16 * c);
+            }
         }
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
             const float4 a0 = *reinterpret_cast<const float4*>(A + (r0 + i) * AP + k0 + 16 * c + 4 * g);
             const float4 a1 = *reinterpret_cast<const float4*>(A + (r0 + 16 + i) * AP + k0 + 16 * c + 4 * g);
-            const float4 b0 = *reinterpret_cast<const float4*>(WS + (c0 + i) * WP + 16 * c + 4 * g);
-            const float4 b1 = *reinterpret_cast<const float4*>(WS + (c0 + 16 + i) * WP + 16 * c + 4 * g);
+            const float4 b0 = bc[c][0], b1 = bc[c][1];
 #define LB_STEP(S)                                                                                        \
             acc.t[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.S, b0.S, acc.t[0][0], 0, 0, 0);          \
             acc.t[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.S, b1.S, acc.t[0][1], 0, 0, 0);          \
@@ -120,7 +123,6 @@ __global__ __launch_bounds__(256, K <= 8 ? 3 : 2) void local_block_kernel(RoitrL
     constexpr int HV = H / 64;                // row elements per lane in the LayerNorm passes
     __shared__ __attribute__((aligned(16))) float R1[TM * AP];   // x image, later the LayerNorm-ed y image
     __shared__ __attribute__((aligned(16))) float R2[TM * AP];   // q rows -> attention rows -> row-major staging of the two epilogues
-    __shared__ __attribute__((aligned(16))) float WS[H * WP];
     __shared__ int ids[TM];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ntiles = (a.M + TM - 1) / TM;
@@ -151,9 +153,10 @@ __global__ __launch_bounds__(256, K <= 8 ? 3 : 2) void local_block_kernel(RoitrL
     const int r0 = TM == 64 ? (wave >> 1) * 32 : 0;
     const int c0 = TM == 64 ? (wave & 1) * 32 : wave * 32;
     Acc acc;
-    // ---- P1: q = x Wq^T + bq -> R2   (gemm_phase opens with a barrier: R1 is complete)
+    // ---- P1: q = x Wq^T + bq -> R2
+    __syncthreads();                                              // the x image is complete
     acc_zero(acc);
-    if (DBG != 2) gemm_phase<H, AP>(acc, R1, H, a.wq, H, 0, WS, r0, c0, tid);
+    if (DBG != 2) gemm_phase<H, AP>(acc, R1, H, a.wq, H, 0, r0, c0, tid);
     acc_store<AP>(acc, a.bq, R2, r0, c0, lane);
     __syncthreads();
     // ---- P2: attention, in place on R2 (a wave touches only the rows of its own nodes)
@@ -250,11 +253,12 @@ __global__ __launch_bounds__(256, K <= 8 ? 3 : 2) void local_block_kernel(RoitrL
             }
         }
     }
-    // ---- P3: y = LN([att | x] Wcat^T + bcat)   (the opening barrier of gemm_phase publishes the attention rows)
+    // ---- P3: y = LN([att | x] Wcat^T + bcat)
+    __syncthreads();                                              // the attention rows of every wave are in place
     acc_zero(acc);
     if (DBG != 2) {
-    gemm_phase<H, AP>(acc, R2, H, a.wcat, 2 * H, 0, WS, r0, c0, tid);
-    gemm_phase<H, AP>(acc, R1, H, a.wcat, 2 * H, H, WS, r0, c0, tid);
+    gemm_phase<H, AP>(acc, R2, H, a.wcat, 2 * H, 0, r0, c0, tid);
+    gemm_phase<H, AP>(acc, R1, H, a.wcat, 2 * H, H, r0, c0, tid);
     }
     __syncthreads();                                              // every wave is done reading R1 / R2
     acc_store<AP>(acc, a.bcat, R2, r0, c0, lane);
@@ -301,9 +305,10 @@ __global__ __launch_bounds__(256, K <= 8 ? 3 : 2) void local_block_kernel(RoitrL
             for (int i = 0; i < HV; ++i) xres[u][i] = *reinterpret_cast<const float4*>(a.x + node * H + 4 * (lc + 16 * i));
         }
     }
+    __syncthreads();                                              // the y image is complete
     acc_zero(acc);
-    if (DBG != 2) gemm_phase<H, AP>(acc, R1, H, a.wout, H, 0, WS, r0, c0, tid);
-    __syncthreads();                                              // R2's LayerNorm reads are long done; this one orders the MFMA reads of WS / R1
+    if (DBG != 2) gemm_phase<H, AP>(acc, R1, H, a.wout, H, 0, r0, c0, tid);
+    __syncthreads();                                              // every wave is done reading the y image
     acc_store<AP>(acc, a.bout, R2, r0, c0, lane);
     __syncthreads();
     {
@@ -360,7 +365,6 @@ __global__ __launch_bounds__(256) void local_first_kernel(RoitrLocalFirst a)
     constexpr int H = 64, TM = 64, AP = H + 4, HV = 1;
     __shared__ __attribute__((aligned(16))) float R1[TM * AP];   // LayerNorm-ed y image
     __shared__ __attribute__((aligned(16))) float R2[TM * AP];   // g rows (32 columns used) -> row-major staging of the epilogues
-    __shared__ __attribute__((aligned(16))) float WS[H * WP];
     __shared__ int ids[TM];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ntiles = (a.M + TM - 1) / TM;
@@ -421,8 +425,9 @@ __global__ __launch_bounds__(256) void local_first_kernel(RoitrLocalFirst a)
     const int r0 = (wave >> 1) * 32, c0 = (wave & 1) * 32;
     Acc acc;
     // ---- z = G g (K = 32, the bias rides in column 21) -> LayerNorm -> y
+    __syncthreads();                                              // the g rows are complete
     acc_zero(acc);
-    gemm_phase<H, AP>(acc, R2, 32, a.G, 32, 0, WS, r0, c0, tid);
+    gemm_phase<H, AP>(acc, R2, 32, a.G, 32, 0, r0, c0, tid);
     __syncthreads();
     acc_store<AP>(acc, a.zero_bias, R2, r0, c0, lane);
     __syncthreads();
@@ -442,8 +447,9 @@ __global__ __launch_bounds__(256) void local_first_kernel(RoitrLocalFirst a)
         }
     }
     // ---- out = y Wout^T + bout
+    __syncthreads();                                              // the y image is complete
     acc_zero(acc);
-    gemm_phase<H, AP>(acc, R1, H, a.wout, H, 0, WS, r0, c0, tid);
+    gemm_phase<H, AP>(acc, R1, H, a.wout, H, 0, r0, c0, tid);
     __syncthreads();
     acc_store<AP>(acc, a.bout, R2, r0, c0, lane);
     __syncthreads();

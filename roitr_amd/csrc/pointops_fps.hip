@@ -85,14 +85,24 @@ __device__ __forceinline__ unsigned tie_field(int koff, int bs_ref_mask, int bs_
 constexpr int FPS_IDX_CAP = 4096;    // selected indices parked in LDS (written out once at the end)
 constexpr int FPS_PTS_CAP = 8192;    // clouds up to this size keep an xyz copy in LDS for the winner lookup
 
+// Hierarchy shortcut (round 3).  The next level samples the picks of this level IN PICK ORDER from the same first point, so
+// as long as every arg-max of this level's first m' iterations was attained by exactly ONE point, FPS on those picks returns
+// their first m' positions: the running minimum distances of the picked points are the same numbers (same coordinates, same
+// arithmetic), the maximum over the subset is the maximum over the whole cloud and it sits at the same, unique, point.  A tie
+// is the only place where the reference's block-tournament order (which depends on the cloud size) could choose differently.
+// `tie_out[cloud]` = first pick index at which the maximum was shared (INT_MAX: none among the first `track` picks);
+// `prev_tie` != null: this launch samples the previous level's picks -- a cloud whose prev_tie covers all m picks writes the
+// prefix and leaves (passing the value on for the level after it), every other cloud runs the real thing.
 template <int BLOCK, int PPT>
 __global__ __launch_bounds__(BLOCK) void fps_kernel(const float* __restrict__ xyz, const int* __restrict__ offset,
                                                     const int* __restrict__ new_offset, float* __restrict__ tmp,
-                                                    int* __restrict__ idx, int bs_ref_mask, int bs_ref_bits, int lds_pts)
+                                                    int* __restrict__ idx, int bs_ref_mask, int bs_ref_bits, int lds_pts,
+                                                    const int* __restrict__ prev_tie, int* __restrict__ tie_out, int track_div)
 {
     constexpr int NW = BLOCK / 64;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float2* slots = reinterpret_cast<float2*>(smem);                       // [2][NW] : (max d2, tie word as float bits)
+    __shared__ int wcnt[2][NW];                                            // points attaining the wave maximum (tracked picks only)
     int* sidx = reinterpret_cast<int*>(smem + 2 * NW * sizeof(float2));    // [FPS_IDX_CAP]
     // xyz copy for the winner lookup, three planes of lds_pts floats (12 B per point: two 5000-point clouds share a CU)
     float* spts = reinterpret_cast<float*>(smem + 2 * NW * sizeof(float2) + FPS_IDX_CAP * sizeof(int));
@@ -107,6 +117,17 @@ __global__ __launch_bounds__(BLOCK) void fps_kernel(const float* __restrict__ xy
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const bool pts_in_lds = n <= lds_pts;
+    if (prev_tie) {
+        const int pt_ = prev_tie[bid];
+        if (pt_ >= end_m - start_m) {                       // block-uniform: the picks are the cloud's first m points
+            for (int j = tid; j < end_m - start_m; j += BLOCK) idx[start_m + j] = start_n + j;
+            if (tie_out && tid == 0) tie_out[bid] = pt_;
+            return;
+        }
+    }
+    // picks whose arg-max uniqueness is recorded: the next level keeps (m / track_div) of this level's m picks
+    const int track = (tie_out && track_div > 0) ? (end_m - start_m) / track_div : 0;
+    int first_tie = 0x7fffffff;
 
     float px[PPT], py[PPT], pz[PPT], pt[PPT];
     // (k-start) mod bs_ref only depends on j mod 4 because bs_ref <= 4*BLOCK for every dispatch below
@@ -144,15 +165,23 @@ __global__ __launch_bounds__(BLOCK) void fps_kernel(const float* __restrict__ xy
             dmax = fmaxf(dmax, d2);
         }
         const float wd = wave_fmax(dmax);
+        const bool tracked = jm - start_m < track;           // block-uniform
         unsigned btb = 0u;
+        int nat = 0;
 #pragma unroll
         for (int j = 0; j < PPT; ++j) {
             const unsigned tb = tba[j & 3] - (unsigned)(j * BLOCK);
-            const unsigned c = pt[j] == wd ? tb : 0u;
+            const bool at = pt[j] == wd;
+            const unsigned c = at ? tb : 0u;
             btb = c > btb ? c : btb;
+            if (tracked) nat += at ? 1 : 0;
         }
         const unsigned wtb = wave_umax(btb);
         float2* buf = slots + (jm & 1) * NW;
+        if (tracked) {
+            const int wn = (int)wave_sum((float)nat);          // <= 64 * PPT: exact in fp32
+            if (lane == 0) wcnt[jm & 1][wave] = wn;
+        }
         if (lane == 0) buf[wave] = make_float2(wd, __uint_as_float(wtb));
         // LDS-only barrier: wait for this wave's LDS write, not for outstanding global traffic
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -166,6 +195,12 @@ __global__ __launch_bounds__(BLOCK) void fps_kernel(const float* __restrict__ xy
         for (int w = 0; w < NW; ++w) {
             const unsigned c = sl[w].x == gd ? __float_as_uint(sl[w].y) : 0u;
             gtb = c > gtb ? c : gtb;
+        }
+        if (tracked) {
+            int tot = 0;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) tot += sl[w].x == gd ? wcnt[jm & 1][w] : 0;
+            if (tot != 1 && first_tie == 0x7fffffff) first_tie = jm - start_m;
         }
         int old = start_n;
         if (gd >= 0.f) old = start_n + (int)(0x1FFFFFu - ((gtb - 1u) & 0x1FFFFFu));
@@ -183,6 +218,7 @@ __global__ __launch_bounds__(BLOCK) void fps_kernel(const float* __restrict__ xy
     }
     __syncthreads();
     for (int j = 1 + tid; j < end_m - start_m && j < FPS_IDX_CAP; j += BLOCK) idx[start_m + j] = sidx[j];
+    if (tie_out && tid == 0) tie_out[bid] = track > 0 ? first_tie : 0;   // nothing tracked: the next level must not assume anything
 
 #pragma unroll
     for (int j = 0; j < PPT; ++j) {
@@ -247,8 +283,19 @@ int ref_block_size(int n)
 
 }  // namespace
 
+extern "C" int roitr_furthestsampling_ex(int b, int n_max, const float* xyz, const int* offset, const int* new_offset, float* tmp, int* idx,
+                                         const int* prev_tie, int* tie_out, int track_div, hipStream_t stream);
 extern "C" int roitr_furthestsampling(int b, int n_max, const float* xyz, const int* offset, const int* new_offset,
                                       float* tmp, int* idx, hipStream_t stream)
+{
+    return roitr_furthestsampling_ex(b, n_max, xyz, offset, new_offset, tmp, idx, nullptr, nullptr, 0, stream);
+}
+
+/* The sampling chain of a hierarchy (see fps_kernel): tie_out (b ints, device) receives per cloud the first pick index whose
+ * arg-max was shared among this level's first (m / track_div) picks; prev_tie = the tie_out of the level whose PICKS (in pick
+ * order) this call samples -- clouds it covers are answered with the prefix 0 .. m-1 without running the chain.  Both optional. */
+extern "C" int roitr_furthestsampling_ex(int b, int n_max, const float* xyz, const int* offset, const int* new_offset, float* tmp, int* idx,
+                                         const int* prev_tie, int* tie_out, int track_div, hipStream_t stream)
 {
     if (b <= 0) return ROITR_OK;
     if (n_max >= (1 << 21)) return ROITR_ERR_UNSUPPORTED;
@@ -266,7 +313,8 @@ extern "C" int roitr_furthestsampling(int b, int n_max, const float* xyz, const 
             hipFuncAttributeMaxDynamicSharedMemorySize, (int)fps_lds_bytes(BLK, FPS_PTS_CAP));        \
         (void)attr_;                                                                                  \
         roitr_prof_begin(ROITR_PROF_FPS, -1.0, stream);                                               \
-        fps_kernel<BLK, P><<<b, BLK, fps_lds_bytes(BLK, lds_pts), stream>>>(xyz, offset, new_offset, tmp, idx, mask, bits, lds_pts); \
+        fps_kernel<BLK, P><<<b, BLK, fps_lds_bytes(BLK, lds_pts), stream>>>(xyz, offset, new_offset, tmp, idx, mask, bits, lds_pts, prev_tie, tie_out, \
+                                                                            track_div);                                             \
         roitr_prof_end(ROITR_PROF_FPS, stream);                                                       \
         ROITR_LAUNCH_CHECK();                                                                         \
         return ROITR_OK;                                                                              \
@@ -295,6 +343,7 @@ extern "C" int roitr_furthestsampling(int b, int n_max, const float* xyz, const 
     // (101 vs 75 ms for 2 pairs) than with the L2-streaming kernel below (6.9 us per iteration).
     fps_stream_kernel<1024><<<b, 1024, 0, stream>>>(xyz, offset, new_offset, tmp, idx, mask, bits);
     ROITR_LAUNCH_CHECK();
+    if (tie_out) ROITR_HIP(hipMemsetAsync(tie_out, 0, sizeof(int) * (size_t)b, stream));   // untracked: the next level runs its own chain
     return ROITR_OK;
 }
 

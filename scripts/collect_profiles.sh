@@ -4,7 +4,7 @@
 # 1) bench.py JSON lines (config 2 default, one pair per step, config 3, config 4 bf16 / f32),
 # 2) rocprofv3 --kernel-trace --stats (csv) of the default bench,
 # 3) two separate --pmc passes (FETCH_SIZE, WRITE_SIZE; kernel-trace only) of the default bench,
-# 4) the config-5 kNN micro-benchmark (scripts/knn_config5.sh: timing + SQ counters, own --pmc pass).
+# 4) bench.py --config 5 (kNN(64) + PPF stress) + its SQ counter pass (scripts/knn_config5_sq.sh) + the SQ pass of the forward.
 set -u
 tag=${1:-r02}
 export TMPDIR=/tmp
@@ -24,9 +24,13 @@ P="python bench.py --no-cpu-baseline --no-single-pair --no-rccl-selftest --no-pr
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o s -- $P --steps 4 --warmup 1 > $out/stats.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -o f -- $P --steps 1 --warmup 1 > $out/pmc_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -o w -- $P --steps 1 --warmup 1 > $out/pmc_write.log 2>&1
-python scripts/pmc_summary.py $out/pmc_fetch/f_counter_collection.csv $out/pmc_write/w_counter_collection.csv $out/${tag}_pmc_traffic.json 512
+python scripts/pmc_summary.py $out/pmc_fetch/f_counter_collection.csv $out/pmc_write/w_counter_collection.csv $out/${tag}_pmc_traffic.json 512 2 2
 python scripts/prof_summary.py $out/stats s 5 45 > $out/${tag}_kernel_summary.txt
 cp $out/stats/s_kernel_stats.csv $out/${tag}_kernel_stats.csv
 python scripts/hbm_table.py $out $tag > $out/${tag}_hbm_gbs.txt
-bash scripts/knn_config5.sh $out/knn5 > $out/${tag}_knn_config5.txt 2>&1
+python bench.py --config 5 > $out/bench_c5.log 2>&1
+tail -1 $out/bench_c5.log > $out/${tag}_bench_config5.json
+bash scripts/knn_config5_sq.sh $out/knn5sq > $out/${tag}_knn_config5_sq.txt 2>&1
+cp $out/knn5sq/sq_knn_config5.json $out/sq_knn_config5.json
+bash scripts/sq_pass.sh $out/sq > $out/${tag}_sq_pass.txt 2>&1
 for f in $out/${tag}_bench*.json; do echo $f; cut -c1-400 $f; done

@@ -67,6 +67,46 @@ def test_fps_bit_exact_many_clouds(kind, n_clouds, n):
     assert np.array_equal(few, ref[:noff[7]])
 
 
+@pytest.mark.parametrize("kind", ["uniform", "lattice", "dup"])
+@pytest.mark.parametrize("sizes", [[5000, 4999, 1250], [1024] * 20, [313, 5000]])
+def test_fps_hierarchy_chain_with_prefix_shortcut(kind, sizes):
+    """roitr_furthestsampling_ex over three levels the way the engine chains it (each level samples the previous level's picks
+    in pick order): clouds whose tracked arg-maxima were unique are answered with the prefix, the others (lattice / duplicate
+    clouds: shared maxima everywhere) run the chain -- either way every level equals the oracle's plain FPS of that level."""
+    import ctypes
+    from roitr_amd import _lib as L
+    rng = np.random.default_rng(hash((kind, tuple(sizes))) % 2**32)
+    xyz = np.concatenate([cloud(rng, n, kind) for n in sizes])
+    b = len(sizes)
+    lib = L.lib()
+    cur, cur_sizes = xyz, list(sizes)
+    prev_tie = None
+    shortcut_taken = []
+    for lvl in range(3):
+        nxt_sizes = [max(n // 4, 1) for n in cur_sizes]
+        off = np.cumsum(cur_sizes).astype(np.int32)
+        noff = np.cumsum(nxt_sizes).astype(np.int32)
+        ref = O.furthestsampling(cur, off, noff)
+        d_xyz, d_off, d_noff = dev(cur), dev(off), dev(noff)
+        tmp = torch.full((cur.shape[0],), 1e10, dtype=torch.float32, device="cuda")
+        idx = torch.empty((int(noff[-1]),), dtype=torch.int32, device="cuda")
+        tie = torch.full((b,), -7, dtype=torch.int32, device="cuda")
+        L.check(lib.roitr_furthestsampling_ex(b, int(max(cur_sizes)), L.ptr(d_xyz), L.ptr(d_off), L.ptr(d_noff), L.ptr(tmp), L.ptr(idx),
+                                              L.ptr(prev_tie), L.ptr(tie), 4, L.stream_ptr()), "fps_ex")
+        got = idx.cpu().numpy()
+        assert np.array_equal(got, ref), (kind, lvl)
+        if prev_tie is not None:
+            pt = prev_tie.cpu().numpy()
+            shortcut_taken.append([bool(pt[c] >= nxt_sizes[c]) for c in range(b)])
+        prev_tie = tie
+        cur = np.ascontiguousarray(cur[got.astype(np.int64)])
+        cur_sizes = nxt_sizes
+    if kind == "uniform":
+        assert all(all(r) for r in shortcut_taken)          # no shared maxima on a generic cloud: the two lower levels are prefixes
+    if kind == "lattice":
+        assert not all(all(r) for r in shortcut_taken)      # the fallback really ran somewhere
+
+
 def test_fps_golden(golden_pair):
     from roitr_amd import pointops as P
     g = golden_pair
