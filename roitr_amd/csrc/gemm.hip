@@ -334,6 +334,8 @@ void shape_log(const RoitrGemm* g, bool fast, float ms)
 }  // namespace
 
 int roitr_gemm_bf16_launch(const RoitrGemm* g, hipStream_t stream);   // gemm_bf16.hip
+bool roitr_gemm_wide_takes(const RoitrGemm* g);                         // gemm_wide.hip: K >= 128, N >= 192 plain GEMMs
+int roitr_gemm_wide_launch(const RoitrGemm* g, hipStream_t stream);
 
 extern "C" int roitr_gemm(const RoitrGemm* g, hipStream_t stream)
 {
@@ -378,6 +380,10 @@ extern "C" int roitr_gemm(const RoitrGemm* g, hipStream_t stream)
     static const bool shapes = getenv("ROITR_GEMM_SHAPES") != nullptr;  // debug: per-shape timing table at exit (synchronous)
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (shapes) { hipEventCreate(&e0); hipEventCreate(&e1); hipEventRecord(e0, stream); }
+    if (roitr_gemm_wide_takes(g)) {
+        const int rc = roitr_gemm_wide_launch(g, stream);
+        if (rc != ROITR_OK) { roitr_prof_end(ROITR_PROF_GEMM, stream); return rc; }
+    } else
     if (g->ln_gamma) {
         if (!fast) { if (tn != 1) return ROITR_ERR_UNSUPPORTED; gemm_kernel<false, 1, true><<<grid, 256, 0, stream>>>(*g, nx, ny, T); }
         else if (tn == 1) gemm_kernel<true, 1, true><<<grid, 256, 0, stream>>>(*g, nx, ny, T);

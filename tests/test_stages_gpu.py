@@ -384,7 +384,39 @@ def test_gemm_rows_do_not_depend_on_the_row_count():
         assert torch.equal(big[:156], small)
 
 
-@pytest.mark.parametrize("N,K,Kc", [(64, 64, 64), (128, 128, 128), (256, 64, 192)])
+@pytest.mark.parametrize("M,N,K,gather,addend,relu", [(1000, 192, 128, False, False, True), (333, 768, 256, True, False, False),
+                                                        (64 * 5 + 7, 256, 512, False, True, True), (70001, 256, 128, True, True, False),
+                                                        (40000, 512, 256, False, False, True), (130, 1024, 192, False, False, False)])
+def test_gemm_wide_kernel_against_float64(M, N, K, gather, addend, relu):
+    """csrc/gemm_wide.hip (K >= 128, N >= 192: weight fragments straight from L1 / L2, A double-buffered in 64-k slabs) against a
+    float64 product: all three tile widths, ragged last row tile, row gather with out-of-range rows (zero rows), the addend on A,
+    bias / alpha / ReLU.  Error bound: fp32 accumulation of K terms relative to the row's |a| . |w| mass."""
+    import ctypes
+    from roitr_amd import _lib as L
+    from roitr_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(M + N + K)
+    R = M + 50
+    a = torch.randn((R, K), generator=g).cuda()
+    a2 = torch.randn((R, K), generator=g).cuda() if addend else None
+    w = (torch.randn((N, K), generator=g) / K ** 0.5).cuda()
+    b = torch.randn((N,), generator=g).cuda()
+    idx = torch.randint(0, R + 20, (M,), generator=g).to(torch.int32).cuda() if gather else None   # >= R: zero rows
+    out = torch.empty((M, N), device="cuda")
+    gm = ops._Gemm(M, N, K, L.ptr(a), L.ptr(a2), K, L.ptr(idx), R if gather else 0, L.ptr(w), K, L.ptr(None), 0, L.ptr(b), 0.75, int(relu),
+                   L.ptr(out), N, 1, 0, 0, 0, 0, 0, 0, L.ptr(None), 0, 0)
+    L.check(L.lib().roitr_gemm(ctypes.byref(gm), L.stream_ptr()), "gemm")
+    src = idx.long() if gather else torch.arange(M, device="cuda")
+    ok = src < R
+    rows = (a.double() + (a2.double() if addend else 0.0))[src.clamp_max(R - 1)] * ok[:, None]
+    ref = 0.75 * (rows @ w.double().T) + b.double()
+    mass = 0.75 * (rows.abs() @ w.double().abs().T) + b.double().abs()
+    if relu:
+        ref = ref.clamp_min(0)
+    err = ((out.double() - ref).abs() / (mass + 1e-30)).max().item()
+    assert err < 2e-6, err
+
+
+@pytest.mark.parametrize("N,K,Kc", [(64, 64, 64), (128, 128, 128), (256, 64, 192), (256, 256, 256)])
 def test_gemm_k_concatenated_operand(N, K, Kc):
     """RoitrGemm::A_cat -- [x | x_cat] @ W^T without the concatenation (the folded block transformers: K = H + I): bitwise the
     product of the concatenated operand, plain and with the fused LayerNorm epilogue."""
