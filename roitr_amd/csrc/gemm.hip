@@ -334,8 +334,6 @@ void shape_log(const RoitrGemm* g, bool fast, float ms)
 }  // namespace
 
 int roitr_gemm_bf16_launch(const RoitrGemm* g, hipStream_t stream);   // gemm_bf16.hip
-bool roitr_gemm_wide_takes(const RoitrGemm* g);                         // gemm_wide.hip: K >= 128, N >= 192 plain GEMMs
-int roitr_gemm_wide_launch(const RoitrGemm* g, hipStream_t stream);
 
 extern "C" int roitr_gemm(const RoitrGemm* g, hipStream_t stream)
 {
@@ -377,13 +375,15 @@ extern "C" int roitr_gemm(const RoitrGemm* g, hipStream_t stream)
     // Also measured and removed (round 1-2): an LDS-DMA variant (global_load_lds_dwordx4 into a swizzled row-major image, two
     // stages, one barrier per slab): 98 vs 95 TFLOP/s at K = 2048 and 84 vs 80 at K = 256, but 62 vs 74 at K = 128 and 44 vs
     // 56 at K = 64 (32 KB of LDS per block: 5 instead of 7 resident blocks) -> 19.8 vs 17.9 ms of GEMM per 128-pair forward.
+    // Round 3, measured and removed: a second kernel for K >= 128 / N >= 192 built like the on-chip GEMMs of local_block.hip
+    // (v_mfma_f32_16x16x4_f32, weight fragments as float4 straight from L1 / L2, only A staged: 64 x 64-k slabs, double buffered,
+    // one barrier per 64 k).  Correct (float64 test, all shapes of the forward) but 1.35-1.5x SLOWER on every shape it took
+    // (M 319488 N 768 K 256: 1.67 vs 1.21 ms; M 1.28 M N 256 K 128: 1.31 vs 0.87 ms; gemm family 48.7 vs 37.6 ms per 512-pair
+    // step): a lane's weight float4 comes from its own weight row, so one fragment load touches 16 cache lines at 64 B each --
+    // the vector-memory pipe, not LDS, becomes the operand bottleneck once nothing else (attention, LayerNorm) overlaps it.
     static const bool shapes = getenv("ROITR_GEMM_SHAPES") != nullptr;  // debug: per-shape timing table at exit (synchronous)
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (shapes) { hipEventCreate(&e0); hipEventCreate(&e1); hipEventRecord(e0, stream); }
-    if (roitr_gemm_wide_takes(g)) {
-        const int rc = roitr_gemm_wide_launch(g, stream);
-        if (rc != ROITR_OK) { roitr_prof_end(ROITR_PROF_GEMM, stream); return rc; }
-    } else
     if (g->ln_gamma) {
         if (!fast) { if (tn != 1) return ROITR_ERR_UNSUPPORTED; gemm_kernel<false, 1, true><<<grid, 256, 0, stream>>>(*g, nx, ny, T); }
         else if (tn == 1) gemm_kernel<true, 1, true><<<grid, 256, 0, stream>>>(*g, nx, ny, T);

@@ -387,9 +387,8 @@ def test_gemm_rows_do_not_depend_on_the_row_count():
 @pytest.mark.parametrize("M,N,K,gather,addend,relu", [(1000, 192, 128, False, False, True), (333, 768, 256, True, False, False),
                                                         (64 * 5 + 7, 256, 512, False, True, True), (70001, 256, 128, True, True, False),
                                                         (40000, 512, 256, False, False, True), (130, 1024, 192, False, False, False)])
-def test_gemm_wide_kernel_against_float64(M, N, K, gather, addend, relu):
-    """csrc/gemm_wide.hip (K >= 128, N >= 192: weight fragments straight from L1 / L2, A double-buffered in 64-k slabs) against a
-    float64 product: all three tile widths, ragged last row tile, row gather with out-of-range rows (zero rows), the addend on A,
+def test_gemm_wide_shapes_against_float64(M, N, K, gather, addend, relu):
+    """The matrix-shaped layers of the forward (K >= 128, N >= 192) through the C ABI against a float64 product: ragged last row tile, row gather with out-of-range rows (zero rows), the addend on A,
     bias / alpha / ReLU.  Error bound: fp32 accumulation of K terms relative to the row's |a| . |w| mass."""
     import ctypes
     from roitr_amd import _lib as L
