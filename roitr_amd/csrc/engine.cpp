@@ -125,7 +125,8 @@ struct Engine {
     hipEvent_t pinned_ev[RING] = {nullptr, nullptr, nullptr, nullptr};
     int ring_pos = 0;
     hipStream_t side = nullptr;      // FPS chain runs here, beside the level-1 encoder work
-    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    static constexpr int NEV = 8;
+    hipEvent_t ev[NEV] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     std::string err;
     hipStream_t fin_stream = nullptr;   // stream of the running finalize (weight conversions are queued on it)
     // ---- captured forwards (roitr_engine_forward_graph): one hipGraphExec per (sizes, io pointers) key
@@ -585,7 +586,7 @@ extern "C" void roitr_engine_destroy(void* h)
         if (g.pin) (void)hipHostFree(g.pin);
     }
     if (E->side) (void)hipStreamDestroy(E->side);
-    for (int i = 0; i < 5; ++i) if (E->ev[i]) (void)hipEventDestroy(E->ev[i]);
+    for (int i = 0; i < Engine::NEV; ++i) if (E->ev[i]) (void)hipEventDestroy(E->ev[i]);
     for (int i = 0; i < Engine::RING; ++i) {
         if (E->pinned[i]) (void)hipHostFree(E->pinned[i]);
         if (E->pinned_ev[i]) (void)hipEventDestroy(E->pinned_ev[i]);
@@ -876,23 +877,38 @@ extern "C" int roitr_engine_forward(void* h, const RoitrForwardIO* io, hipStream
     D.eoff = (long*)(ddesc + ((desc_ints * 4 + 15) & ~(size_t)15));
 
     roitr_prof_begin(ROITR_PROF_PH_FORWARD, 0.0, st);
-    // ---------------- hierarchy: FPS chain on a side stream, per level kNN groups + PPF + encoder on the main one
-    // (model/model.py:56-80, 30-42, 195-205).  The FPS chain depends on nothing but the input coordinates and is a
-    // long serial kernel on 2B workgroups, so it runs beside the level-1 geometry and encoder instead of in front
-    // of them; level l's work waits for "level l sampled" only.
+    // ---------------- hierarchy: the GEOMETRY CHAIN on a side stream, the feature path on the main one
+    // (model/model.py:56-80, 30-42, 195-205).  Everything below depends on the input coordinates only: the FPS chain, the
+    // grids, self / TransitionDown kNN groups + PPF of levels 2-4, the decoder's 3-NN, the distance / angle indices and the
+    // embedding E of the global transformer.  These kernels are issue- / latency- / LDS-bound (FPS: one long serial workgroup
+    // per cloud; kNN: VALU issue; geo_table: LDS), the feature path beside them is MFMA- and HBM-bound, so they share the chip
+    // instead of queueing in front of each level (round 3; the FPS chain alone since round 1).  Level 1's grid and self kNN stay on
+    // the main stream (the first transformer needs them at once).  Level l's feature work waits for "level l geometry done" only.
     const float* p[4]; const float* nrm[4];
     p[0] = io->points_geom; nrm[0] = io->normals;
     int* down[4] = {nullptr, nullptr, nullptr, nullptr};  // FPS indices into level l-1 (global rows)
     int* g_self[4]; float* ppf_self[4];                    // self kNN groups (blocks + decoder)
     int* g_td[4]; float* ppf_td[4];                        // TransitionDown groups (level l nodes over level l-1 points)
+    int* i3[3]; float* d3[3];                              // decoder: 3 nearest level-(l+1) points of every level-l point
     void* knn_ws[4];
     bool grid[4];
     const void* order[4] = {nullptr, nullptr, nullptr, nullptr};  // cell-order visiting order of each level's points
     float* xe[4];
     if (!E.side) {
+        // (a lower or higher queue priority for this stream changes nothing measurable: 97.3 / 98.2 / 98.2 ms per 512-pair step)
         ROITR_HIP(hipStreamCreateWithFlags(&E.side, hipStreamNonBlocking));
-        for (int i = 0; i < 5; ++i) ROITR_HIP(hipEventCreateWithFlags(&E.ev[i], hipEventDisableTiming));
+        for (int i = 0; i < Engine::NEV; ++i) ROITR_HIP(hipEventCreateWithFlags(&E.ev[i], hipEventDisableTiming));
     }
+    hipStream_t sd = E.side;
+    const float* pts_out = io->points_out ? io->points_out : io->points_geom;
+    float* node_xyz = io->node_xyz ? io->node_xyz : A.get<float>((size_t)T4 * 3);
+    int* node_masks = io->node_masks ? io->node_masks : A.get<int>(T4);
+    int* kidx = io->node_knn_idx ? io->node_knn_idx : A.get<int>((size_t)T4 * LIM);
+    int* kmask = io->node_knn_mask ? io->node_knn_mask : A.get<int>((size_t)T4 * LIM);
+    float* d_idx = nullptr; float* a_idx = nullptr; float* Emb = nullptr;
+    // bf16 operand mode: E (an operand of the q~ . E and a' . E contractions of every self layer) is stored bf16 when the
+    // attention kernel for this width reads it (C = 256 / 512, 4 heads, <= 512 superpoints)
+    const bool e_h = E.cfg.operand_dtype == 1 && E.proj_d.wb && E.proj_a.wb && (C4 == 256 || C4 == 512) && V.nmax[3] <= 512;
     {
         float* fps_tmp = A.get<float>(T1);
         int* fps_tie[4] = {nullptr, A.get<int>(NC), A.get<int>(NC), nullptr};   // per cloud: first pick with a shared arg-max
@@ -901,21 +917,139 @@ extern "C" int roitr_engine_forward(void* h, const RoitrForwardIO* io, hipStream
             p[l] = A.get<float>((size_t)V.T[l] * 3);
             nrm[l] = A.get<float>((size_t)V.T[l] * 3);
         }
-        if (A.fail) { roitr_set_error("arena exhausted (sampling)", __FILE__, __LINE__); return ROITR_ERR_ARG; }
+        // every buffer the side stream writes is carved here, before the encoder's mark / release scopes
+        for (int l = 0; l < 4; ++l) {
+            const int K = E.nsample[l];
+            const int mcap = l == 0 ? T1 : V.T[l - 1];
+            knn_ws[l] = A.get<char>(roitr_knn_workspace_bytes(NC, V.T[l], mcap));
+            grid[l] = V.T[l] > GRID_MIN_POINTS * NC;
+            g_self[l] = A.get<int>((size_t)V.T[l] * K);
+            ppf_self[l] = A.get<float>((size_t)V.T[l] * K * 4);
+            if (l > 0) {
+                g_td[l] = A.get<int>((size_t)V.T[l] * K);
+                ppf_td[l] = A.get<float>((size_t)V.T[l] * K * 4);
+            } else {
+                g_td[0] = g_self[0]; ppf_td[0] = ppf_self[0];  // stride 1: the same kNN (model/model.py:75 vs :31)
+            }
+            if (l < 3) { i3[l] = A.get<int>((size_t)V.T[l] * 3); d3[l] = A.get<float>((size_t)V.T[l] * 3); }
+        }
+        d_idx = A.get<float>(etot);
+        a_idx = A.get<float>((size_t)etot * 3);
+        Emb = A.get<float>((size_t)etot * C4);
+        if (A.fail) { roitr_set_error("arena exhausted (geometry)", __FILE__, __LINE__); return ROITR_ERR_ARG; }
+
+        // ---- main stream: level-1 grid + self kNN (+ PPF)
+        if (grid[0]) {
+            // 6 points per cell on average: at level 1 (k = 8) the sphere of one cell size then holds ~2.5 (k + 2) points, what
+            // the prefilter kNN kernel's radius rule needs
+            CHK(roitr_knn_build_grid_ex(NC, V.T[0], T1, p[0], D.off[0], knn_ws[0], 6.0f, st));
+            order[0] = roitr_knn_sorted_points(NC, V.T[0], T1, knn_ws[0]);
+        }
         ROITR_HIP(hipEventRecord(E.ev[0], st));  // inputs + descriptors are in place
-        ROITR_HIP(hipStreamWaitEvent(E.side, E.ev[0], 0));
+        CHK(roitr_knnquery_ex(NC, V.T[0], V.T[0], E.nsample[0] + 1, p[0], p[0], D.off[0], D.off[0], nullptr, nullptr, g_self[0], ppf_self[0],
+                              nrm[0], nrm[0], grid[0] ? 1 : 0, T1, knn_ws[0], st));
+        ROITR_HIP(hipEventRecord(E.ev[4], st));  // the level-1 workspace (grid + retry list) is free for the TransitionDown query
+
+        // ---- side stream
+        ROITR_HIP(hipStreamWaitEvent(sd, E.ev[0], 0));
         for (int l = 1; l < 4; ++l) {
+            const int K = E.nsample[l];
             // tmp = 1e10 (functions/pointops.py:22)
-            ROITR_HIP(hipMemsetD32Async((hipDeviceptr_t)fps_tmp, 0x501502F9 /* bits of 1e10f */, V.T[l - 1], E.side));
+            ROITR_HIP(hipMemsetD32Async((hipDeviceptr_t)fps_tmp, 0x501502F9 /* bits of 1e10f */, V.T[l - 1], sd));
             roitr_prof_next_bytes(ROITR_PROF_FPS, 12.0 * V.T[l - 1] + 4.0 * V.T[l] + 8.0 * V.T[l - 1]);
             // levels 2 and 3 sample the previous level's picks in pick order: answered with the prefix while no arg-max was
             // shared (pointops_fps.hip), the serial chain of 312 + 78 dependent iterations otherwise
             CHK(roitr_furthestsampling_ex(NC, V.nmax[l - 1], p[l - 1], D.off[l - 1], D.off[l], fps_tmp, down[l], l > 1 ? fps_tie[l - 1] : nullptr,
-                                          l < 3 ? fps_tie[l] : nullptr, 4, E.side));
-            CHK(roitr_gather_rows(V.T[l], 3, p[l - 1], down[l], 0, (float*)p[l], E.side));
-            CHK(roitr_gather_rows(V.T[l], 3, nrm[l - 1], down[l], 0, (float*)nrm[l], E.side));
-            ROITR_HIP(hipEventRecord(E.ev[l], E.side));
+                                          l < 3 ? fps_tie[l] : nullptr, 4, sd));
+            CHK(roitr_gather_rows(V.T[l], 3, p[l - 1], down[l], 0, (float*)p[l], sd));
+            CHK(roitr_gather_rows(V.T[l], 3, nrm[l - 1], down[l], 0, (float*)nrm[l], sd));
+            // grid over this level's points (refs for: own self-kNN, next level's TD query, finer level's 3-NN)
+            if (grid[l]) {
+                CHK(roitr_knn_build_grid_ex(NC, V.T[l], V.T[l - 1], p[l], D.off[l], knn_ws[l], 6.0f, sd));
+                order[l] = roitr_knn_sorted_points(NC, V.T[l], V.T[l - 1], knn_ws[l]);
+            }
+            CHK(roitr_knnquery_ex(NC, V.T[l], V.T[l], K + 1, p[l], p[l], D.off[l], D.off[l], nullptr, nullptr, g_self[l], ppf_self[l], nrm[l],
+                                  nrm[l], grid[l] ? 1 : 0, V.T[l - 1], knn_ws[l], sd));
+            if (l == 1) ROITR_HIP(hipStreamWaitEvent(sd, E.ev[4], 0));
+            const int mcap_prev = l - 1 == 0 ? T1 : V.T[l - 2];
+            CHK(roitr_knnquery_ex(NC, V.T[l - 1], V.T[l], K + 1, p[l - 1], p[l], D.off[l - 1], D.off[l], nullptr, nullptr, g_td[l],
+                                  ppf_td[l], nrm[l - 1], nrm[l], grid[l - 1] ? 1 : 0, mcap_prev, knn_ws[l - 1], sd));
+            ROITR_HIP(hipEventRecord(E.ev[l], sd));
         }
+        // the embedding of the global transformer (positional_encoding.py:139-154): needs the level-4 coordinates only
+        CHK(roitr_geo_indices(T4, p[3], D.off[3], D.cloud_of_node, D.eoff, 0.2f, 15.0f, 3, V.nmax[3], d_idx, a_idx, sd));
+        if (E.geo_tab && roitr_geo_embed_table(etot, C4, 3, d_idx, a_idx, E.geo_tab, E.geo_tab_h, E.geo_tab_nd, E.geo_tab_na, E.geo_div,
+                                               E.proj_d.w, E.proj_d.b, E.proj_a.w, E.proj_a.b, Emb, e_h ? 1 : 0, sd) != ROITR_OK)
+            E.geo_tab = nullptr;   // e.g. a device that does not grant the table's LDS: this engine serves the GEMM form from now on
+        if (E.geo_tab) {}
+        else if (e_h)
+            CHK(roitr_geo_embed_bf16_out(etot, C4, 3, d_idx, a_idx, E.geo_div, E.proj_d.wb, E.proj_d.b, E.proj_a.wb, E.proj_a.b,
+                                         reinterpret_cast<unsigned short*>(Emb), sd));
+        else if (E.cfg.operand_dtype == 1 && E.proj_d.wb && E.proj_a.wb)
+            CHK(roitr_geo_embed_bf16(etot, C4, 3, d_idx, a_idx, E.geo_div, E.proj_d.wb, E.proj_d.b, E.proj_a.wb, E.proj_a.b, Emb, sd));
+        else
+            CHK(roitr_geo_embed(etot, C4, 3, d_idx, a_idx, E.geo_div, E.proj_d.w, E.proj_d.b, E.proj_a.w, E.proj_a.b, Emb, sd));
+        ROITR_HIP(hipEventRecord(E.ev[5], sd));
+        // the decoder's 3-NN (pointops.py:168-182 `interpolation`): level-l points among the level-(l+1) points
+        for (int l = 2; l >= 0; --l)
+            CHK(roitr_knnquery_ex(NC, V.T[l + 1], V.T[l], 3, p[l + 1], p[l], D.off[l + 1], D.off[l], i3[l], d3[l], nullptr, nullptr, nullptr,
+                                  nullptr, grid[l + 1] ? 1 : 0, V.T[l], knn_ws[l + 1], sd));
+        ROITR_HIP(hipEventRecord(E.ev[6], sd));
+        // node coordinates (model/model.py:233-235), point-to-node partition (lib/utils.py:428-471) and the ground-truth side
+        // outputs: coordinates, the FPS picks and the given transform only
+        {
+            int* c3 = A.get<int>(V.T[2]);
+            int* c4 = A.get<int>(T4);
+            int* p2n = A.get<int>(T1);
+            float* p2nd = A.get<float>(T1);
+            if (A.fail) { roitr_set_error("arena exhausted (partition)", __FILE__, __LINE__); return ROITR_ERR_ARG; }
+            CHK(roitr_compose_idx(V.T[2], down[1], down[2], c3, sd));  // level-3 nodes as level-1 rows
+            CHK(roitr_compose_idx(T4, c3, down[3], c4, sd));
+            CHK(roitr_gather_rows(T4, 3, pts_out, c4, 0, node_xyz, sd));
+            CHK(roitr_point_to_node_partition(NC, T1, T4, pts_out, D.off[0], node_xyz, D.off[3], D.cloud_of_node, LIM, p2n, p2nd, node_masks,
+                                              kidx, kmask, sd));
+        }
+        // ---------------- ground-truth side outputs (RIGA_v2.py:91-116), only when rot / trans are given
+        if (io->rot && io->trans && (io->gt_node_occ || io->gt_corr_idx)) {
+            const int Tp = T1 + NC;                  // padded rows
+            const int Ts = V.off[0][B - 1];          // source rows
+            const int Tsp = Ts + B, Ttp = Tp - Tsp;  // padded source / target rows
+            float* pad = A.get<float>((size_t)Tp * 3);
+            int* poff = A.get<int>((size_t)3 * B + 4);
+            float* d2p = A.get<float>(Tp);
+            void* ws_s = A.get<char>(roitr_knn_workspace_bytes(B, Tsp, Ttp));
+            void* ws_t = A.get<char>(roitr_knn_workspace_bytes(B, Ttp, Tsp));
+            if (A.fail) { roitr_set_error("arena exhausted (gt)", __FILE__, __LINE__); return ROITR_ERR_ARG; }
+            CHK(roitr_build_padded_clouds(B, T1, pts_out, D.off[0], io->rot, io->trans, pad, poff, sd));
+            const float* src_p = pad; const float* tgt_p = pad + (size_t)Tsp * 3;
+            const int* off_s = poff; const int* off_t = poff + 2 * B;
+            const int use_grid = (Tsp > GRID_MIN_POINTS * B) ? 1 : 0;
+            if (io->gt_node_occ) {
+                // kNN(1) of every padded target point among the transformed padded source points, and back (l.509-510)
+                if (use_grid) CHK(roitr_knn_build_grid(B, Tsp, Ttp, src_p, off_s, ws_s, sd));
+                const float occ_cap2 = E.cfg.occlusion_radius * E.cfg.occlusion_radius * 1.01f;   // only `distance < radius` is read
+                CHK(roitr_knn_within(B, Tsp, Ttp, src_p, tgt_p, off_s, off_t, occ_cap2, d2p + Tsp, use_grid, Ttp, ws_s, sd));
+                if (use_grid) CHK(roitr_knn_build_grid(B, Ttp, Tsp, tgt_p, off_t, ws_t, sd));
+                CHK(roitr_knn_within(B, Ttp, Tsp, tgt_p, src_p, off_t, off_s, occ_cap2, d2p, use_grid, Tsp, ws_t, sd));
+                CHK(roitr_node_occlusion_score(T4, LIM, D.cloud_of_node, D.off[0], kidx, kmask, node_masks, d2p, E.cfg.occlusion_radius,
+                                               io->gt_node_occ, sd));
+            }
+            if (io->gt_corr_idx && io->gt_corr_overlaps && io->gt_corr_count) {
+                const long ms = (long)V.nmax[3] * V.nmax[3];
+                float* om = A.get<float>((size_t)B * ms);
+                float* nt_ = A.get<float>((size_t)T4 * 3);
+                float* nr_ = A.get<float>(T4);
+                if (A.fail) { roitr_set_error("arena exhausted (gt)", __FILE__, __LINE__); return ROITR_ERR_ARG; }
+                RoitrNodeCorr nc; memset(&nc, 0, sizeof(nc));
+                nc.pairs = B; nc.limit = LIM; nc.max_nodes = V.nmax[3]; nc.pos_radius = E.cfg.matching_radius;
+                nc.nodes = node_xyz; nc.node_offset = D.off[3]; nc.node_masks = node_masks; nc.points = pts_out; nc.pt_offset = D.off[0];
+                nc.knn_idx = kidx; nc.knn_mask = kmask; nc.rot = io->rot; nc.trans = io->trans; nc.overlap = om; nc.mat_stride = ms;
+                nc.out_idx = io->gt_corr_idx; nc.out_overlap = io->gt_corr_overlaps; nc.out_count = io->gt_corr_count;
+                nc.n_nodes = T4; nc.nodes_t = nt_; nc.radius = nr_;
+                CHK(roitr_node_correspondences(&nc, sd));
+            }
+        }
+        ROITR_HIP(hipEventRecord(E.ev[7], sd));
     }
     roitr_prof_begin(ROITR_PROF_PH_ENC, 0.0, st);
     {
@@ -926,34 +1060,11 @@ extern "C" int roitr_engine_forward(void* h, const RoitrForwardIO* io, hipStream
                 ROITR_HIP(hipStreamWaitEvent(st, E.ev[l], 0));
                 CHK(tap(E, st, "fps." + std::to_string(l + 1), down[l], sizeof(int) * V.T[l]));
             }
-            // grid over this level's points (refs for: own self-kNN, next level's TD query, finer level's 3-NN)
-            const int mcap = l == 0 ? T1 : V.T[l - 1];
-            knn_ws[l] = A.get<char>(roitr_knn_workspace_bytes(NC, V.T[l], mcap));
-            grid[l] = V.T[l] > GRID_MIN_POINTS * NC;
-            g_self[l] = A.get<int>((size_t)V.T[l] * K);
-            ppf_self[l] = A.get<float>((size_t)V.T[l] * K * 4);
-            if (A.fail) break;
-            if (grid[l]) {
-                // 6 points per cell on average: at level 1 (k = 8) the sphere of one cell size then holds ~2.5 (k + 2) points, what
-                // the prefilter kNN kernel's radius rule needs
-                CHK(roitr_knn_build_grid_ex(NC, V.T[l], mcap, p[l], D.off[l], knn_ws[l], 6.0f, st));
-                order[l] = roitr_knn_sorted_points(NC, V.T[l], mcap, knn_ws[l]);
-            }
-            CHK(roitr_knnquery_ex(NC, V.T[l], V.T[l], K + 1, p[l], p[l], D.off[l], D.off[l], nullptr, nullptr, g_self[l], ppf_self[l], nrm[l],
-                                  nrm[l], grid[l] ? 1 : 0, mcap, knn_ws[l], st));
             CHK(tap(E, st, "group.self." + std::to_string(l + 1), g_self[l], sizeof(int) * (size_t)V.T[l] * K));
             CHK(tap(E, st, "ppf.self." + std::to_string(l + 1), ppf_self[l], sizeof(float) * (size_t)V.T[l] * K * 4));
             if (l > 0) {
-                g_td[l] = A.get<int>((size_t)V.T[l] * K);
-                ppf_td[l] = A.get<float>((size_t)V.T[l] * K * 4);
-                if (A.fail) break;
-                const int mcap_prev = l - 1 == 0 ? T1 : V.T[l - 2];
-                CHK(roitr_knnquery_ex(NC, V.T[l - 1], V.T[l], K + 1, p[l - 1], p[l], D.off[l - 1], D.off[l], nullptr, nullptr, g_td[l],
-                                      ppf_td[l], nrm[l - 1], nrm[l], grid[l - 1] ? 1 : 0, mcap_prev, knn_ws[l - 1], st));
                 CHK(tap(E, st, "group.td." + std::to_string(l + 1), g_td[l], sizeof(int) * (size_t)V.T[l] * K));
                 CHK(tap(E, st, "ppf.td." + std::to_string(l + 1), ppf_td[l], sizeof(float) * (size_t)V.T[l] * K * 4));
-            } else {
-                g_td[0] = g_self[0]; ppf_td[0] = ppf_self[0];  // stride 1: the same kNN (model/model.py:75 vs :31)
             }
             // ---- encoder level l
             float* a = A.get<float>((size_t)V.T[l] * pl);
@@ -990,27 +1101,9 @@ extern "C" int roitr_engine_forward(void* h, const RoitrForwardIO* io, hipStream
     float* gfeat = A.get<float>((size_t)T4 * C4);
     {
         const size_t mark = A.off;
-        float* d_idx = A.get<float>(etot);
-        float* a_idx = A.get<float>((size_t)etot * 3);
-        float* Emb = A.get<float>((size_t)etot * C4);
-        if (A.fail) { roitr_set_error("arena exhausted (geo embedding)", __FILE__, __LINE__); return ROITR_ERR_ARG; }
-        CHK(roitr_geo_indices(T4, p[3], D.off[3], D.cloud_of_node, D.eoff, 0.2f, 15.0f, 3, V.nmax[3], d_idx, a_idx, st));
+        ROITR_HIP(hipStreamWaitEvent(st, E.ev[5], 0));   // E and its index arrays were written on the side stream
         CHK(tap(E, st, "geo.d_idx", d_idx, sizeof(float) * etot));
         CHK(tap(E, st, "geo.a_idx", a_idx, sizeof(float) * etot * 3));
-        // bf16 operand mode: E (an operand of the q~ . E and a' . E contractions of every self layer) is stored bf16 when the
-        // attention kernel for this width reads it (C = 256 / 512, 4 heads, <= 512 superpoints)
-        const bool e_h = E.cfg.operand_dtype == 1 && E.proj_d.wb && E.proj_a.wb && (C4 == 256 || C4 == 512) && V.nmax[3] <= 512;
-        if (E.geo_tab && roitr_geo_embed_table(etot, C4, 3, d_idx, a_idx, E.geo_tab, E.geo_tab_h, E.geo_tab_nd, E.geo_tab_na, E.geo_div,
-                                               E.proj_d.w, E.proj_d.b, E.proj_a.w, E.proj_a.b, Emb, e_h ? 1 : 0, st) != ROITR_OK)
-            E.geo_tab = nullptr;   // e.g. a device that does not grant the table's LDS: this engine serves the GEMM form from now on
-        if (E.geo_tab) {}
-        else if (e_h)
-            CHK(roitr_geo_embed_bf16_out(etot, C4, 3, d_idx, a_idx, E.geo_div, E.proj_d.wb, E.proj_d.b, E.proj_a.wb, E.proj_a.b,
-                                         reinterpret_cast<unsigned short*>(Emb), st));
-        else if (E.cfg.operand_dtype == 1 && E.proj_d.wb && E.proj_a.wb)
-            CHK(roitr_geo_embed_bf16(etot, C4, 3, d_idx, a_idx, E.geo_div, E.proj_d.wb, E.proj_d.b, E.proj_a.wb, E.proj_a.b, Emb, st));
-        else
-            CHK(roitr_geo_embed(etot, C4, 3, d_idx, a_idx, E.geo_div, E.proj_d.w, E.proj_d.b, E.proj_a.w, E.proj_a.b, Emb, st));
         CHK(tap(E, st, "geo.emb", Emb, (e_h ? sizeof(unsigned short) : sizeof(float)) * (size_t)etot * C4));   // bf16 mode: the tap holds bf16
 
         float* fcur = A.get<float>((size_t)T4 * C4);
@@ -1115,6 +1208,7 @@ extern "C" int roitr_engine_forward(void* h, const RoitrForwardIO* io, hipStream
         CHK(block(E, st, E.dec[3], T4, x0, g_self[3], ppf_self[3], E.nsample[3], xd[3], order[3]));
         CHK(tap(E, st, "dec4.1", xd[3], sizeof(float) * (size_t)T4 * pl));
     }
+    ROITR_HIP(hipStreamWaitEvent(st, E.ev[6], 0));   // the 3-NN of the three TransitionUp layers (side stream)
     for (int l = 2; l >= 0; --l) {
         // TransitionUp (model/model.py:112-116): linear1(x1) + interpolation(p2, p1, linear2(x2))
         const int pl = E.planes[l], pc = E.planes[l + 1];
@@ -1124,18 +1218,13 @@ extern "C" int roitr_engine_forward(void* h, const RoitrForwardIO* io, hipStream
         float* a1 = A.get<float>((size_t)Tl * pl);
         float* b0 = A.get<float>((size_t)Tc * pl);
         float* b1 = A.get<float>((size_t)Tc * pl);
-        int* i3 = A.get<int>((size_t)Tl * 3);
-        float* d3 = A.get<float>((size_t)Tl * 3);
         float* x0 = A.get<float>((size_t)Tl * pl);
         xd[l] = A.get<float>((size_t)Tl * pl);
         if (A.fail) { roitr_set_error("arena exhausted (decoder)", __FILE__, __LINE__); return ROITR_ERR_ARG; }
         CHK(gemm_ln(st, Tl, xe[l], U.l1, nullptr, nullptr, U.l1n_w, U.l1n_b, nullptr, true, a0, a1));
         (void)pc;
         CHK(gemm_ln(st, Tc, xd[l + 1], U.l2, nullptr, nullptr, U.l2n_w, U.l2n_b, nullptr, true, b0, b1));
-        const int mcap_c = V.T[l];  // the coarser level's workspace was carved with m_capacity = T[l]
-        CHK(roitr_knnquery_ex(NC, Tc, Tl, 3, p[l + 1], p[l], D.off[l + 1], D.off[l], i3, d3, nullptr, nullptr, nullptr, nullptr,
-                              grid[l + 1] ? 1 : 0, mcap_c, knn_ws[l + 1], st));
-        CHK(roitr_interp3_add(Tl, pl, b1, i3, d3, a1, x0, st));
+        CHK(roitr_interp3_add(Tl, pl, b1, i3[l], d3[l], a1, x0, st));
         CHK(tap(E, st, "dec" + std::to_string(l + 1) + ".0", x0, sizeof(float) * (size_t)Tl * pl));
         CHK(block(E, st, E.dec[l], Tl, x0, g_self[l], ppf_self[l], E.nsample[l], xd[l], order[l]));
         CHK(tap(E, st, "dec" + std::to_string(l + 1) + ".1", xd[l], sizeof(float) * (size_t)Tl * pl));
@@ -1144,29 +1233,18 @@ extern "C" int roitr_engine_forward(void* h, const RoitrForwardIO* io, hipStream
     roitr_prof_end(ROITR_PROF_PH_DEC, st);
     roitr_prof_begin(ROITR_PROF_PH_MATCH, 0.0, st);
     // ---------------- heads (RIGA_v2.py:64-68) and node coordinates (model/model.py:233-235)
-    const float* pts_out = io->points_out ? io->points_out : io->points_geom;
-    float* node_xyz = io->node_xyz ? io->node_xyz : A.get<float>((size_t)T4 * 3);
+    ROITR_HIP(hipStreamWaitEvent(st, E.ev[7], 0));   // node coordinates, partition and ground-truth side outputs (side stream)
     float* node_feats = io->node_feats ? io->node_feats : A.get<float>((size_t)T4 * C4);
     float* point_feats = io->point_feats ? io->point_feats : A.get<float>((size_t)T1 * C4);
     {
-        int* c3 = A.get<int>(V.T[2]);
-        int* c4 = A.get<int>(T4);
         float* cp = A.get<float>((size_t)T4 * C4);
         if (A.fail) { roitr_set_error("arena exhausted (heads)", __FILE__, __LINE__); return ROITR_ERR_ARG; }
-        CHK(roitr_compose_idx(V.T[2], down[1], down[2], c3, st));  // level-3 nodes as level-1 rows
-        CHK(roitr_compose_idx(T4, c3, down[3], c4, st));
-        CHK(roitr_gather_rows(T4, 3, pts_out, c4, 0, node_xyz, st));
         CHK(gemm(st, T4, gfeat, E.coarse_proj, cp));
         CHK(roitr_l2_normalize(T4, C4, cp, node_feats, st));
         CHK(gemm(st, T1, xd[0], E.fine_proj, point_feats));
     }
 
     // ---------------- point-to-node partition, coarse matching, patches, OT, fine matching
-    int* node_masks = io->node_masks ? io->node_masks : A.get<int>(T4);
-    int* kidx = io->node_knn_idx ? io->node_knn_idx : A.get<int>((size_t)T4 * LIM);
-    int* kmask = io->node_knn_mask ? io->node_knn_mask : A.get<int>((size_t)T4 * LIM);
-    int* p2n = A.get<int>(T1);
-    float* p2nd = A.get<float>(T1);
     int* tgt_corr = io->tgt_corr ? io->tgt_corr : A.get<int>((size_t)B * P_);
     int* src_corr = io->src_corr ? io->src_corr : A.get<int>((size_t)B * P_);
     float* cscore = io->corr_scores ? io->corr_scores : A.get<float>((size_t)B * P_);
@@ -1193,8 +1271,6 @@ extern "C" int roitr_engine_forward(void* h, const RoitrForwardIO* io, hipStream
     float* cxy = A.get<float>((size_t)B * xystride);
     if (A.fail) { roitr_set_error("arena exhausted (matching)", __FILE__, __LINE__); return ROITR_ERR_ARG; }
 
-    CHK(roitr_point_to_node_partition(NC, T1, T4, pts_out, D.off[0], node_xyz, D.off[3], D.cloud_of_node, LIM, p2n, p2nd, node_masks, kidx,
-                                      kmask, st));
     {   // all tgt_b x src_b feature dot products in one ragged-batched GEMM (rows: tgt cloud B+b, cols: src cloud b)
         RoitrGemm g; memset(&g, 0, sizeof(g));
         g.M = V.nmax[3]; g.N = V.nmax[3]; g.K = C4; g.A = node_feats; g.lda = C4; g.W = node_feats; g.ldw = C4; g.alpha = 1.f;
@@ -1250,46 +1326,6 @@ extern "C" int roitr_engine_forward(void* h, const RoitrForwardIO* io, hipStream
         fm.flags = flags; fm.counts = counts; fm.offsets = offsets; fm.n_out = n_out;
         fm.out_row_pts = o_t; fm.out_col_pts = o_s; fm.out_scores = o_sc; fm.out_patch = io->out_patch; fm.out_cap = (long)cap;
         CHK(roitr_fine_matching(&fm, st));
-    }
-    // ---------------- ground-truth side outputs (RIGA_v2.py:91-116), only when rot / trans are given
-    if (io->rot && io->trans && (io->gt_node_occ || io->gt_corr_idx)) {
-        const int Tp = T1 + NC;                  // padded rows
-        const int Ts = V.off[0][B - 1];          // source rows
-        const int Tsp = Ts + B, Ttp = Tp - Tsp;  // padded source / target rows
-        float* pad = A.get<float>((size_t)Tp * 3);
-        int* poff = A.get<int>((size_t)3 * B + 4);
-        float* d2p = A.get<float>(Tp);
-        void* ws_s = A.get<char>(roitr_knn_workspace_bytes(B, Tsp, Ttp));
-        void* ws_t = A.get<char>(roitr_knn_workspace_bytes(B, Ttp, Tsp));
-        if (A.fail) { roitr_set_error("arena exhausted (gt)", __FILE__, __LINE__); return ROITR_ERR_ARG; }
-        CHK(roitr_build_padded_clouds(B, T1, pts_out, D.off[0], io->rot, io->trans, pad, poff, st));
-        const float* src_p = pad; const float* tgt_p = pad + (size_t)Tsp * 3;
-        const int* off_s = poff; const int* off_t = poff + 2 * B;
-        const int use_grid = (Tsp > GRID_MIN_POINTS * B) ? 1 : 0;
-        if (io->gt_node_occ) {
-            // kNN(1) of every padded target point among the transformed padded source points, and back (l.509-510)
-            if (use_grid) CHK(roitr_knn_build_grid(B, Tsp, Ttp, src_p, off_s, ws_s, st));
-            const float occ_cap2 = E.cfg.occlusion_radius * E.cfg.occlusion_radius * 1.01f;   // only `distance < radius` is read
-            CHK(roitr_knn_within(B, Tsp, Ttp, src_p, tgt_p, off_s, off_t, occ_cap2, d2p + Tsp, use_grid, Ttp, ws_s, st));
-            if (use_grid) CHK(roitr_knn_build_grid(B, Ttp, Tsp, tgt_p, off_t, ws_t, st));
-            CHK(roitr_knn_within(B, Ttp, Tsp, tgt_p, src_p, off_t, off_s, occ_cap2, d2p, use_grid, Tsp, ws_t, st));
-            CHK(roitr_node_occlusion_score(T4, LIM, D.cloud_of_node, D.off[0], kidx, kmask, node_masks, d2p, E.cfg.occlusion_radius,
-                                           io->gt_node_occ, st));
-        }
-        if (io->gt_corr_idx && io->gt_corr_overlaps && io->gt_corr_count) {
-            const long ms = (long)V.nmax[3] * V.nmax[3];
-            float* om = A.get<float>((size_t)B * ms);
-            float* nt_ = A.get<float>((size_t)T4 * 3);
-            float* nr_ = A.get<float>(T4);
-            if (A.fail) { roitr_set_error("arena exhausted (gt)", __FILE__, __LINE__); return ROITR_ERR_ARG; }
-            RoitrNodeCorr nc; memset(&nc, 0, sizeof(nc));
-            nc.pairs = B; nc.limit = LIM; nc.max_nodes = V.nmax[3]; nc.pos_radius = E.cfg.matching_radius;
-            nc.nodes = node_xyz; nc.node_offset = D.off[3]; nc.node_masks = node_masks; nc.points = pts_out; nc.pt_offset = D.off[0];
-            nc.knn_idx = kidx; nc.knn_mask = kmask; nc.rot = io->rot; nc.trans = io->trans; nc.overlap = om; nc.mat_stride = ms;
-            nc.out_idx = io->gt_corr_idx; nc.out_overlap = io->gt_corr_overlaps; nc.out_count = io->gt_corr_count;
-            nc.n_nodes = T4; nc.nodes_t = nt_; nc.radius = nr_;
-            CHK(roitr_node_correspondences(&nc, st));
-        }
     }
     roitr_prof_end(ROITR_PROF_PH_MATCH, st);
     roitr_prof_end(ROITR_PROF_PH_FORWARD, st);
