@@ -61,3 +61,32 @@ def test_forward_is_deterministic_and_batch_invariant():
     for x, y in zip(a, b):
         _same(x, y)
     _same(c[0], a[2]); _same(c[1], a[0])
+
+
+def test_batches_in_flight_do_not_interfere():
+    """Two forwards enqueued back to back (what the tester and bench.py do) share the engine's scratch arena, and each of them
+    runs its geometry chain -- FPS, grids, kNN, the embedding E, partition, ground-truth outputs -- on the engine's side stream
+    beside its feature path: the second call's side stream must not touch the arena before the first call is through, and every
+    side-stream product must be joined before it is read.  Results of calls that overlap other calls, in both orders and with
+    ground-truth outputs on and off, are bit-identical to the same pairs run alone."""
+    from roitr_amd.synthetic import make_pair
+    from tests.gpu_util import build_model, pair_to_device
+    model = build_model("3DMatch")
+    small = [pair_to_device(make_pair(n, config=2, pair_index=i)) for i, n in enumerate((1024, 1500))]
+    big = [pair_to_device(make_pair(n, config=2, pair_index=10 + i)) for i, n in enumerate((5000, 4000, 3000, 5000, 2048, 4500))]
+    with torch.no_grad():
+        ref_small = model.forward_batch(small)
+        torch.cuda.synchronize()
+        ref_big = model.forward_batch(big)
+        torch.cuda.synchronize()
+        for rounds in range(3):
+            hs = [model.launch_batch(big), model.launch_batch(small), model.launch_batch(big, want_gt=False), model.launch_batch(small)]
+            got = [model.finish_batch(h) for h in hs]
+            for x, y in zip(got[0], ref_big):
+                _same(x, y)
+            for x, y in zip(got[1], ref_small):
+                _same(x, y)
+            for x, y in zip(got[3], ref_small):
+                _same(x, y)
+            for x, y in zip(got[2], ref_big):
+                assert torch.equal(x["corr_scores"], y["corr_scores"]) and torch.equal(x["src_corr_points"], y["src_corr_points"])
