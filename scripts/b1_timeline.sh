@@ -10,8 +10,8 @@ for f in glob.glob("$out/t/**/*kernel_trace.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         rows.append((int(r["Start_Timestamp"]),int(r["End_Timestamp"]),re.sub(r"\(anonymous namespace\)::","",r["Kernel_Name"]).split("(")[0][-40:], r.get("Queue_Id","")))
 rows.sort()
-# take the last 20 forwards: find fps_kernel<256, 20> launches as forward markers
-marks=[i for i,r in enumerate(rows) if "fps_kernel<256, 20>" in r[2]]
+# take the last 20 forwards: the first transformer of the network (one launch per forward) marks them
+marks=[i for i,r in enumerate(rows) if "local_first_kernel" in r[2]]
 if len(marks)>22:
     a,b=marks[-21],marks[-1]
     seg=rows[a:b]; nf=20

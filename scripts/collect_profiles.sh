@@ -1,15 +1,25 @@
 #!/bin/bash
 # Round profile collection on the GPU box (run through gpurun from the repo root):
-#   bash scripts/collect_profiles.sh r02
-# 1) bench.py JSON lines (config 2 default, one pair per step, config 3, config 4 bf16 / f32),
-# 2) rocprofv3 --kernel-trace --stats (csv) of the default bench,
-# 3) two separate --pmc passes (FETCH_SIZE, WRITE_SIZE; kernel-trace only) of the default bench,
+#   bash scripts/collect_profiles.sh r03
+# 1) rocprofv3 --kernel-trace --stats (csv) of the default bench,
+# 2) two separate --pmc passes (FETCH_SIZE, WRITE_SIZE; kernel-trace only) of the default bench -> profiles/pmc_traffic.json,
+# 3) bench.py JSON lines (config 2 default, one pair per step, config 3, config 4 bf16 / f32, the driver's command),
 # 4) bench.py --config 5 (kNN(64) + PPF stress) + its SQ counter pass (scripts/knn_config5_sq.sh) + the SQ pass of the forward.
 set -u
 tag=${1:-r02}
 export TMPDIR=/tmp
 out=gpurun_out/$tag
 rm -rf $out; mkdir -p $out
+P="python bench.py --no-cpu-baseline --no-single-pair --no-rccl-selftest --no-profile-pass"
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o s -- $P --steps 4 --warmup 1 > $out/stats.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -o f -- $P --steps 1 --warmup 1 > $out/pmc_fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -o w -- $P --steps 1 --warmup 1 > $out/pmc_write.log 2>&1
+python scripts/pmc_summary.py $out/pmc_fetch/f_counter_collection.csv $out/pmc_write/w_counter_collection.csv $out/${tag}_pmc_traffic.json 512 2 2
+# the bench lines below read roofline.traffic from THIS round's counter passes
+cp $out/${tag}_pmc_traffic.json profiles/pmc_traffic.json
+python scripts/prof_summary.py $out/stats s 5 45 > $out/${tag}_kernel_summary.txt
+cp $out/stats/s_kernel_stats.csv $out/${tag}_kernel_stats.csv
+python scripts/hbm_table.py $out $tag > $out/${tag}_hbm_gbs.txt
 python bench.py > $out/bench.log 2>&1
 tail -1 $out/bench.log > $out/${tag}_bench.json
 python bench.py --pairs-per-step 1 --steps 200 --warmup 20 --no-cpu-baseline > $out/bench_b1.log 2>&1
@@ -20,14 +30,8 @@ python bench.py --config 4 --no-single-pair > $out/bench_c4.log 2>&1
 tail -1 $out/bench_c4.log > $out/${tag}_bench_config4_bf16.json
 python bench.py --config 4 --dtype f32 --no-cpu-baseline --no-single-pair > $out/bench_c4f.log 2>&1
 tail -1 $out/bench_c4f.log > $out/${tag}_bench_config4_f32.json
-P="python bench.py --no-cpu-baseline --no-single-pair --no-rccl-selftest --no-profile-pass"
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o s -- $P --steps 4 --warmup 1 > $out/stats.log 2>&1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -o f -- $P --steps 1 --warmup 1 > $out/pmc_fetch.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -o w -- $P --steps 1 --warmup 1 > $out/pmc_write.log 2>&1
-python scripts/pmc_summary.py $out/pmc_fetch/f_counter_collection.csv $out/pmc_write/w_counter_collection.csv $out/${tag}_pmc_traffic.json 512 2 2
-python scripts/prof_summary.py $out/stats s 5 45 > $out/${tag}_kernel_summary.txt
-cp $out/stats/s_kernel_stats.csv $out/${tag}_kernel_stats.csv
-python scripts/hbm_table.py $out $tag > $out/${tag}_hbm_gbs.txt
+python bench.py --gpus 1 --steps 20 --warmup 5 > $out/bench_driver.log 2>&1
+tail -1 $out/bench_driver.log > $out/${tag}_bench_driver_cmd.json
 python bench.py --config 5 > $out/bench_c5.log 2>&1
 tail -1 $out/bench_c5.log > $out/${tag}_bench_config5.json
 bash scripts/knn_config5_sq.sh $out/knn5sq > $out/${tag}_knn_config5_sq.txt 2>&1
