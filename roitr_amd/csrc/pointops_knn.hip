@@ -1552,7 +1552,10 @@ int knnquery_impl(int b, int n, int m, int nsample, const float* xyz, const floa
         // dominated and the grid is fine enough for the radius rule -- the level-1 self query (need 10, 6 points per cell: 3.56 ->
         // 2.24 ms) -- and loses on the 3-NN interpolation queries (need 4: the 4-deep chain was never the cost, 0.84 -> 4.0 ms)
         // and, with grids of 6 points per cell, on need 18 (the sphere of one cell size holds 25 points: most lanes would hand
-        // their query over; with 9 per cell 3 x 1.0 -> 3 x (2.1 + 0.45) ms).  So: need 5..10 only.
+        // their query over; with 9 per cell 3 x 1.0 -> 3 x (2.1 + 0.45) ms; re-measured at the end of round 3 with a 48 / 56-slot table and
+        // target counts of 1.4 - 2.0 (nsample + 1): 8 - 15 % of the need-18 queries still go to the ring kernel -- the clouds are
+        // surface-like, the count inside a radius does not follow the box's volume density -- kNN 12.7 -> 17.4 - 19.9 ms per step).
+        // So: need 5..10 only.
         if (need <= 2) LANE_CASE(2);
         else if (need <= 4) LANE_CASE(4);
         else if (need <= 10) { if (exact_k) PREF_CASE(10, 40); else LANE_CASE(10); }
