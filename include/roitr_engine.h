@@ -138,6 +138,30 @@ typedef struct RoitrLocalAttn {
 int roitr_local_attention(const RoitrLocalAttn* a, roitr_stream_t stream);
 int roitr_build_pfold(int H, int heads, const float* wpe, const float* bpe, float* pfold, roitr_stream_t stream);
 
+/* TransitionDown form of the local PPF attention with the key / value projections folded into the query side
+ * (csrc/local_attn.hip local_attn_fold_kernel; attention.py:152-200 behind ppftransformer.py:227-253).  M query nodes, 16 neighbours
+ * each among the rows of x (N_in, in_dim):
+ *     score(h, j) = scale * ( qt[node][h] . x_j + (Wpe_h^T q_h) . ppf_j )       (terms constant over j are dropped: softmax)
+ *     xbar[node][h] = sum_j a_hj x_j            (M, 4, in_dim)  -> the caller applies Wv'_h and bv'_h (one batched GEMM)
+ *     vpart[node]   = Wvpe_h pbar_h + bvpe_h    (M, H)          -> the positional value term; attention output = vpart + Wv' xbar + bv'
+ * with qt[node][h] = Wk'_h^T q_h (M, 4, in_dim) supplied by the caller.  fp32, 4 heads, K = 16,
+ * (in_dim, H) in {(64, 128), (128, 256), (256, 256)}; everything 16-byte aligned. */
+typedef struct RoitrLocalAttnFold {
+    int M, in_dim, H;
+    const float* x; int ldx;
+    const float* q; int ldq;      /* (M, H) query rows (for the PPF coefficients) */
+    const float* qt;              /* (M, 4 * in_dim) */
+    const int* group_idx; const float* ppf;   /* (M, 16), (M, 16, 4) */
+    const float* wpe;             /* (H, 4) */
+    const float* wvpe; const float* bvpe;     /* (H, 4), (H) */
+    float scale;
+    float* xbar;                  /* (M, 4 * in_dim) */
+    float* vpart;                 /* (M, H) */
+    const void* node_order;       /* optional float4[M]: visiting order */
+} RoitrLocalAttnFold;
+int roitr_local_attention_fold(const RoitrLocalAttnFold* a, roitr_stream_t stream);
+int roitr_local_attention_fold_supported(int in_dim, int H, int K);
+
 /* The block form of the local PPF transformer in ONE launch (csrc/local_block.hip), for the 64- / 128-wide levels:
  *   out = relu( bn2( out_proj( LN( linear(att) + in_proj(x) ) ) ) + x )     model/model.py:131-142, ppftransformer.py:227-253
  * with att = local PPF attention of q = x Wq^T + bq over the neighbours' k | v rows.  The caller supplies kv (M, 2H) = the k | v

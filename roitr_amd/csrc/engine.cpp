@@ -55,6 +55,7 @@ struct LocalT {  // LocalPPFTransformer (+ derived weights)
     // TransitionDown transformers (in_dim != H): [q|qp|k|v] straight from the layer input, W' = Wqkv Win (R x in_dim),
     // b' = Wqkv b_in + bqkv -- in_proj and the q/k/v projections are two linear maps with nothing in between
     float* wqkv_x = nullptr; float* bqkv_x = nullptr; unsigned short* wqkv_x_b = nullptr;
+    float* wkT_x = nullptr;                        // (in_dim, H): transpose of the k rows of wqkv_x (TransitionDown fold, fp32)
     // block transformers in fp32: linear(att) + in_proj(x) as ONE GEMM over the K-concatenated operand [att | x]:
     // wcat = [Wlin | Win] (H x (H + in_dim)), bcat = b_lin + b_in; f = in_proj(x) is then never materialised
     float* wcat = nullptr; float* bcat = nullptr;
@@ -217,7 +218,7 @@ bool ln_fuses(int N, int K, int lda, int ldw)
 // dimension lda_cat (fp32 kernels only)
 int gemm_ln(hipStream_t st, int M, const float* A, const Lin& l, const float* res, const int* res_idx, const float* gamma,
             const float* beta, const float* post, bool relu, float* tmp, float* out, int bf = 0, const float* A_cat = nullptr,
-            int lda_cat = 0, int k_cat = 0)
+            int lda_cat = 0, int k_cat = 0, const float* A2 = nullptr)
 {
     const float* w = l.w;
     const float* b = l.b;
@@ -230,7 +231,7 @@ int gemm_ln(hipStream_t st, int M, const float* A, const Lin& l, const float* re
         memset(&g, 0, sizeof(g));
         g.M = M; g.N = N; g.K = K; g.A = A; g.lda = lda; g.W = w; g.ldw = ldw; g.bias = b; g.alpha = 1.0f; g.C = out; g.ldc = N; g.batch = 1;
         g.ln_gamma = gamma; g.ln_beta = beta; g.ln_res = res; g.ln_res_idx = res_idx; g.ln_post = post; g.ln_relu = relu ? 1 : 0; g.ln_eps = 1e-5f;
-        g.A_cat = A_cat; g.lda_cat = lda_cat; g.k_cat = k_cat;
+        g.A_cat = A_cat; g.lda_cat = lda_cat; g.k_cat = k_cat; g.A2 = A2;   // A2 (optional): the operand is A + A2
         CHK(use_bf16(g, w, l.wb, bf));
         return roitr_gemm(&g, st);
     }
@@ -242,7 +243,7 @@ int gemm_ln(hipStream_t st, int M, const float* A, const Lin& l, const float* re
         g.A_cat = A_cat; g.lda_cat = lda_cat; g.k_cat = k_cat;
         CHK(roitr_gemm(&g, st));
     } else
-    CHK(gemm(st, M, N, K, A, lda, w, ldw, b, tmp, N, false, nullptr, nullptr, 1.0f, l.wb, bf));
+    CHK(gemm(st, M, N, K, A, lda, w, ldw, b, tmp, N, false, nullptr, A2, 1.0f, l.wb, bf));
     return roitr_add_layernorm(M, N, tmp, res, res_idx, gamma, beta, post, relu ? 1 : 0, 1e-5f, out, st);
 }
 
@@ -340,6 +341,12 @@ int fold_local(Engine& E, LocalT& L, hipStream_t st)
         CHK(roitr_transpose(H, I, L.in_proj.w, I, winT, H, st));                       // (in, H)
         CHK(gemm(st, R, I, H, L.wqkv, H, winT, H, nullptr, L.wqkv_x, I));               // (R, in) = Wqkv Win
         CHK(gemm(st, 1, R, H, L.in_proj.b, H, L.wqkv, H, L.bqkv, L.bqkv_x, R));         // Wqkv b_in + bqkv
+        if (E.cfg.operand_dtype == 0 && NQ == 0) {
+            // q~_h = Wk'_h^T q_h needs the k rows transposed: (I, H), head h = columns h c .. (csrc/local_attn.hip, fold form)
+            L.wkT_x = A.get<float>((size_t)I * H);
+            if (A.fail) return ROITR_ERR_ARG;
+            CHK(roitr_transpose(H, I, L.wqkv_x + (size_t)(H + NQ) * I, I, L.wkT_x, H, st));
+        }
         if (E.cfg.operand_dtype == 1) {
             L.wqkv_x_b = A.get<unsigned short>((size_t)R * I);
             if (A.fail) return ROITR_ERR_ARG;
@@ -408,6 +415,48 @@ int local_transformer(Engine& E, hipStream_t st, const LocalT& L, int N_in, cons
     if (catf) {}
     else if (folded) CHK(gemm(st, M, x, L.in_proj, f, false, node_idx));
     else CHK(gemm(st, N_in, x, L.in_proj, f));
+    // TransitionDown in fp32: the k | v projections folded into the query side (csrc/local_attn.hip local_attn_fold_kernel) --
+    // q~ = Wk'^T q per head in front, Wv' applied to the attention-weighted INPUT rows behind; the (N_in, 2H) tensor is never formed
+    if (folded && L.wkT_x && NQ == 0 && roitr_local_attention_fold_supported(L.in_dim, H, K)) {
+        const int I = L.in_dim, c = H / HEADS;
+        float* qe = A.get<float>((size_t)M * H);
+        float* qt = A.get<float>((size_t)M * HEADS * I);
+        float* xbar = A.get<float>((size_t)M * HEADS * I);
+        float* vpart = A.get<float>((size_t)M * H);
+        float* val = A.get<float>((size_t)M * H);
+        float* hid = A.get<float>((size_t)M * H);
+        float* y = A.get<float>((size_t)M * H);
+        if (A.fail) { roitr_set_error("arena exhausted (TransitionDown fold)", __FILE__, __LINE__); return ROITR_ERR_ARG; }
+        CHK(gemm(st, M, H, I, x, I, L.wqkv_x, I, L.bqkv_x, qe, H, false, node_idx));
+        {   // qt[(row, h), :] = Wk'_h^T q_h   (batched over heads; no bias: q_h . bk'_h is constant over the neighbours)
+            RoitrGemm gq; memset(&gq, 0, sizeof(gq));
+            gq.M = M; gq.N = I; gq.K = c; gq.A = qe; gq.lda = H; gq.W = L.wkT_x; gq.ldw = H; gq.alpha = 1.f;
+            gq.C = qt; gq.ldc = HEADS * I; gq.batch = HEADS; gq.sA = c; gq.sW = c; gq.sC = I;
+            CHK(roitr_gemm(&gq, st));
+        }
+        RoitrLocalAttnFold a;
+        memset(&a, 0, sizeof(a));
+        a.M = M; a.in_dim = I; a.H = H; a.x = x; a.ldx = I; a.q = qe; a.ldq = H; a.qt = qt; a.group_idx = group; a.ppf = ppf;
+        a.wpe = L.wpe; a.wvpe = L.wvpe; a.bvpe = L.bvpe; a.scale = 1.0f / sqrtf((float)c); a.xbar = xbar; a.vpart = vpart; a.node_order = order;
+        CHK(roitr_local_attention_fold(&a, st));
+        {   // val[:, h-slice] = Wv'_h xbar_h + bv'_h
+            RoitrGemm gv; memset(&gv, 0, sizeof(gv));
+            gv.M = M; gv.N = c; gv.K = I; gv.A = xbar; gv.lda = HEADS * I; gv.W = L.wqkv_x + (size_t)(2 * H) * I; gv.ldw = I;
+            gv.bias = L.bqkv_x + 2 * H; gv.alpha = 1.f; gv.C = val; gv.ldc = H; gv.batch = HEADS; gv.sA = I; gv.sW = (long)c * I; gv.sC = c; gv.sBias = c;
+            CHK(roitr_gemm(&gv, st));
+        }
+        // linear(att) + f -> LayerNorm, att = vpart + val (the sum is formed while the operand is staged)
+        CHK(gemm_ln(st, M, vpart, L.lin, f, nullptr, L.norm_w, L.norm_b, nullptr, false, hid, y, 0, nullptr, 0, 0, val));
+        if (bn2_res) {
+            float* t = A.get<float>((size_t)M * L.out_dim);
+            if (A.fail) return ROITR_ERR_ARG;
+            CHK(gemm_ln(st, M, y, L.out_proj, nullptr, nullptr, L.bn2_w, L.bn2_b, bn2_res, true, t, out));
+        } else {
+            CHK(gemm(st, M, y, L.out_proj, out));
+        }
+        A.off = mark;
+        return 0;
+    }
     // bf16 operand mode: the q | k | v tensor (operands of the attention products) and the attention output (operand of
     // `linear`) are stored bf16 by their producers -- half the bytes of the gather-bound attention kernel
     const bool hb = (folded ? bf16_layer(L.wqkv_x_b, L.in_dim) : bf16_layer(L.wqkv_b, H)) && bf16_layer(L.lin.wb, H);

@@ -232,29 +232,6 @@ __global__ __launch_bounds__(256) void mha_kernel(RoitrMha a)
 // launch at 128 pairs against 0.3-0.4 ms for one pass over E at HBM speed.
 __device__ __forceinline__ float dot4(const float4 a, const float4 b) { return fmaf(a.w, b.w, fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x))); }
 
-// Sum 16 values per lane over the 16 lanes of a DPP row "transposed": lane i ends with the row total of ONE value,
-//     value index  row16_slot(i) = (bit2(i) << 3) | (bit0(i) << 2) | (bit1(i) << 1) | bit3(i),
-// in 15 exchange-and-add steps (8 + 4 + 2 + 1) instead of 16 x 4: a lane keeps the half of its values that matches one of its
-// lane bits and receives the partner's partial sums for that half.  The first exchange uses row_half_mirror (partner = lane ^ 7:
-// nothing is resolved yet, any partner with the other bit 2 will do), then quad_perm lane ^ 1, lane ^ 2 and row_ror:8 (lane ^ 8).
-template <int CTRL> __device__ __forceinline__ float dpp_get(float v)
-{
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
-}
-__device__ __forceinline__ int row16_slot(int i) { return ((i >> 2) & 1) << 3 | (i & 1) << 2 | ((i >> 1) & 1) << 1 | ((i >> 3) & 1); }
-__device__ __forceinline__ float row16_transpose_sum(const float (&v)[16], int lane)
-{
-    const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4, b3 = lane & 8;
-    float w[8], u[4], t[2];
-#pragma unroll
-    for (int m = 0; m < 8; ++m) w[m] = (b2 ? v[8 + m] : v[m]) + dpp_get<0x141>(b2 ? v[m] : v[8 + m]);   // row_half_mirror
-#pragma unroll
-    for (int m = 0; m < 4; ++m) u[m] = (b0 ? w[4 + m] : w[m]) + dpp_get<0xB1>(b0 ? w[m] : w[4 + m]);    // quad_perm [1,0,3,2]
-#pragma unroll
-    for (int m = 0; m < 2; ++m) t[m] = (b1 ? u[2 + m] : u[m]) + dpp_get<0x4E>(b1 ? u[m] : u[2 + m]);    // quad_perm [2,3,0,1]
-    return (b3 ? t[1] : t[0]) + dpp_get<0x128>(b3 ? t[0] : t[1]);                                        // row_ror:8
-}
-
 template <int R>   // R = key rows per wave kept in registers: n <= 4 R
 __global__ __launch_bounds__(256, R <= 20 ? 3 : 2) void mha_geo_kernel(RoitrMha a)
 {

@@ -297,6 +297,127 @@ __global__ __launch_bounds__(256) void local_attn_quad_kernel(RoitrLocalAttn a)
 
 // Pfold (5*NH x H): row h*5+j holds Wpe[h*c + cc][j] (j<4) / bpe[h*c+cc] (j=4) at column h*c+cc, else 0.
 // q_ext weights = [Wq ; Pfold @ Wq], bias = [bq ; Pfold @ bq]  (see header comment).
+// ---------------------------------------------------------------------------------------------------------------
+// TransitionDown form with the key / value projections FOLDED INTO THE QUERY SIDE (round 3).  A TransitionDown transformer has
+// M = N_in / 4 query nodes over the N_in points of the level above, 16 neighbours each (ppftransformer.py:227-253 behind
+// model/model.py:56-80): the launch sequence above projects k | v for EVERY point -- a (N_in, 2H) tensor, 5.2 GB at level 2 of a
+// 512-pair batch, written once and then gathered as 16 rows of 2H floats per node.  Both projections are linear in the point's
+// input row x_j (k_j = Wk' x_j + bk', v_j = Wv' x_j + bv', Wk' / Wv' already folded with in_proj), so per head h
+//     q_h . k_jh          = (Wk'_h^T q_h) . x_j + q_h . bk'_h       -- the second term does not depend on j: softmax drops it
+//     sum_j a_hj v_jh     =  Wv'_h (sum_j a_hj x_j) + bv'_h          -- probabilities sum to 1
+// Here: q~_h = Wk'_h^T q_h (I numbers per head and node, one batched GEMM in front), the kernel gathers the INPUT rows x_j (I floats
+// instead of 2H = 4I), scores them against the four q~_h, and emits xbar_h = sum_j a_hj x_j (4 x I per node; one batched GEMM behind
+// applies Wv'_h) next to the positional value term Wvpe_h pbar_h + bvpe_h.  Same FLOPs as the k | v GEMM it replaces (each point
+// is gathered by 4 nodes on average), a quarter of the gather bytes, no (N_in, 2H) tensor.
+// One wave per node, lane = V = I / 64 consecutive input channels.  The 16 neighbours x 4 heads = 64 wave-wide dot products of a
+// node are reduced TOGETHER: v_permlane32_swap / v_permlane16_swap (gfx950) fold the four DPP rows while keeping one quarter of
+// the values per row (row h ends with head h), row16_transpose_sum finishes inside the row -- lane (h, i) ends with the score of
+// (head h, neighbour row16_slot(i)) in 63 adds instead of 64 x 6.  Softmax, pbar and the probability table are row-local after that.
+typedef unsigned la_u2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float swap32_sum(float a, float b)   // lanes < 32: sum of a over (l, l + 32); lanes >= 32: the same for b
+{
+    const la_u2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(r.x) + __uint_as_float(r.y);
+}
+__device__ __forceinline__ float swap16_sum(float a, float b)   // even rows: sum of a over (row, row + 1); odd rows: the same for b
+{
+    const la_u2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(r.x) + __uint_as_float(r.y);
+}
+__device__ __forceinline__ float row_allmax(float v)
+{
+    v = fmaxf(v, dpp_get<0xB1>(v)); v = fmaxf(v, dpp_get<0x4E>(v)); v = fmaxf(v, dpp_get<0x141>(v)); v = fmaxf(v, dpp_get<0x140>(v));
+    return v;
+}
+
+template <int V, int HQ>   // V = in_dim / 64 (x channels per lane), HQ = H / 64 (q / output channels per lane); K = 16, 4 heads
+__global__ __launch_bounds__(256) void local_attn_fold_kernel(RoitrLocalAttnFold a)
+{
+    constexpr int K = 16, I = 64 * V, H = 64 * HQ;
+    __shared__ __attribute__((aligned(16))) float probs[4][64];   // per wave: [head][neighbour]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int slot = xcd_block_id((a.M + 3) >> 2) * 4 + wave;
+    if (slot >= a.M) return;
+    int nd = slot;
+    if (a.node_order) nd = __float_as_int(reinterpret_cast<const float4*>(a.node_order)[slot].w);
+    const int node = __builtin_amdgcn_readfirstlane(nd);
+    const int h = lane >> 4, i16 = lane & 15, kk_l = row16_slot(i16);
+    // ---- round trip 1: addressed by the node id
+    const int g = a.group_idx[(size_t)node * K + i16];
+    float qt[4][V], qv[HQ];
+#pragma unroll
+    for (int hh = 0; hh < 4; ++hh) VecLoad<V>::ld(a.qt + ((size_t)node * 4 + hh) * I + lane * V, qt[hh]);
+    VecLoad<HQ>::ld(a.q + (size_t)node * a.ldq + lane * HQ, qv);
+    const float4 pf = reinterpret_cast<const float4*>(a.ppf)[(size_t)node * K + kk_l];   // this lane's neighbour
+    // ---- round trip 2: the input rows of the 16 neighbours
+    float xr[K][V];
+#pragma unroll
+    for (int kk = 0; kk < K; ++kk) {
+        const int gk = __builtin_amdgcn_readlane(g, kk);
+        VecLoad<V>::ld(a.x + (size_t)gk * a.ldx + lane * V, xr[kk]);
+    }
+    // u_h = Wpe_h^T q_h: the PPF coefficients of the score (q_h . bpe_h is constant over the neighbours: dropped with q_h . bk'_h)
+    float u0 = 0.f, u1 = 0.f, u2 = 0.f, u3 = 0.f;
+#pragma unroll
+    for (int i = 0; i < HQ; ++i) {
+        const float4 w = reinterpret_cast<const float4*>(a.wpe)[lane * HQ + i];
+        u0 = fmaf(w.x, qv[i], u0); u1 = fmaf(w.y, qv[i], u1); u2 = fmaf(w.z, qv[i], u2); u3 = fmaf(w.w, qv[i], u3);
+    }
+    u0 = row_allsum(u0); u1 = row_allsum(u1); u2 = row_allsum(u2); u3 = row_allsum(u3);
+    // ---- 64 partial dot products per lane, reduced over the wave in three transposing stages
+    float z[16];
+    {
+        float w[32];
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+            const int h0 = i >> 4, k0 = i & 15;      // value i = (head h0, neighbour k0), value i + 32 = (head h0 + 2, neighbour k0)
+            float d0 = 0.f, d1 = 0.f;
+#pragma unroll
+            for (int c = 0; c < V; ++c) { d0 = fmaf(qt[h0][c], xr[k0][c], d0); d1 = fmaf(qt[h0 + 2][c], xr[k0][c], d1); }
+            w[i] = swap32_sum(d0, d1);
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) z[i] = swap16_sum(w[i], w[i + 16]);
+    }
+    // row h now holds, lane for lane, the 4-row sums of head h's 16 values
+    const float tot = row16_transpose_sum(z, lane);
+    const float s = (tot + (u0 * pf.x + u1 * pf.y + u2 * pf.z + u3 * pf.w)) * a.scale;
+    const float mx = row_allmax(s);
+    const float e = expf(s - mx);
+    const float p = e / row_allsum(e);
+    probs[wave][h * 16 + kk_l] = p;
+    // pbar_h = sum_k p(h, k) ppf_k (every lane of row h)
+    const float pb0 = row_allsum(p * pf.x), pb1 = row_allsum(p * pf.y), pb2 = row_allsum(p * pf.z), pb3 = row_allsum(p * pf.w);
+    {
+        float o[HQ], bias[HQ];
+        VecLoad<HQ>::ld(a.bvpe + lane * HQ, bias);
+#pragma unroll
+        for (int i = 0; i < HQ; ++i) {
+            const float4 w = reinterpret_cast<const float4*>(a.wvpe)[lane * HQ + i];
+            o[i] = w.x * pb0 + w.y * pb1 + w.z * pb2 + w.w * pb3 + bias[i];
+        }
+        VecLoad<HQ>::st(a.vpart + (size_t)node * H + lane * HQ, o);
+    }
+    lds_fence();
+    // ---- xbar_h = sum_k p(h, k) x_k: the probabilities of a head are wave-uniform LDS broadcasts
+#pragma unroll
+    for (int hh = 0; hh < 4; ++hh) {
+        float acc[V];
+#pragma unroll
+        for (int c = 0; c < V; ++c) acc[c] = 0.f;
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+            const float4 p4 = reinterpret_cast<const float4*>(probs[wave])[hh * 4 + q4];
+#pragma unroll
+            for (int c = 0; c < V; ++c) {
+                acc[c] = fmaf(p4.x, xr[4 * q4][c], acc[c]); acc[c] = fmaf(p4.y, xr[4 * q4 + 1][c], acc[c]);
+                acc[c] = fmaf(p4.z, xr[4 * q4 + 2][c], acc[c]); acc[c] = fmaf(p4.w, xr[4 * q4 + 3][c], acc[c]);
+            }
+        }
+        VecLoad<V>::st(a.xbar + ((size_t)node * 4 + hh) * I + lane * V, acc);
+    }
+}
+
 __global__ void build_pfold_kernel(int H, int NH, const float* __restrict__ wpe, const float* __restrict__ bpe, float* __restrict__ pf)
 {
     const int t = blockIdx.x * 256 + threadIdx.x;
@@ -350,6 +471,38 @@ extern "C" int roitr_local_attention(const RoitrLocalAttn* a, hipStream_t stream
     roitr_prof_end(ROITR_PROF_LOCAL_ATTN, stream);
     ROITR_LAUNCH_CHECK();
     return ROITR_OK;
+}
+
+extern "C" int roitr_local_attention_fold(const RoitrLocalAttnFold* a, hipStream_t stream)
+{
+    if (a->M <= 0) return ROITR_OK;
+    const int v = a->in_dim / 64, hq = a->H / 64;
+    if (a->in_dim % 64 || a->H % 64 || (v != 1 && v != 2 && v != 4) || (hq != 2 && hq != 4) || !a->wpe || !a->wvpe || !a->bvpe) {
+        roitr_set_error("local_attention_fold: (in_dim, H) must be (64, 128), (128, 256) or (256, 256) with the folded PPF weights given", __FILE__, __LINE__);
+        return ROITR_ERR_UNSUPPORTED;
+    }
+    if ((a->ldx | a->ldq) % 4 || (((uintptr_t)a->x | (uintptr_t)a->q | (uintptr_t)a->qt | (uintptr_t)a->xbar | (uintptr_t)a->vpart | (uintptr_t)a->ppf |
+                                   (uintptr_t)a->wpe | (uintptr_t)a->wvpe | (uintptr_t)a->bvpe) & 15)) {
+        roitr_set_error("local_attention_fold: rows and arrays must be 16-byte aligned", __FILE__, __LINE__);
+        return ROITR_ERR_UNSUPPORTED;
+    }
+    // algorithmic bytes: q and q~ rows, 16 gathered input rows, ppf + idx in; xbar and the positional value row out
+    roitr_prof_begin(ROITR_PROF_LOCAL_ATTN, (double)a->M * (a->H * 4.0 + 4.0 * a->in_dim * 4 + 16.0 * (a->in_dim * 4.0 + 20.0) + 4.0 * a->in_dim * 4 + a->H * 4.0), stream);
+    const int grid = xcd_grid(div_up(a->M, 4));
+#define LF_CASE(VV, QQ) local_attn_fold_kernel<VV, QQ><<<grid, 256, 0, stream>>>(*a)
+    if (v == 1 && hq == 2) LF_CASE(1, 2);
+    else if (v == 2 && hq == 4) LF_CASE(2, 4);
+    else if (v == 4 && hq == 4) LF_CASE(4, 4);
+    else { roitr_prof_end(ROITR_PROF_LOCAL_ATTN, stream); return ROITR_ERR_UNSUPPORTED; }
+#undef LF_CASE
+    roitr_prof_end(ROITR_PROF_LOCAL_ATTN, stream);
+    ROITR_LAUNCH_CHECK();
+    return ROITR_OK;
+}
+
+extern "C" int roitr_local_attention_fold_supported(int in_dim, int H, int K)
+{
+    return K == 16 && ((in_dim == 64 && H == 128) || (in_dim == 128 && H == 256) || (in_dim == 256 && H == 256)) ? 1 : 0;
 }
 
 extern "C" int roitr_build_pfold(int H, int heads, const float* wpe, const float* bpe, float* pfold, hipStream_t stream)

@@ -305,6 +305,39 @@ def geo_embed(d_idx, a_idx, div_term, w_d, b_d, w_a, b_a, split=False, bf16=Fals
     return out
 
 
+class _LocalAttnFold(ctypes.Structure):
+    _fields_ = [("M", ctypes.c_int), ("in_dim", ctypes.c_int), ("H", ctypes.c_int),
+                ("x", ctypes.c_void_p), ("ldx", ctypes.c_int), ("q", ctypes.c_void_p), ("ldq", ctypes.c_int),
+                ("qt", ctypes.c_void_p), ("group_idx", ctypes.c_void_p), ("ppf", ctypes.c_void_p),
+                ("wpe", ctypes.c_void_p), ("wvpe", ctypes.c_void_p), ("bvpe", ctypes.c_void_p), ("scale", ctypes.c_float),
+                ("xbar", ctypes.c_void_p), ("vpart", ctypes.c_void_p), ("node_order", ctypes.c_void_p)]
+
+
+def local_attention_fold(x, q, qt, group_idx, ppf, wpe, wvpe, bvpe, node_order=None):
+    """TransitionDown form of the local PPF attention with the key / value projections folded into the query side
+    (csrc/local_attn.hip local_attn_fold_kernel; include/roitr_engine.h RoitrLocalAttnFold).  x (N_in, I) input rows, q (M, H),
+    qt (M, 4, I) = Wk'_h^T q_h per head, group_idx (M, 16) int32 rows of x, ppf (M, 16, 4), wpe / wvpe (H, 4), bvpe (H).
+    Returns (xbar (M, 4, I) = sum_j a_hj x_j, vpart (M, H) = Wvpe_h pbar_h + bvpe_h): the attention output of the unfolded form is
+    vpart + [Wv'_h xbar_h + bv'_h]_h."""
+    f = lambda t: t.contiguous().float()
+    x, q, qt, ppf, wpe, wvpe, bvpe = f(x), f(q), f(qt), f(ppf), f(wpe), f(wvpe), f(bvpe)
+    group_idx = _i32c(group_idx)
+    M, H, I = int(q.shape[0]), int(q.shape[1]), int(x.shape[1])
+    if int(group_idx.shape[1]) != 16:
+        raise L.RoitrError("local_attention_fold: 16 neighbours per node")
+    xbar = torch.empty((M, 4, I), dtype=torch.float32, device=x.device)
+    vpart = torch.empty((M, H), dtype=torch.float32, device=x.device)
+    a = _LocalAttnFold()
+    a.M, a.in_dim, a.H = M, I, H
+    a.x, a.ldx, a.q, a.ldq, a.qt = L.ptr(x), I, L.ptr(q), H, L.ptr(qt)
+    a.group_idx, a.ppf, a.wpe, a.wvpe, a.bvpe = L.ptr(group_idx), L.ptr(ppf), L.ptr(wpe), L.ptr(wvpe), L.ptr(bvpe)
+    a.scale, a.xbar, a.vpart = 1.0 / float(H // 4) ** 0.5, L.ptr(xbar), L.ptr(vpart)
+    no = f(node_order) if node_order is not None else None
+    a.node_order = L.ptr(no)
+    L.check(L.lib().roitr_local_attention_fold(ctypes.byref(a), L.stream_ptr()), "local_attention_fold")
+    return xbar, vpart
+
+
 class _LocalBlock(ctypes.Structure):
     _fields_ = [("M", ctypes.c_int), ("K", ctypes.c_int), ("H", ctypes.c_int),
                 ("x", ctypes.c_void_p), ("kv", ctypes.c_void_p), ("group_idx", ctypes.c_void_p), ("ppf", ctypes.c_void_p),

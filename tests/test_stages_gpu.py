@@ -477,3 +477,49 @@ def test_local_block_against_float64(H, K, M, order):
     ref = np.maximum(ln(y @ D["wout"].T + D["bout"], D["bn2_w"], D["bn2_b"]) + X, 0.0)
     err = np.abs(got - ref).max()
     assert err < 3e-5, err
+
+
+@pytest.mark.parametrize("I,H,M,N_in", [(64, 128, 1000, 4000), (128, 256, 517, 2100), (256, 256, 130, 700)])
+def test_local_attention_fold_against_the_unfolded_form(I, H, M, N_in):
+    """csrc/local_attn.hip local_attn_fold_kernel (the TransitionDown layers of the fp32 engine): scores from q~_h = Wk_h^T q_h
+    against the gathered INPUT rows, outputs xbar_h = sum_j a_hj x_j and the positional value term -- against the unfolded form
+    (k | v projected per point, attention.py:152-200) in float64.  The terms the fold drops (q_h . bk_h, q_h . bpe_h) are
+    constant over the neighbours of a node: the float64 reference keeps them, the softmax must not see a difference."""
+    from roitr_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(I + H + M)
+    c = H // 4
+    x = torch.randn((N_in, I), generator=g, dtype=torch.float64)
+    q = torch.randn((M, H), generator=g, dtype=torch.float64)
+    wk = torch.randn((H, I), generator=g, dtype=torch.float64) / I ** 0.5
+    bk = torch.randn((H,), generator=g, dtype=torch.float64)
+    wv = torch.randn((H, I), generator=g, dtype=torch.float64) / I ** 0.5
+    bv = torch.randn((H,), generator=g, dtype=torch.float64)
+    wpe = torch.randn((H, 4), generator=g, dtype=torch.float64)
+    bpe = torch.randn((H,), generator=g, dtype=torch.float64)
+    wvpe = torch.randn((H, 4), generator=g, dtype=torch.float64)
+    bvpe = torch.randn((H,), generator=g, dtype=torch.float64)
+    grp = torch.randint(0, N_in, (M, 16), generator=g)
+    ppf = torch.rand((M, 16, 4), generator=g, dtype=torch.float64) * 3.0
+    # ---- unfolded float64 reference
+    k = (x @ wk.T + bk)[grp].reshape(M, 16, 4, c)
+    v = (x @ wv.T + bv)[grp].reshape(M, 16, 4, c)
+    p = (ppf @ wpe.T + bpe).reshape(M, 16, 4, c)
+    vp = (ppf @ wvpe.T + bvpe).reshape(M, 16, 4, c)
+    qh = q.reshape(M, 1, 4, c)
+    s = ((qh * k).sum(-1) + (qh * p).sum(-1)) / c ** 0.5                    # (M, 16, 4)
+    a = torch.softmax(s, dim=1)
+    ref = (a[..., None] * (v + vp)).sum(1).reshape(M, H)
+    # ---- folded form through the kernel (q~ and the value projection in float64 around it: only the kernel is under test)
+    qt = torch.einsum("mhc,hci->mhi", q.reshape(M, 4, c), wk.reshape(4, c, I))
+    xbar, vpart = ops.local_attention_fold(x.float().cuda(), q.float().cuda(), qt.float().cuda(), grp.to(torch.int32).cuda(), ppf.float().cuda(),
+                                           wpe.float().cuda(), wvpe.float().cuda(), bvpe.float().cuda())
+    val = torch.einsum("mhi,hci->mhc", xbar.double().cpu(), wv.reshape(4, c, I)).reshape(M, H) + bv
+    got = vpart.double().cpu() + val
+    scale_ = ref.abs().mean().item()
+    err = (got - ref).abs().max().item() / scale_
+    assert err < 2e-5, err
+    # xbar rows are convex combinations of the gathered rows
+    lo = x[grp].min(1).values[:, None, :].expand(M, 4, I) - 1e-5
+    hi = x[grp].max(1).values[:, None, :].expand(M, 4, I) + 1e-5
+    xb = xbar.double().cpu()
+    assert bool(((xb >= lo) & (xb <= hi)).all())
