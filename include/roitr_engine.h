@@ -49,6 +49,11 @@ typedef struct RoitrGemm {
      * index / gather as A, leading dimension lda_cat), i.e. C = [A | A_cat] @ W^T with W (N, K), K = k_cat + width(A_cat);
      * k_cat % 32 == 0.  Lets `linear(att) + in_proj(x)` of a local transformer run as ONE GEMM. */
     const float* A_cat; int lda_cat; int k_cat;
+    /* optional, fused LayerNorm epilogue of the fp32 kernel only: the three-nearest-neighbour interpolation of TransitionUp
+     * (pointops.py:168-182 behind model/model.py:112-116) added AFTER the activation,
+     *   C[r,:] += sum_k w_k ip_feat[ip_idx[3 r + k], :],   w_k = (1 / (sqrt(ip_dist2[3 r + k]) + 1e-8)) / sum of the three,
+     * ip_feat rows N floats, dense: `linear1(x1) + interpolation(...)` in the launch that computes linear1. */
+    const float* ip_feat; const int* ip_idx; const float* ip_dist2;
 } RoitrGemm;
 #define ROITR_BF16_W 1
 #define ROITR_BF16_A 2
@@ -63,6 +68,11 @@ int roitr_f32_to_bf16(long n, const float* src, unsigned short* dst, roitr_strea
  * attention.py:319, model/model.py:138-140 (bn2, += identity, relu), geoattention.py:50,161,241. */
 int roitr_add_layernorm(int M, int C, const float* x, const float* res, const int* res_idx, const float* gamma,
                         const float* beta, const float* post_add, int relu, float eps, float* out, roitr_stream_t stream);
+/* the same followed by the three-nearest-neighbour interpolation of TransitionUp, added after the activation (see RoitrGemm::ip_*):
+ * out[r,:] = act( LayerNorm(x[r,:] + res) * gamma + beta ) + sum_k w_k ip_feat[ip_idx[3 r + k], :] */
+int roitr_add_layernorm_interp(int M, int C, const float* x, const float* res, const int* res_idx, const float* gamma,
+                               const float* beta, int relu, float eps, const float* ip_feat, const int* ip_idx, const float* ip_dist2,
+                               float* out, roitr_stream_t stream);
 /* F.normalize(p=2, dim=1), model/RIGA_v2.py:64-65 */
 int roitr_l2_normalize(int M, int C, const float* x, float* out, roitr_stream_t stream);
 int roitr_transpose(int rows, int cols, const float* in, int ld_in, float* out, int ld_out, roitr_stream_t stream);

@@ -209,6 +209,8 @@ int gemm(hipStream_t st, int M, const float* A, const Lin& l, float* C, bool rel
 // fat blocks: +1.0 ms per 128-pair forward), also for small M only, to save the 41 add_layernorm launches of a one-pair
 // forward -- 5.84 vs 5.23 ms per pair: a 64 x 256 tile puts four accumulators (4096 MFMA cycles per K-slab) on the critical
 // path of a handful of blocks, which costs more than the launch it saves.
+// TransitionUp's interpolation addend (RoitrGemm::ip_*): rows of `feat` (l.out floats) mixed by the 3-NN of every output row
+struct Interp3 { const float* feat; const int* idx; const float* dist2; };
 bool ln_fuses(int N, int K, int lda, int ldw)
 {
     return (N == 64 || N == 128) && K % 32 == 0 && lda % 4 == 0 && ldw % 4 == 0;
@@ -218,7 +220,7 @@ bool ln_fuses(int N, int K, int lda, int ldw)
 // dimension lda_cat (fp32 kernels only)
 int gemm_ln(hipStream_t st, int M, const float* A, const Lin& l, const float* res, const int* res_idx, const float* gamma,
             const float* beta, const float* post, bool relu, float* tmp, float* out, int bf = 0, const float* A_cat = nullptr,
-            int lda_cat = 0, int k_cat = 0, const float* A2 = nullptr)
+            int lda_cat = 0, int k_cat = 0, const float* A2 = nullptr, const Interp3* ip = nullptr)
 {
     const float* w = l.w;
     const float* b = l.b;
@@ -232,6 +234,7 @@ int gemm_ln(hipStream_t st, int M, const float* A, const Lin& l, const float* re
         g.M = M; g.N = N; g.K = K; g.A = A; g.lda = lda; g.W = w; g.ldw = ldw; g.bias = b; g.alpha = 1.0f; g.C = out; g.ldc = N; g.batch = 1;
         g.ln_gamma = gamma; g.ln_beta = beta; g.ln_res = res; g.ln_res_idx = res_idx; g.ln_post = post; g.ln_relu = relu ? 1 : 0; g.ln_eps = 1e-5f;
         g.A_cat = A_cat; g.lda_cat = lda_cat; g.k_cat = k_cat; g.A2 = A2;   // A2 (optional): the operand is A + A2
+        if (ip) { g.ip_feat = ip->feat; g.ip_idx = ip->idx; g.ip_dist2 = ip->dist2; }
         CHK(use_bf16(g, w, l.wb, bf));
         return roitr_gemm(&g, st);
     }
@@ -244,6 +247,10 @@ int gemm_ln(hipStream_t st, int M, const float* A, const Lin& l, const float* re
         CHK(roitr_gemm(&g, st));
     } else
     CHK(gemm(st, M, N, K, A, lda, w, ldw, b, tmp, N, false, nullptr, A2, 1.0f, l.wb, bf));
+    if (ip) {
+        if (post) { roitr_set_error("engine: interpolation addend and post-add together", __FILE__, __LINE__); return ROITR_ERR_ARG; }
+        return roitr_add_layernorm_interp(M, N, tmp, res, res_idx, gamma, beta, relu ? 1 : 0, 1e-5f, ip->feat, ip->idx, ip->dist2, out, st);
+    }
     return roitr_add_layernorm(M, N, tmp, res, res_idx, gamma, beta, post, relu ? 1 : 0, 1e-5f, out, st);
 }
 
@@ -1270,10 +1277,17 @@ extern "C" int roitr_engine_forward(void* h, const RoitrForwardIO* io, hipStream
         float* x0 = A.get<float>((size_t)Tl * pl);
         xd[l] = A.get<float>((size_t)Tl * pl);
         if (A.fail) { roitr_set_error("arena exhausted (decoder)", __FILE__, __LINE__); return ROITR_ERR_ARG; }
-        CHK(gemm_ln(st, Tl, xe[l], U.l1, nullptr, nullptr, U.l1n_w, U.l1n_b, nullptr, true, a0, a1));
         (void)pc;
         CHK(gemm_ln(st, Tc, xd[l + 1], U.l2, nullptr, nullptr, U.l2n_w, U.l2n_b, nullptr, true, b0, b1));
-        CHK(roitr_interp3_add(Tl, pl, b1, i3[l], d3[l], a1, x0, st));
+        if (E.cfg.operand_dtype == 0) {
+            // fp32: `linear1(x1) + interpolation(p2, p1, linear2(x2))` in the launch that computes linear1 -- the interpolation rides in
+            // the LayerNorm epilogue (after the ReLU), the (Tl, pl) intermediate a1 is never written
+            const Interp3 ip = {b1, i3[l], d3[l]};
+            CHK(gemm_ln(st, Tl, xe[l], U.l1, nullptr, nullptr, U.l1n_w, U.l1n_b, nullptr, true, a0, x0, 0, nullptr, 0, 0, nullptr, &ip));
+        } else {
+            CHK(gemm_ln(st, Tl, xe[l], U.l1, nullptr, nullptr, U.l1n_w, U.l1n_b, nullptr, true, a0, a1));
+            CHK(roitr_interp3_add(Tl, pl, b1, i3[l], d3[l], a1, x0, st));
+        }
         CHK(tap(E, st, "dec" + std::to_string(l + 1) + ".0", x0, sizeof(float) * (size_t)Tl * pl));
         CHK(block(E, st, E.dec[l], Tl, x0, g_self[l], ppf_self[l], E.nsample[l], xd[l], order[l]));
         CHK(tap(E, st, "dec" + std::to_string(l + 1) + ".1", xd[l], sizeof(float) * (size_t)Tl * pl));

@@ -254,11 +254,29 @@ __global__ __launch_bounds__(256) void gemm_kernel(RoitrGemm g, int nx, int ny, 
 #pragma unroll
                 for (int i = 0; i < TN; ++i) { const float d = t[i] - mean; q_ += d * d; }
                 const float rstd = 1.0f / sqrtf(wave_sum(q_) / (float)TBN + g.ln_eps);
+                // TransitionUp: + three-nearest-neighbour interpolation of the coarser level's rows (same expression order as
+                // interp3_add_kernel, nn_ops.hip); indices and distances of a row are wave-uniform
+                const float* f0 = nullptr; const float* f1 = nullptr; const float* f2 = nullptr;
+                float w0 = 0.f, w1 = 0.f, w2 = 0.f;
+                if (g.ip_feat) {
+                    const int* ii = g.ip_idx + (size_t)row * 3;
+                    const float* dd = g.ip_dist2 + (size_t)row * 3;
+                    w0 = 1.0f / (sqrtf(dd[0]) + 1e-8f); w1 = 1.0f / (sqrtf(dd[1]) + 1e-8f); w2 = 1.0f / (sqrtf(dd[2]) + 1e-8f);
+                    const float ws = (w0 + w1) + w2;
+                    w0 /= ws; w1 /= ws; w2 /= ws;
+                    f0 = g.ip_feat + (size_t)ii[0] * TBN; f1 = g.ip_feat + (size_t)ii[1] * TBN; f2 = g.ip_feat + (size_t)ii[2] * TBN;
+                }
 #pragma unroll
                 for (int i = 0; i < TN; ++i) {
                     float y = (t[i] - mean) * rstd * gam[i] + bet[i];
                     if (g.ln_post) y += g.ln_post[(size_t)row * TBN + lane + 64 * i];
                     if (g.ln_relu) y = fmaxf(y, 0.f);
+                    if (f0) {
+                        const int c = lane + 64 * i;
+                        float acc = 0.f;
+                        acc += f0[c] * w0; acc += f1[c] * w1; acc += f2[c] * w2;
+                        y = y + acc;
+                    }
                     C[(size_t)row * g.ldc + lane + 64 * i] = y;
                 }
             }
@@ -350,6 +368,7 @@ extern "C" int roitr_gemm(const RoitrGemm* g, hipStream_t stream)
     }
     const int tn = g->ln_gamma ? g->N / BN : 1;   // LayerNorm epilogue: one block spans the row
     if (g->ln_gamma && (g->N % BN || (tn != 1 && tn != 2 && tn != 4) || g->batch != 1 || g->seg_off || g->relu || !g->ln_beta)) return ROITR_ERR_UNSUPPORTED;
+    if (g->ip_feat && (!g->ln_gamma || !g->ip_idx || !g->ip_dist2)) { roitr_set_error("roitr_gemm: the interpolation addend rides in the fused LayerNorm epilogue only", __FILE__, __LINE__); return ROITR_ERR_UNSUPPORTED; }
     const int nx = div_up(g->N, BN * tn), ny = div_up(g->M, BM);
     const long Tl = (long)nx * ny * g->batch;
     if (Tl > 0x7ffffff0L) return ROITR_ERR_UNSUPPORTED;

@@ -305,6 +305,7 @@ extern "C" int roitr_gemm_bf16_supported(const RoitrGemm* g)
 
 int roitr_gemm_bf16_launch(const RoitrGemm* g, hipStream_t stream)
 {
+    if (g->ip_feat) { roitr_set_error("roitr_gemm: the interpolation addend is an fp32-kernel epilogue", __FILE__, __LINE__); return ROITR_ERR_UNSUPPORTED; }
     if (!roitr_gemm_bf16_supported(g)) {
         roitr_set_error("roitr_gemm: shape / layout not supported by the bf16 kernel (K % 64, 16-byte rows, bf16 weights)", __FILE__, __LINE__);
         return ROITR_ERR_UNSUPPORTED;

@@ -17,7 +17,8 @@ template <int VPL>  // values per lane: C <= 64*VPL
 __global__ __launch_bounds__(256) void add_layernorm_kernel(int M, int C, const float* __restrict__ x, const float* __restrict__ res,
                                                             const int* __restrict__ res_idx, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, const float* __restrict__ post, int relu,
-                                                            float eps, float* __restrict__ out)
+                                                            float eps, float* __restrict__ out, const float* __restrict__ ip_feat = nullptr,
+                                                            const int* __restrict__ ip_idx = nullptr, const float* __restrict__ ip_dist2 = nullptr)
 {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -43,6 +44,17 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(int M, int C, const 
         q += d * d;
     }
     const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)C + eps);
+    // TransitionUp: + three-nearest-neighbour interpolation (expression order of interp3_add_kernel below), after the activation
+    const float* f0 = nullptr; const float* f1 = nullptr; const float* f2 = nullptr;
+    float w0 = 0.f, w1 = 0.f, w2 = 0.f;
+    if (ip_feat) {
+        const int* ii = ip_idx + (size_t)row * 3;
+        const float* dd = ip_dist2 + (size_t)row * 3;
+        w0 = 1.0f / (sqrtf(dd[0]) + 1e-8f); w1 = 1.0f / (sqrtf(dd[1]) + 1e-8f); w2 = 1.0f / (sqrtf(dd[2]) + 1e-8f);
+        const float ws = (w0 + w1) + w2;
+        w0 /= ws; w1 /= ws; w2 /= ws;
+        f0 = ip_feat + (size_t)ii[0] * C; f1 = ip_feat + (size_t)ii[1] * C; f2 = ip_feat + (size_t)ii[2] * C;
+    }
 #pragma unroll
     for (int i = 0; i < VPL; ++i) {
         const int c = lane + 64 * i;
@@ -50,6 +62,11 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(int M, int C, const 
             float y = (v[i] - mean) * rstd * gamma[c] + beta[c];
             if (post) y += post[(size_t)row * C + c];
             if (relu) y = fmaxf(y, 0.f);
+            if (f0) {
+                float acc = 0.f;
+                acc += f0[c] * w0; acc += f1[c] * w1; acc += f2[c] * w2;
+                y = y + acc;
+            }
             out[(size_t)row * C + c] = y;
         }
     }
@@ -177,6 +194,20 @@ extern "C" int roitr_add_layernorm(int M, int C, const float* x, const float* re
     if (C > 1024) return ROITR_ERR_UNSUPPORTED;
     const int blocks = div_up(M, 4);
 #define LN_CASE(V) add_layernorm_kernel<V><<<blocks, 256, 0, stream>>>(M, C, x, res, res_idx, gamma, beta, post_add, relu, eps, out)
+    if (C <= 64) LN_CASE(1); else if (C <= 128) LN_CASE(2); else if (C <= 256) LN_CASE(4); else if (C <= 512) LN_CASE(8); else LN_CASE(16);
+#undef LN_CASE
+    ROITR_LAUNCH_CHECK();
+    return ROITR_OK;
+}
+
+extern "C" int roitr_add_layernorm_interp(int M, int C, const float* x, const float* res, const int* res_idx, const float* gamma,
+                                          const float* beta, int relu, float eps, const float* ip_feat, const int* ip_idx,
+                                          const float* ip_dist2, float* out, hipStream_t stream)
+{
+    if (M <= 0) return ROITR_OK;
+    if (C > 1024 || !ip_feat || !ip_idx || !ip_dist2) return ROITR_ERR_UNSUPPORTED;
+    const int blocks = div_up(M, 4);
+#define LN_CASE(V) add_layernorm_kernel<V><<<blocks, 256, 0, stream>>>(M, C, x, res, res_idx, gamma, beta, nullptr, relu, eps, out, ip_feat, ip_idx, ip_dist2)
     if (C <= 64) LN_CASE(1); else if (C <= 128) LN_CASE(2); else if (C <= 256) LN_CASE(4); else if (C <= 512) LN_CASE(8); else LN_CASE(16);
 #undef LN_CASE
     ROITR_LAUNCH_CHECK();

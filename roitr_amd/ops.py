@@ -153,7 +153,8 @@ class _Gemm(ctypes.Structure):
                 ("seg_a0", ctypes.c_int), ("seg_w0", ctypes.c_int),
                 ("ln_gamma", _P), ("ln_beta", _P), ("ln_res", _P), ("ln_res_idx", _P), ("ln_post", _P),
                 ("ln_relu", ctypes.c_int), ("ln_eps", ctypes.c_float), ("bf16", ctypes.c_int),
-                ("A_cat", _P), ("lda_cat", ctypes.c_int), ("k_cat", ctypes.c_int)]
+                ("A_cat", _P), ("lda_cat", ctypes.c_int), ("k_cat", ctypes.c_int),
+                ("ip_feat", _P), ("ip_idx", _P), ("ip_dist2", _P)]
 
 
 BF16_W, BF16_A, BF16_C = 1, 2, 4   # RoitrGemm::bf16 flags (include/roitr_engine.h)
@@ -202,10 +203,11 @@ def linear(x, weight, bias=None, relu=False, alpha=1.0, bf16=False, out_bf16=Fal
 
 
 def linear_layernorm(x, weight, bias, gamma, beta, res=None, res_idx=None, post=None, relu=False, eps=1e-5, bf16=False, out_bf16=False,
-                     x_cat=None):
+                     x_cat=None, interp=None):
     """[relu](LayerNorm(x @ weight.T + bias + res[res_idx]) * gamma + beta + post) in ONE launch (64 / 128 / 256 output
     channels): the nn.Linear -> (+ residual) -> nn.LayerNorm call sites of attention.py:319, model/model.py:89-97,138-140.
-    bf16 / out_bf16 as in linear()."""
+    bf16 / out_bf16 as in linear().  interp = (feat (R, N), idx (M, 3) int32, dist2 (M, 3)): TransitionUp's three-nearest-neighbour
+    interpolation (pointops.py:168-182) of the rows of `feat`, added after the activation (fp32 kernel only)."""
     x, weight, flags = _bf16_flags(bf16, x, weight, out_bf16)
     M, K = x.shape
     N = weight.shape[0]
@@ -218,7 +220,22 @@ def linear_layernorm(x, weight, bias, gamma, beta, res=None, res_idx=None, post=
     keep = []
     _k_cat(g, x, x_cat, keep)
     g.ldw = weight.shape[1]
+    if interp is not None:
+        keep += [c(interp[0]), c(interp[1], torch.int32), c(interp[2])]
+        g.ip_feat, g.ip_idx, g.ip_dist2 = L.ptr(keep[-3]), L.ptr(keep[-2]), L.ptr(keep[-1])
     L.check(L.lib().roitr_gemm(ctypes.byref(g), L.stream_ptr()), "gemm+layernorm")
+    return out
+
+
+def add_layernorm_interp(x, gamma, beta, feat, idx, dist2, res=None, res_idx=None, relu=False, eps=1e-5):
+    """[relu](LayerNorm(x + res[res_idx]) * gamma + beta) + three-nearest-neighbour interpolation of the rows of `feat`
+    (roitr_add_layernorm_interp: the two-launch twin of linear_layernorm(..., interp=...))."""
+    c = lambda t, dt=torch.float32: None if t is None else t.contiguous().to(dt)
+    x, gm, bt, rs, ri, ft, ix, d2 = c(x), c(gamma), c(beta), c(res), c(res_idx, torch.int32), c(feat), c(idx, torch.int32), c(dist2)
+    M, C = x.shape
+    out = torch.empty_like(x)
+    L.check(L.lib().roitr_add_layernorm_interp(M, C, L.ptr(x), L.ptr(rs), L.ptr(ri), L.ptr(gm), L.ptr(bt), int(relu), ctypes.c_float(eps),
+                                               L.ptr(ft), L.ptr(ix), L.ptr(d2), L.ptr(out), L.stream_ptr()), "add_layernorm_interp")
     return out
 
 

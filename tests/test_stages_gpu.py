@@ -523,3 +523,31 @@ def test_local_attention_fold_against_the_unfolded_form(I, H, M, N_in):
     hi = x[grp].max(1).values[:, None, :].expand(M, 4, I) + 1e-5
     xb = xbar.double().cpu()
     assert bool(((xb >= lo) & (xb <= hi)).all())
+
+
+@pytest.mark.parametrize("M,K,N,R", [(1000, 64, 64, 260), (777, 128, 128, 200), (333, 256, 256, 90)])
+def test_transition_up_interpolation_in_the_layernorm_epilogue(M, K, N, R):
+    """TransitionUp (model/model.py:112-116): relu(LN(linear1(x1))) + interpolation(p2, p1, feat) -- the interpolation
+    (pointops.py:168-182) rides in the LayerNorm epilogue of the GEMM (N = 64 / 128) or of roitr_add_layernorm_interp (the
+    two-launch form of wider rows).  Against float64, and bitwise against the three-launch sequence it replaces."""
+    from roitr_amd import ops, pointops as P
+    g = torch.Generator().manual_seed(M + N)
+    x = torch.randn(M, K, generator=g).cuda()
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).cuda()
+    b = torch.randn(N, generator=g).cuda()
+    gam, bet = torch.randn(N, generator=g).cuda(), torch.randn(N, generator=g).cuda()
+    feat = torch.randn(R, N, generator=g).cuda()
+    idx = torch.randint(0, R, (M, 3), generator=g).to(torch.int32).cuda()
+    d2 = (torch.rand(M, 3, generator=g) * 0.3).cuda()
+    d2[5, 0] = 0.0                                            # a query that coincides with a coarse point: weight 1e8, normalised
+    lin = x.double() @ w.double().T + b.double()
+    base = torch.nn.functional.layer_norm(lin, (N,), gam.double(), bet.double(), 1e-5).clamp_min(0)
+    wgt = 1.0 / (d2.double().sqrt() + 1e-8)
+    wgt = wgt / wgt.sum(1, keepdim=True)
+    ref = base + (feat.double()[idx.long()] * wgt[..., None]).sum(1)
+    two = ops.add_layernorm_interp(ops.linear(x, w, b), gam, bet, feat, idx, d2, relu=True)
+    assert torch.allclose(two.double(), ref, atol=3e-5, rtol=3e-5), float((two.double() - ref).abs().max())
+    if N <= 128:
+        got = ops.linear_layernorm(x, w, b, gam, bet, relu=True, interp=(feat, idx, d2))
+        assert torch.allclose(got.double(), ref, atol=3e-5, rtol=3e-5), float((got.double() - ref).abs().max())
+        assert torch.equal(got, two)                          # the fused and the two-launch epilogue are bitwise twins
