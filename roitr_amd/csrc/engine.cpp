@@ -208,7 +208,8 @@ int gemm(hipStream_t st, int M, const float* A, const Lin& l, float* C, bool rel
 // invariance.  Measured and dropped: fusing the 256-wide rows as well (64 x 256 tiles leave the coarse levels with too few, too
 // fat blocks: +1.0 ms per 128-pair forward), also for small M only, to save the 41 add_layernorm launches of a one-pair
 // forward -- 5.84 vs 5.23 ms per pair: a 64 x 256 tile puts four accumulators (4096 MFMA cycles per K-slab) on the critical
-// path of a handful of blocks, which costs more than the launch it saves.
+// path of a handful of blocks, which costs more than the launch it saves.  Round 3, at 512 pairs per call (the choice may depend on
+// M: the forms are bitwise twins): fusing the 256-wide rows from M >= 60 000 / 200 000 rows: 93.1 / 92.6 vs 92.5 ms per step.
 // TransitionUp's interpolation addend (RoitrGemm::ip_*): rows of `feat` (l.out floats) mixed by the 3-NN of every output row
 struct Interp3 { const float* feat; const int* idx; const float* dist2; };
 bool ln_fuses(int N, int K, int lda, int ldw)
