@@ -90,6 +90,18 @@ __device__ __forceinline__ float row16_transpose_sum(const float (&v)[16], int l
     return (b3 ? t[1] : t[0]) + dpp_get<0x128>(b3 ? t[0] : t[1]);                                        // row_ror:8
 }
 
+// gfx950 lane-swap adds: fold the two halves / the row pairs of a wave while every lane keeps one of two values
+typedef unsigned la_u2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float swap32_sum(float a, float b)   // lanes < 32: sum of a over (l, l + 32); lanes >= 32: the same for b
+{
+    const la_u2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(r.x) + __uint_as_float(r.y);
+}
+__device__ __forceinline__ float swap16_sum(float a, float b)   // even rows: sum of a over (row, row + 1); odd rows: the same for b
+{
+    const la_u2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(r.x) + __uint_as_float(r.y);
+}
 // XCD-aware block id.  The dispatcher places block b on XCD b % 8 (MI355X_MICROARCH.md, workgroup dispatch), each XCD
 // with a private 4 MiB L2: consecutive blocks that share gathered rows would each fetch them into a different L2.
 // This remap hands every XCD one contiguous eighth of the logical block range.  Launch xcd_grid(n) blocks and skip

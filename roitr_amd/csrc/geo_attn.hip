@@ -260,10 +260,11 @@ __global__ __launch_bounds__(256, R <= 20 ? 3 : 2) void mha_geo_kernel(RoitrMha 
     float4 qt4[NH];
 #pragma unroll
     for (int h = 0; h < NH; ++h) qt4[h] = reinterpret_cast<const float4*>(a.qt + ((size_t)row * NH + h) * C)[lane];
-    const float qb = row_allsum(dot4(qv, reinterpret_cast<const float4*>(a.bp)[lane]));   // q_h . bp_h, h = this lane's row
-    // ---- scores, part 1 (while the E rows are in flight): q_h . k_j from L2-resident key rows, 5 rows per batch; after the
-    // 16-lane reduction every lane of DPP row h holds the head-h value of the key row
-    float s1v[R];
+    // this lane's share of q_h . bp_h (h = its DPP row): summed over the row inside the score reduction below
+    const float qb_l = dot4(qv, reinterpret_cast<const float4*>(a.bp)[lane]);
+    // ---- scores, part 1 (while the E rows are in flight): this lane's share of q_h . k_j + q_h . bp_h from L2-resident key rows,
+    // 5 rows per batch
+    float qk[R];
 #pragma unroll
     for (int r0 = 0; r0 < R; r0 += 5) {
         float4 kv[5];
@@ -274,25 +275,48 @@ __global__ __launch_bounds__(256, R <= 20 ? 3 : 2) void mha_geo_kernel(RoitrMha 
         }
 #pragma unroll
         for (int u = 0; u < 5; ++u)
-            if (r0 + u < R) s1v[r0 + u] = row_allsum(dot4(qv, kv[u]));
+            if (r0 + u < R) qk[r0 + u] = dot4(qv, kv[u]) + qb_l;
     }
-    // ---- scores, part 2: + q~_h . E_ij + q_h . bp_h.  Round 3: the 4 heads x 4 key rows = 16 wave-wide dot products of a group of
-    // rows are reduced TOGETHER (row16_transpose_sum inside the DPP rows, then two cross-row adds) instead of one 64-lane
-    // reduction each -- the kernel was bound by exactly those (SQ pass of round 2: 391 v_add_dpp + 569 hazard nops per wave against
-    // 660 FMAs).  The first lane of DPP row h feeds the head-h terms that do not involve E (q_h . k_j + q_h . bp_h) into the same sum.
+    // ---- scores, part 2: + q~_h . E_ij.  The 4 heads x 16 key rows = 64 wave-wide dot products of a batch of rows are reduced
+    // TOGETHER: v_permlane32_swap / v_permlane16_swap fold the four DPP rows while row h keeps head h's quarter of the values,
+    // row16_transpose_sum finishes inside the row -- lane (h, i) ends with the score of (head h, key row16_slot(i)) in 63 adds
+    // (round 2: one 64-lane reduction per value; first form of round 3: groups of 16 values + two LDS shuffles per group).  The
+    // terms that do not involve E ride in the same sum: a lane adds its share of q_h . k_j + q_h . bp_h to the value of its own head.
     static_assert(R % 4 == 0, "key rows per wave come in groups of four");
     {
         const int i16 = lane & 15;
-        const bool feeder = i16 == 0;                         // lane 16 h: DPP row h
 #pragma unroll
-        for (int g4 = 0; g4 < R / 4; ++g4) {
+        for (int b16 = 0; b16 + 16 <= R; b16 += 16) {
+            float z[16];
+            {
+                float w[32];
+#pragma unroll
+                for (int i = 0; i < 32; ++i) {
+                    const int h0 = i >> 4, r = i & 15;      // value i = (head h0, row r), value i + 32 = (head h0 + 2, row r)
+                    const float4 ev = e[b16 + r];
+                    float d0 = hl == h0 ? qk[b16 + r] : 0.f, d1 = hl == h0 + 2 ? qk[b16 + r] : 0.f;
+                    d0 = fmaf(qt4[h0].x, ev.x, d0); d0 = fmaf(qt4[h0].y, ev.y, d0); d0 = fmaf(qt4[h0].z, ev.z, d0); d0 = fmaf(qt4[h0].w, ev.w, d0);
+                    d1 = fmaf(qt4[h0 + 2].x, ev.x, d1); d1 = fmaf(qt4[h0 + 2].y, ev.y, d1); d1 = fmaf(qt4[h0 + 2].z, ev.z, d1); d1 = fmaf(qt4[h0 + 2].w, ev.w, d1);
+                    w[i] = swap32_sum(d0, d1);
+                }
+#pragma unroll
+                for (int i = 0; i < 16; ++i) z[i] = swap16_sum(w[i], w[i + 16]);
+            }
+            const float tot = row16_transpose_sum(z, lane);
+            const int j = wave + 4 * (b16 + row16_slot(i16));
+            if (j < nk) sc[hl][j] = tot * a.scale;
+        }
+        // the rows past the last full batch (R = 20: four of them): groups of 4 heads x 4 rows, row sums + two cross-row adds
+#pragma unroll
+        for (int g4 = (R / 16) * 4; g4 < R / 4; ++g4) {
             float v[16];
 #pragma unroll
             for (int h = 0; h < NH; ++h)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    float d = dot4(qt4[h], e[4 * g4 + r]);
-                    if (feeder && hl == h) d += s1v[4 * g4 + r] + qb;
+                    const float4 ev = e[4 * g4 + r];
+                    float d = hl == h ? qk[4 * g4 + r] : 0.f;
+                    d = fmaf(qt4[h].x, ev.x, d); d = fmaf(qt4[h].y, ev.y, d); d = fmaf(qt4[h].z, ev.z, d); d = fmaf(qt4[h].w, ev.w, d);
                     v[h * 4 + r] = d;
                 }
             float tot = row16_transpose_sum(v, lane);
@@ -334,10 +358,11 @@ __global__ __launch_bounds__(256, R <= 20 ? 3 : 2) void mha_geo_kernel(RoitrMha 
             sm += e1[u]; sm2 += e2[u];
         }
         sm = wave_sum(sm); sm2 = wave_sum(sm2);
+        // rows past the cloud's last key get probability 0 in both tables: the passes below need no per-key bound checks
 #pragma unroll
         for (int u = 0; u < (NKP + 63) / 64; ++u) {
             const int j = lane + 64 * u;
-            if (j < nk) { sc[h][j] = e1[u] / sm; sc2t[j * 4 + h] = e2[u] / sm2; }
+            if (j < NKP) { sc[h][j] = j < nk ? e1[u] / sm : 0.f; sc2t[j * 4 + h] = j < nk ? e2[u] / sm2 : 0.f; }
         }
     }
     __syncthreads();
@@ -351,7 +376,7 @@ __global__ __launch_bounds__(256, R <= 20 ? 3 : 2) void mha_geo_kernel(RoitrMha 
 #pragma unroll
         for (int rr = 0; rr < EB; ++rr) {
             const int j = wave + 4 * rr;
-            const float p = j < nk ? sc[hl][j] : 0.f;
+            const float p = sc[hl][j];
             hacc.x = fmaf(p, vfirst[rr].x, hacc.x); hacc.y = fmaf(p, vfirst[rr].y, hacc.y); hacc.z = fmaf(p, vfirst[rr].z, hacc.z); hacc.w = fmaf(p, vfirst[rr].w, hacc.w);
         }
         constexpr int CH = 8;   // rows per later batch (a real loop: unrolled, the compiler hoists every batch's loads and spills)
@@ -366,7 +391,7 @@ __global__ __launch_bounds__(256, R <= 20 ? 3 : 2) void mha_geo_kernel(RoitrMha 
 #pragma unroll
             for (int u = 0; u < CH; ++u) {
                 const int j = wave + 4 * (r0 + u);
-                const float p = (r0 + u < R && j < nk) ? sc[hl][j] : 0.f;
+                const float p = r0 + u < R ? sc[hl][j < NKP ? j : 0] : 0.f;
                 hacc.x = fmaf(p, vb[u].x, hacc.x); hacc.y = fmaf(p, vb[u].y, hacc.y); hacc.z = fmaf(p, vb[u].z, hacc.z); hacc.w = fmaf(p, vb[u].w, hacc.w);
             }
         }
@@ -379,8 +404,8 @@ __global__ __launch_bounds__(256, R <= 20 ? 3 : 2) void mha_geo_kernel(RoitrMha 
 #pragma unroll
     for (int rr = 0; rr < R; ++rr) {
         const int j = wave + 4 * rr;
-        const float4 p2 = reinterpret_cast<const float4*>(sc2t)[j < nk ? j : 0];
-        const float w0 = j < nk ? p2.x : 0.f, w1 = j < nk ? p2.y : 0.f, w2 = j < nk ? p2.z : 0.f, w3 = j < nk ? p2.w : 0.f;
+        const float4 p2 = reinterpret_cast<const float4*>(sc2t)[j];
+        const float w0 = p2.x, w1 = p2.y, w2 = p2.z, w3 = p2.w;
         acc[0].x = fmaf(w0, e[rr].x, acc[0].x); acc[0].y = fmaf(w0, e[rr].y, acc[0].y); acc[0].z = fmaf(w0, e[rr].z, acc[0].z); acc[0].w = fmaf(w0, e[rr].w, acc[0].w);
         acc[1].x = fmaf(w1, e[rr].x, acc[1].x); acc[1].y = fmaf(w1, e[rr].y, acc[1].y); acc[1].z = fmaf(w1, e[rr].z, acc[1].z); acc[1].w = fmaf(w1, e[rr].w, acc[1].w);
         acc[2].x = fmaf(w2, e[rr].x, acc[2].x); acc[2].y = fmaf(w2, e[rr].y, acc[2].y); acc[2].z = fmaf(w2, e[rr].z, acc[2].z); acc[2].w = fmaf(w2, e[rr].w, acc[2].w);

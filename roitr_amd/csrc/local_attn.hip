@@ -313,17 +313,6 @@ __global__ __launch_bounds__(256) void local_attn_quad_kernel(RoitrLocalAttn a)
 // node are reduced TOGETHER: v_permlane32_swap / v_permlane16_swap (gfx950) fold the four DPP rows while keeping one quarter of
 // the values per row (row h ends with head h), row16_transpose_sum finishes inside the row -- lane (h, i) ends with the score of
 // (head h, neighbour row16_slot(i)) in 63 adds instead of 64 x 6.  Softmax, pbar and the probability table are row-local after that.
-typedef unsigned la_u2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ float swap32_sum(float a, float b)   // lanes < 32: sum of a over (l, l + 32); lanes >= 32: the same for b
-{
-    const la_u2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
-    return __uint_as_float(r.x) + __uint_as_float(r.y);
-}
-__device__ __forceinline__ float swap16_sum(float a, float b)   // even rows: sum of a over (row, row + 1); odd rows: the same for b
-{
-    const la_u2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
-    return __uint_as_float(r.x) + __uint_as_float(r.y);
-}
 __device__ __forceinline__ float row_allmax(float v)
 {
     v = fmaxf(v, dpp_get<0xB1>(v)); v = fmaxf(v, dpp_get<0x4E>(v)); v = fmaxf(v, dpp_get<0x141>(v)); v = fmaxf(v, dpp_get<0x140>(v));
