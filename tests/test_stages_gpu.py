@@ -368,6 +368,19 @@ def test_engine_uses_the_table_and_agrees_with_the_gemm_form():
     for k in ("src_node_feats", "tgt_node_feats", "src_point_feats", "tgt_point_feats"):
         assert (out[k] - ref[k]).abs().max().item() < 2e-5, k
     assert torch.equal(out["src_nodes"], ref["src_nodes"])
+    # ROITR_GEO_TABLE_RANGE: a table that ends at 2 units (0.4 m) -- most superpoint distances of the pair then take the direct
+    # sin / cos evaluation inside the kernel; the result must not depend on where the table ends
+    os.environ["ROITR_GEO_TABLE_RANGE"] = "2"
+    try:
+        short = build_model("3DMatch")
+        si = short.geo_table_info()
+        assert si is not None and si["n_int_d"] < info["n_int_d"]
+        with torch.no_grad():
+            got = short.forward(**pair)
+    finally:
+        del os.environ["ROITR_GEO_TABLE_RANGE"]
+    for k in ("src_node_feats", "tgt_node_feats", "src_point_feats", "tgt_point_feats"):
+        assert (out[k] - got[k]).abs().max().item() < 2e-5, k
 
 
 def test_gemm_rows_do_not_depend_on_the_row_count():
