@@ -125,7 +125,7 @@ struct Engine {
     char* pinned[RING] = {nullptr, nullptr, nullptr, nullptr}; size_t pinned_cap[RING] = {0, 0, 0, 0};
     hipEvent_t pinned_ev[RING] = {nullptr, nullptr, nullptr, nullptr};
     int ring_pos = 0;
-    hipStream_t side = nullptr;      // FPS chain runs here, beside the level-1 encoder work
+    hipStream_t side = nullptr;      // the geometry chain (FPS, grids, kNN + PPF of levels 2-4, 3-NN, embedding E, partition, GT outputs)
     static constexpr int NEV = 8;
     hipEvent_t ev[NEV] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     std::string err;

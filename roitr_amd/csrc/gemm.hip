@@ -237,9 +237,46 @@ __global__ __launch_bounds__(256) void gemm_kernel(RoitrGemm g, int nx, int ny, 
                 }
             }
             __syncthreads();
+            // TransitionUp addend: lane t holds the descriptors of the wave's t-th row of this pass (indices, normalised weights:
+            // interp3_add_kernel's expressions), the rows' feature values are fetched one row AHEAD of their use
+            int pi0 = 0, pi1 = 0, pi2 = 0; float pw0 = 0.f, pw1 = 0.f, pw2 = 0.f;
+            float fn0[TN], fn1[TN], fn2[TN];
+            if (g.ip_feat) {
+                const int rowl = m0 + pass * RP + wave + 4 * lane;
+                if (lane < RP / 4 && rowl < g.M) {
+                    const int* ii = g.ip_idx + (size_t)rowl * 3;
+                    const float* dd = g.ip_dist2 + (size_t)rowl * 3;
+                    pi0 = ii[0]; pi1 = ii[1]; pi2 = ii[2];
+                    pw0 = 1.0f / (sqrtf(dd[0]) + 1e-8f); pw1 = 1.0f / (sqrtf(dd[1]) + 1e-8f); pw2 = 1.0f / (sqrtf(dd[2]) + 1e-8f);
+                    const float ws = (pw0 + pw1) + pw2;
+                    pw0 /= ws; pw1 /= ws; pw2 /= ws;
+                }
+                const float* a0 = g.ip_feat + (size_t)__builtin_amdgcn_readlane(pi0, 0) * TBN;
+                const float* a1 = g.ip_feat + (size_t)__builtin_amdgcn_readlane(pi1, 0) * TBN;
+                const float* a2 = g.ip_feat + (size_t)__builtin_amdgcn_readlane(pi2, 0) * TBN;
+#pragma unroll
+                for (int i = 0; i < TN; ++i) { fn0[i] = a0[lane + 64 * i]; fn1[i] = a1[lane + 64 * i]; fn2[i] = a2[lane + 64 * i]; }
+            }
             for (int rl = wave; rl < RP; rl += 4) {
                 const int row = m0 + pass * RP + rl;
                 if (row >= g.M) break;   // wave-uniform
+                float fc0[TN], fc1[TN], fc2[TN];
+                float w0 = 0.f, w1 = 0.f, w2 = 0.f;
+                if (g.ip_feat) {
+                    const int t_ = (rl - wave) >> 2;
+#pragma unroll
+                    for (int i = 0; i < TN; ++i) { fc0[i] = fn0[i]; fc1[i] = fn1[i]; fc2[i] = fn2[i]; }
+                    w0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pw0), t_));
+                    w1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pw1), t_));
+                    w2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pw2), t_));
+                    if (rl + 4 < RP && row + 4 < g.M) {        // the next row's feature rows: in flight across this row's LayerNorm
+                        const float* a0 = g.ip_feat + (size_t)__builtin_amdgcn_readlane(pi0, t_ + 1) * TBN;
+                        const float* a1 = g.ip_feat + (size_t)__builtin_amdgcn_readlane(pi1, t_ + 1) * TBN;
+                        const float* a2 = g.ip_feat + (size_t)__builtin_amdgcn_readlane(pi2, t_ + 1) * TBN;
+#pragma unroll
+                        for (int i = 0; i < TN; ++i) { fn0[i] = a0[lane + 64 * i]; fn1[i] = a1[lane + 64 * i]; fn2[i] = a2[lane + 64 * i]; }
+                    }
+                }
                 const float* rr = g.ln_res ? g.ln_res + (size_t)(g.ln_res_idx ? g.ln_res_idx[row] : row) * TBN : nullptr;
                 float t[TN];
                 float s_ = 0.f;
@@ -254,27 +291,14 @@ __global__ __launch_bounds__(256) void gemm_kernel(RoitrGemm g, int nx, int ny, 
 #pragma unroll
                 for (int i = 0; i < TN; ++i) { const float d = t[i] - mean; q_ += d * d; }
                 const float rstd = 1.0f / sqrtf(wave_sum(q_) / (float)TBN + g.ln_eps);
-                // TransitionUp: + three-nearest-neighbour interpolation of the coarser level's rows (same expression order as
-                // interp3_add_kernel, nn_ops.hip); indices and distances of a row are wave-uniform
-                const float* f0 = nullptr; const float* f1 = nullptr; const float* f2 = nullptr;
-                float w0 = 0.f, w1 = 0.f, w2 = 0.f;
-                if (g.ip_feat) {
-                    const int* ii = g.ip_idx + (size_t)row * 3;
-                    const float* dd = g.ip_dist2 + (size_t)row * 3;
-                    w0 = 1.0f / (sqrtf(dd[0]) + 1e-8f); w1 = 1.0f / (sqrtf(dd[1]) + 1e-8f); w2 = 1.0f / (sqrtf(dd[2]) + 1e-8f);
-                    const float ws = (w0 + w1) + w2;
-                    w0 /= ws; w1 /= ws; w2 /= ws;
-                    f0 = g.ip_feat + (size_t)ii[0] * TBN; f1 = g.ip_feat + (size_t)ii[1] * TBN; f2 = g.ip_feat + (size_t)ii[2] * TBN;
-                }
 #pragma unroll
                 for (int i = 0; i < TN; ++i) {
                     float y = (t[i] - mean) * rstd * gam[i] + bet[i];
                     if (g.ln_post) y += g.ln_post[(size_t)row * TBN + lane + 64 * i];
                     if (g.ln_relu) y = fmaxf(y, 0.f);
-                    if (f0) {
-                        const int c = lane + 64 * i;
+                    if (g.ip_feat) {   // TransitionUp: + three-nearest-neighbour interpolation, after the activation
                         float acc = 0.f;
-                        acc += f0[c] * w0; acc += f1[c] * w1; acc += f2[c] * w2;
+                        acc += fc0[i] * w0; acc += fc1[i] * w1; acc += fc2[i] * w2;
                         y = y + acc;
                     }
                     C[(size_t)row * g.ldc + lane + 64 * i] = y;
