@@ -38,9 +38,19 @@ def check(status, what=""):
 
 
 def ptr(t):
-    """Device pointer of a torch tensor (or None -> NULL)."""
+    """Device pointer of a torch tensor (or None -> NULL).  A host tensor is an error, not a fallback: every entry point of the
+    library dereferences its pointers on the device."""
     if t is None:
         return ctypes.c_void_p(0)
+    if not t.is_cuda:
+        raise RoitrError("roitr_amd needs ROCm device tensors (no CPU fallback): got a tensor on " + str(t.device))
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def host_ptr(t):
+    """Pointer of a HOST tensor, for the few host-side entry points (roitr_geo_table_build)."""
+    if t.is_cuda:
+        raise RoitrError("host_ptr: expected a CPU tensor")
     return ctypes.c_void_p(t.data_ptr())
 
 

@@ -276,8 +276,9 @@ def geo_table_build(div_term, w_d, b_d, w_a, b_a, interval=2.0, d_range=48.0, a_
     div_h, wd_h, bd_h, wa_h, ba_h = map(h, (div_term, w_d, b_d, w_a, b_a))
     table = torch.empty(int(lib.roitr_geo_table_floats(C, nd, na)), dtype=torch.float32)
     fit = (ctypes.c_double * 4)()
-    L.check(lib.roitr_geo_table_build(C, L.ptr(div_h), L.ptr(wd_h), L.ptr(bd_h), L.ptr(wa_h), L.ptr(ba_h), L.c_float(interval), nd, na,
-                                      L.ptr(table), fit), "geo_table_build")
+    hp = L.host_ptr
+    L.check(lib.roitr_geo_table_build(C, hp(div_h), hp(wd_h), hp(bd_h), hp(wa_h), hp(ba_h), L.c_float(interval), nd, na,
+                                      hp(table), fit), "geo_table_build")
     return table.to(w_d.device), nd, na, list(fit)
 
 
