@@ -80,7 +80,8 @@ def test_builder_rejects_bad_arguments():
     z = torch.zeros(C * C)
     fit = (ctypes.c_double * 4)()
     out = torch.zeros(int(lib.roitr_geo_table_floats(C, 4, 4)))
-    args = lambda h, nd: (C, L.ptr(z), L.ptr(z), L.ptr(z), L.ptr(z), L.ptr(z), L.c_float(h), nd, 4, L.ptr(out), fit)
+    hp = L.host_ptr   # the table builder is a host function
+    args = lambda h, nd: (C, hp(z), hp(z), hp(z), hp(z), hp(z), L.c_float(h), nd, 4, hp(out), fit)
     assert lib.roitr_geo_table_build(*args(3.0, 4)) != 0     # the interval must be a power of two (exact index arithmetic)
     assert lib.roitr_geo_table_build(*args(2.0, 0)) != 0
     assert lib.roitr_geo_table_build(*args(2.0, 4)) == 0
