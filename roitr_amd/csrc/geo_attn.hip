@@ -527,66 +527,96 @@ __global__ __launch_bounds__(256) void mha_geo_stream_kernel(RoitrMha a)
 // ------------------------------------------------------------------ plain multi-head attention (cross layers), C = 256, 4 heads
 // geoattention.py:26-66 on the same lane = channel-quad layout as mha_geo_kernel: key rows are read coalesced (one
 // float4 per lane, head = DPP row), the four waves split the keys, values are accumulated by thread = channel.
+// Round 3: a block takes QB = 4 consecutive query rows.  With one row per block every query re-read all key and value rows of the
+// partner cloud from L2 (78 x 2 KB per query: 6.2 GB per launch at 512 pairs = 28 TB/s -- the kernel ran at the L2's bandwidth, not
+// at HBM's); rows of the same cloud now share each loaded row (4 dot products / 4 accumulations per load).  A block whose rows
+// straddle a cloud boundary works through its runs of equal cloud one after the other.  Per query the arithmetic and its order are
+// those of the one-row form: results are bit-identical.
 template <int NKP>   // keys per cloud bound (LDS score rows, softmax registers)
 __global__ __launch_bounds__(256) void mha_plain_kernel(RoitrMha a)
 {
-    constexpr int NH = 4;
-    __shared__ float sc[NH][NKP];
+    constexpr int NH = 4, QB = 4;
+    __shared__ float sc[QB][NH][NKP];
     // XCD-aware row order: every XCD (private L2) gets a contiguous range of query rows, so the key / value rows of a cloud
     // are fetched into ONE L2 instead of all eight (PMC before: 1.27x the algorithmic bytes on the self layers)
-    const int rowi = xcd_block_id(a.q_rows);
-    if (rowi >= a.q_rows) return;
-    const int row = a.q_row0 + rowi;
+    const int nblk = (a.q_rows + QB - 1) / QB;
+    const int blk = xcd_block_id(nblk);
+    if (blk >= nblk) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hl = lane >> 4;
-    const int cl = a.cloud_of_row[row];
-    const int kc = a.partner ? a.partner[cl] : cl;
-    const int ks = kc == 0 ? 0 : a.offset[kc - 1], nk = a.offset[kc] - ks;
-    const float4 qv = reinterpret_cast<const float4*>(a.q + (size_t)row * a.ldq)[lane];
-    const float* kbase = a.k + (size_t)ks * a.ldk + lane * 4;
-    for (int j0 = wave; j0 < nk; j0 += 16) {   // 4 keys of this wave per trip, loads issued together
-        float4 kv[4];
+    const int r_first = blk * QB, r_end = min(r_first + QB, a.q_rows);
+    for (int r0 = r_first; r0 < r_end;) {
+        const int row0 = a.q_row0 + r0;
+        const int cl = a.cloud_of_row[row0];
+        int nq = 1;                                            // rows of this run: same cloud as row0 (block-uniform)
+        while (r0 + nq < r_end && a.cloud_of_row[row0 + nq] == cl) ++nq;
+        const int kc = a.partner ? a.partner[cl] : cl;
+        const int ks = kc == 0 ? 0 : a.offset[kc - 1], nk = a.offset[kc] - ks;
+        float4 qv[QB];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int j = j0 + 4 * u;
-            kv[u] = *reinterpret_cast<const float4*>(kbase + (size_t)(j < nk ? j : nk - 1) * a.ldk);
+        for (int q = 0; q < QB; ++q) qv[q] = reinterpret_cast<const float4*>(a.q + (size_t)(row0 + (q < nq ? q : 0)) * a.ldq)[lane];
+        const float* kbase = a.k + (size_t)ks * a.ldk + lane * 4;
+        for (int j0 = wave; j0 < nk; j0 += 16) {   // 4 keys of this wave per trip, loads issued together
+            float4 kv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j = j0 + 4 * u;
+                kv[u] = *reinterpret_cast<const float4*>(kbase + (size_t)(j < nk ? j : nk - 1) * a.ldk);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j = j0 + 4 * u;
+#pragma unroll
+                for (int q = 0; q < QB; ++q) {
+                    const float s = row_allsum(dot4(qv[q], kv[u]));
+                    if (j < nk && (lane & 15) == 0) sc[q][hl][j] = s * a.scale;
+                }
+            }
         }
+        __syncthreads();
+        {   // softmax over the keys: wave = head, one query after the other
+            const int h = wave;
+            for (int q = 0; q < nq; ++q) {
+                float e1[NKP / 64];
+                float mx = -INFINITY;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int j = j0 + 4 * u;
-            const float s = row_allsum(dot4(qv, kv[u]));
-            if (j < nk && (lane & 15) == 0) sc[hl][j] = s * a.scale;
+                for (int u = 0; u < NKP / 64; ++u) { const int j = lane + 64 * u; e1[u] = j < nk ? sc[q][h][j] : -INFINITY; mx = fmaxf(mx, e1[u]); }
+                mx = wave_max(mx);
+                float sm = 0.f;
+#pragma unroll
+                for (int u = 0; u < NKP / 64; ++u) { const int j = lane + 64 * u; e1[u] = j < nk ? expf(e1[u] - mx) : 0.f; sm += e1[u]; }
+                sm = wave_sum(sm);
+#pragma unroll
+                for (int u = 0; u < NKP / 64; ++u) { const int j = lane + 64 * u; if (j < nk) sc[q][h][j] = e1[u] / sm; }
+            }
         }
-    }
-    __syncthreads();
-    {   // softmax over the keys: wave = head
-        const int h = wave;
-        float e1[NKP / 64];
-        float mx = -INFINITY;
+        __syncthreads();
+        {
+            const int h = tid >> 6;
+            const float* vp = a.v + (size_t)ks * a.ldv + tid;
+            float acc[QB];
 #pragma unroll
-        for (int u = 0; u < NKP / 64; ++u) { const int j = lane + 64 * u; e1[u] = j < nk ? sc[h][j] : -INFINITY; mx = fmaxf(mx, e1[u]); }
-        mx = wave_max(mx);
-        float sm = 0.f;
+            for (int q = 0; q < QB; ++q) acc[q] = 0.f;
+            int j = 0;
+            for (; j + 8 <= nk; j += 8) {
+                float vv[8];
 #pragma unroll
-        for (int u = 0; u < NKP / 64; ++u) { const int j = lane + 64 * u; e1[u] = j < nk ? expf(e1[u] - mx) : 0.f; sm += e1[u]; }
-        sm = wave_sum(sm);
+                for (int u = 0; u < 8; ++u) vv[u] = vp[(size_t)(j + u) * a.ldv];
 #pragma unroll
-        for (int u = 0; u < NKP / 64; ++u) { const int j = lane + 64 * u; if (j < nk) sc[h][j] = e1[u] / sm; }
-    }
-    __syncthreads();
-    {
-        const int h = tid >> 6;
-        const float* vp = a.v + (size_t)ks * a.ldv + tid;
-        float acc = 0.f;
-        int j = 0;
-        for (; j + 8 <= nk; j += 8) {
-            float vv[8];
+                for (int u = 0; u < 8; ++u)
 #pragma unroll
-            for (int u = 0; u < 8; ++u) vv[u] = vp[(size_t)(j + u) * a.ldv];
+                    for (int q = 0; q < QB; ++q) acc[q] = fmaf(sc[q][h][j + u], vv[u], acc[q]);
+            }
+            for (; j < nk; ++j) {
+                const float vv = vp[(size_t)j * a.ldv];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) acc = fmaf(sc[h][j + u], vv[u], acc);
+                for (int q = 0; q < QB; ++q) acc[q] = fmaf(sc[q][h][j], vv, acc[q]);
+            }
+#pragma unroll
+            for (int q = 0; q < QB; ++q)
+                if (q < nq) a.out[(size_t)(row0 + q) * a.ldo + tid] = acc[q];
         }
-        for (; j < nk; ++j) acc = fmaf(sc[h][j], vp[(size_t)j * a.ldv], acc);
-        a.out[(size_t)row * a.ldo + tid] = acc;
+        r0 += nq;
+        if (r0 < r_end) __syncthreads();   // the score table is re-used by the next run
     }
 }
 
@@ -848,8 +878,8 @@ extern "C" int roitr_mha(const RoitrMha* a, hipStream_t stream)
         return ROITR_OK;
     }
     const bool plain = !a->E && a->C == 256 && a->heads == 4 && a->ldq % 4 == 0 && a->ldk % 4 == 0 && a->nk_max <= 1024;
-    if (plain && a->nk_max <= 128) mha_plain_kernel<128><<<xcd_grid(a->q_rows), 256, 0, stream>>>(*a);
-    else if (plain) mha_plain_kernel<1024><<<xcd_grid(a->q_rows), 256, 0, stream>>>(*a);
+    if (plain && a->nk_max <= 128) mha_plain_kernel<128><<<xcd_grid(div_up(a->q_rows, 4)), 256, 0, stream>>>(*a);
+    else if (plain) mha_plain_kernel<1024><<<xcd_grid(div_up(a->q_rows, 4)), 256, 0, stream>>>(*a);
     else if (geo && a->nk_max <= 80) mha_geo_kernel<20><<<xcd_grid(a->q_rows), 256, 0, stream>>>(*a);
     else if (geo) mha_geo_kernel<32><<<xcd_grid(a->q_rows), 256, 0, stream>>>(*a);
     else
