@@ -418,6 +418,8 @@ extern "C" int roitr_gemm(const RoitrGemm* g, hipStream_t stream)
     // Also measured and removed (round 1-2): an LDS-DMA variant (global_load_lds_dwordx4 into a swizzled row-major image, two
     // stages, one barrier per slab): 98 vs 95 TFLOP/s at K = 2048 and 84 vs 80 at K = 256, but 62 vs 74 at K = 128 and 44 vs
     // 56 at K = 64 (32 KB of LDS per block: 5 instead of 7 resident blocks) -> 19.8 vs 17.9 ms of GEMM per 128-pair forward.
+    // Round 3, measured and removed: s_setprio(1) around the 16 MFMAs of a slab (the waves in their MFMA phase first): 38.6 - 39.2 vs
+    // 37.8 ms of GEMM per 512-pair step.
     // Round 3, measured and removed: a second kernel for K >= 128 / N >= 192 built like the on-chip GEMMs of local_block.hip
     // (v_mfma_f32_16x16x4_f32, weight fragments as float4 straight from L1 / L2, only A staged: 64 x 64-k slabs, double buffered,
     // one barrier per 64 k).  Correct (float64 test, all shapes of the forward) but 1.35-1.5x SLOWER on every shape it took
