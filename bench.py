@@ -418,6 +418,13 @@ def attach_traffic(roofs, B, config):
             if n:
                 roof["traffic"] = round(sum(v["hbm_bytes_per_launch"] * v["launches"] for v in ks) / n)
                 roof["traffic_source"] = src
+            # what an exact kNN is bound by: the share of the chip's VALU issue slots its kernels use (SQ pass of this command,
+            # kernels serialised; scripts/sq_pass.sh -> scripts/sq_forward_json.py)
+            sq = load_profile_json("sq_forward.json")
+            if sq and sq.get("knn_family"):
+                roof["valu_issue_frac"] = sq["knn_family"]["valu_issue_frac"]
+                roof["valu_issue_per_kernel"] = {n: v["valu_issue_frac"] for n, v in sq.get("kernels", {}).items() if n.startswith("knn_")}
+                roof["valu_issue_source"] = "profiles/sq_forward.json (" + sq.get("definition", "") + ")"
             continue
         k = pmc.get("kernels", {}).get(name)
         if k:

@@ -37,4 +37,5 @@ tail -1 $out/bench_c5.log > $out/${tag}_bench_config5.json
 bash scripts/knn_config5_sq.sh $out/knn5sq > $out/${tag}_knn_config5_sq.txt 2>&1
 cp $out/knn5sq/sq_knn_config5.json $out/sq_knn_config5.json
 bash scripts/sq_pass.sh $out/sq > $out/${tag}_sq_pass.txt 2>&1
+python scripts/sq_forward_json.py $out/sq/a $out/sq_forward.json > /dev/null 2>&1
 for f in $out/${tag}_bench*.json; do echo $f; cut -c1-400 $f; done
