@@ -319,91 +319,107 @@ __device__ __forceinline__ float row_allmax(float v)
     return v;
 }
 
-template <int V, int HQ>   // V = in_dim / 64 (x channels per lane), HQ = H / 64 (q / output channels per lane); K = 16, 4 heads
+template <int V, int HQ, int NPW>   // V = in_dim / 64 (x channels per lane), HQ = H / 64 (q / output channels per lane); K = 16, 4 heads
 __global__ __launch_bounds__(256) void local_attn_fold_kernel(RoitrLocalAttnFold a)
 {
+    // NPW = nodes a wave works on at once (the gathers of all of them in flight together); per node the arithmetic and its order do
+    // not depend on it.  The launcher uses NPW = 1 (see there).
     constexpr int K = 16, I = 64 * V, H = 64 * HQ;
-    __shared__ __attribute__((aligned(16))) float probs[4][64];   // per wave: [head][neighbour]
+    __shared__ __attribute__((aligned(16))) float probs[4][NPW][64];   // per wave and node: [head][neighbour]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int slot = xcd_block_id((a.M + 3) >> 2) * 4 + wave;
-    if (slot >= a.M) return;
-    int nd = slot;
-    if (a.node_order) nd = __float_as_int(reinterpret_cast<const float4*>(a.node_order)[slot].w);
-    const int node = __builtin_amdgcn_readfirstlane(nd);
+    const int slot0 = (xcd_block_id((a.M + 4 * NPW - 1) / (4 * NPW)) * 4 + wave) * NPW;
+    if (slot0 >= a.M) return;
     const int h = lane >> 4, i16 = lane & 15, kk_l = row16_slot(i16);
+    int node[NPW]; bool live[NPW];
+#pragma unroll
+    for (int n = 0; n < NPW; ++n) {
+        live[n] = slot0 + n < a.M;                       // wave-uniform
+        const int sl = live[n] ? slot0 + n : slot0;      // a dead slot recomputes node slot0 and stores nothing
+        int nd = sl;
+        if (a.node_order) nd = __float_as_int(reinterpret_cast<const float4*>(a.node_order)[sl].w);
+        node[n] = __builtin_amdgcn_readfirstlane(nd);
+    }
     // ---- round trip 1: addressed by the node id
-    const int g = a.group_idx[(size_t)node * K + i16];
-    float qt[4][V], qv[HQ];
+    int g[NPW]; float qt[NPW][4][V], qv[NPW][HQ]; float4 pf[NPW];
 #pragma unroll
-    for (int hh = 0; hh < 4; ++hh) VecLoad<V>::ld(a.qt + ((size_t)node * 4 + hh) * I + lane * V, qt[hh]);
-    VecLoad<HQ>::ld(a.q + (size_t)node * a.ldq + lane * HQ, qv);
-    const float4 pf = reinterpret_cast<const float4*>(a.ppf)[(size_t)node * K + kk_l];   // this lane's neighbour
-    // ---- round trip 2: the input rows of the 16 neighbours
-    float xr[K][V];
+    for (int n = 0; n < NPW; ++n) {
+        g[n] = a.group_idx[(size_t)node[n] * K + i16];
 #pragma unroll
-    for (int kk = 0; kk < K; ++kk) {
-        const int gk = __builtin_amdgcn_readlane(g, kk);
-        VecLoad<V>::ld(a.x + (size_t)gk * a.ldx + lane * V, xr[kk]);
+        for (int hh = 0; hh < 4; ++hh) VecLoad<V>::ld(a.qt + ((size_t)node[n] * 4 + hh) * I + lane * V, qt[n][hh]);
+        VecLoad<HQ>::ld(a.q + (size_t)node[n] * a.ldq + lane * HQ, qv[n]);
+        pf[n] = reinterpret_cast<const float4*>(a.ppf)[(size_t)node[n] * K + kk_l];   // this lane's neighbour
     }
-    // u_h = Wpe_h^T q_h: the PPF coefficients of the score (q_h . bpe_h is constant over the neighbours: dropped with q_h . bk'_h)
-    float u0 = 0.f, u1 = 0.f, u2 = 0.f, u3 = 0.f;
+    // ---- round trip 2: the input rows of the 16 neighbours of every node, all in flight together
+    float xr[NPW][K][V];
 #pragma unroll
-    for (int i = 0; i < HQ; ++i) {
-        const float4 w = reinterpret_cast<const float4*>(a.wpe)[lane * HQ + i];
-        u0 = fmaf(w.x, qv[i], u0); u1 = fmaf(w.y, qv[i], u1); u2 = fmaf(w.z, qv[i], u2); u3 = fmaf(w.w, qv[i], u3);
-    }
-    u0 = row_allsum(u0); u1 = row_allsum(u1); u2 = row_allsum(u2); u3 = row_allsum(u3);
-    // ---- 64 partial dot products per lane, reduced over the wave in three transposing stages
-    float z[16];
-    {
-        float w[32];
+    for (int n = 0; n < NPW; ++n)
 #pragma unroll
-        for (int i = 0; i < 32; ++i) {
-            const int h0 = i >> 4, k0 = i & 15;      // value i = (head h0, neighbour k0), value i + 32 = (head h0 + 2, neighbour k0)
-            float d0 = 0.f, d1 = 0.f;
-#pragma unroll
-            for (int c = 0; c < V; ++c) { d0 = fmaf(qt[h0][c], xr[k0][c], d0); d1 = fmaf(qt[h0 + 2][c], xr[k0][c], d1); }
-            w[i] = swap32_sum(d0, d1);
+        for (int kk = 0; kk < K; ++kk) {
+            const int gk = __builtin_amdgcn_readlane(g[n], kk);
+            VecLoad<V>::ld(a.x + (size_t)gk * a.ldx + lane * V, xr[n][kk]);
         }
 #pragma unroll
-        for (int i = 0; i < 16; ++i) z[i] = swap16_sum(w[i], w[i + 16]);
-    }
-    // row h now holds, lane for lane, the 4-row sums of head h's 16 values
-    const float tot = row16_transpose_sum(z, lane);
-    const float s = (tot + (u0 * pf.x + u1 * pf.y + u2 * pf.z + u3 * pf.w)) * a.scale;
-    const float mx = row_allmax(s);
-    const float e = expf(s - mx);
-    const float p = e / row_allsum(e);
-    probs[wave][h * 16 + kk_l] = p;
-    // pbar_h = sum_k p(h, k) ppf_k (every lane of row h)
-    const float pb0 = row_allsum(p * pf.x), pb1 = row_allsum(p * pf.y), pb2 = row_allsum(p * pf.z), pb3 = row_allsum(p * pf.w);
-    {
-        float o[HQ], bias[HQ];
-        VecLoad<HQ>::ld(a.bvpe + lane * HQ, bias);
+    for (int n = 0; n < NPW; ++n) {
+        // u_h = Wpe_h^T q_h: the PPF coefficients of the score (q_h . bpe_h is constant over the neighbours: dropped with q_h . bk'_h)
+        float u0 = 0.f, u1 = 0.f, u2 = 0.f, u3 = 0.f;
 #pragma unroll
         for (int i = 0; i < HQ; ++i) {
-            const float4 w = reinterpret_cast<const float4*>(a.wvpe)[lane * HQ + i];
-            o[i] = w.x * pb0 + w.y * pb1 + w.z * pb2 + w.w * pb3 + bias[i];
+            const float4 w = reinterpret_cast<const float4*>(a.wpe)[lane * HQ + i];
+            u0 = fmaf(w.x, qv[n][i], u0); u1 = fmaf(w.y, qv[n][i], u1); u2 = fmaf(w.z, qv[n][i], u2); u3 = fmaf(w.w, qv[n][i], u3);
         }
-        VecLoad<HQ>::st(a.vpart + (size_t)node * H + lane * HQ, o);
-    }
-    lds_fence();
-    // ---- xbar_h = sum_k p(h, k) x_k: the probabilities of a head are wave-uniform LDS broadcasts
+        u0 = row_allsum(u0); u1 = row_allsum(u1); u2 = row_allsum(u2); u3 = row_allsum(u3);
+        // ---- 64 partial dot products per lane, reduced over the wave in three transposing stages
+        float z[16];
+        {
+            float w[32];
 #pragma unroll
-    for (int hh = 0; hh < 4; ++hh) {
-        float acc[V];
+            for (int i = 0; i < 32; ++i) {
+                const int h0 = i >> 4, k0 = i & 15;      // value i = (head h0, neighbour k0), value i + 32 = (head h0 + 2, neighbour k0)
+                float d0 = 0.f, d1 = 0.f;
 #pragma unroll
-        for (int c = 0; c < V; ++c) acc[c] = 0.f;
-#pragma unroll
-        for (int q4 = 0; q4 < 4; ++q4) {
-            const float4 p4 = reinterpret_cast<const float4*>(probs[wave])[hh * 4 + q4];
-#pragma unroll
-            for (int c = 0; c < V; ++c) {
-                acc[c] = fmaf(p4.x, xr[4 * q4][c], acc[c]); acc[c] = fmaf(p4.y, xr[4 * q4 + 1][c], acc[c]);
-                acc[c] = fmaf(p4.z, xr[4 * q4 + 2][c], acc[c]); acc[c] = fmaf(p4.w, xr[4 * q4 + 3][c], acc[c]);
+                for (int c = 0; c < V; ++c) { d0 = fmaf(qt[n][h0][c], xr[n][k0][c], d0); d1 = fmaf(qt[n][h0 + 2][c], xr[n][k0][c], d1); }
+                w[i] = swap32_sum(d0, d1);
             }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) z[i] = swap16_sum(w[i], w[i + 16]);
         }
-        VecLoad<V>::st(a.xbar + ((size_t)node * 4 + hh) * I + lane * V, acc);
+        // row h now holds, lane for lane, the 4-row sums of head h's 16 values
+        const float tot = row16_transpose_sum(z, lane);
+        const float s = (tot + (u0 * pf[n].x + u1 * pf[n].y + u2 * pf[n].z + u3 * pf[n].w)) * a.scale;
+        const float mx = row_allmax(s);
+        const float e = expf(s - mx);
+        const float p = e / row_allsum(e);
+        probs[wave][n][h * 16 + kk_l] = p;
+        // pbar_h = sum_k p(h, k) ppf_k (every lane of row h)
+        const float pb0 = row_allsum(p * pf[n].x), pb1 = row_allsum(p * pf[n].y), pb2 = row_allsum(p * pf[n].z), pb3 = row_allsum(p * pf[n].w);
+        {
+            float o[HQ], bias[HQ];
+            VecLoad<HQ>::ld(a.bvpe + lane * HQ, bias);
+#pragma unroll
+            for (int i = 0; i < HQ; ++i) {
+                const float4 w = reinterpret_cast<const float4*>(a.wvpe)[lane * HQ + i];
+                o[i] = w.x * pb0 + w.y * pb1 + w.z * pb2 + w.w * pb3 + bias[i];
+            }
+            if (live[n]) VecLoad<HQ>::st(a.vpart + (size_t)node[n] * H + lane * HQ, o);
+        }
+        lds_fence();
+        // ---- xbar_h = sum_k p(h, k) x_k: the probabilities of a head are wave-uniform LDS broadcasts
+#pragma unroll
+        for (int hh = 0; hh < 4; ++hh) {
+            float acc[V];
+#pragma unroll
+            for (int c = 0; c < V; ++c) acc[c] = 0.f;
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                const float4 p4 = reinterpret_cast<const float4*>(probs[wave][n])[hh * 4 + q4];
+#pragma unroll
+                for (int c = 0; c < V; ++c) {
+                    acc[c] = fmaf(p4.x, xr[n][4 * q4][c], acc[c]); acc[c] = fmaf(p4.y, xr[n][4 * q4 + 1][c], acc[c]);
+                    acc[c] = fmaf(p4.z, xr[n][4 * q4 + 2][c], acc[c]); acc[c] = fmaf(p4.w, xr[n][4 * q4 + 3][c], acc[c]);
+                }
+            }
+            if (live[n]) VecLoad<V>::st(a.xbar + ((size_t)node[n] * 4 + hh) * I + lane * V, acc);
+        }
     }
 }
 
@@ -477,11 +493,12 @@ extern "C" int roitr_local_attention_fold(const RoitrLocalAttnFold* a, hipStream
     }
     // algorithmic bytes: q and q~ rows, 16 gathered input rows, ppf + idx in; xbar and the positional value row out
     roitr_prof_begin(ROITR_PROF_LOCAL_ATTN, (double)a->M * (a->H * 4.0 + 4.0 * a->in_dim * 4 + 16.0 * (a->in_dim * 4.0 + 20.0) + 4.0 * a->in_dim * 4 + a->H * 4.0), stream);
-    const int grid = xcd_grid(div_up(a->M, 4));
-#define LF_CASE(VV, QQ) local_attn_fold_kernel<VV, QQ><<<grid, 256, 0, stream>>>(*a)
-    if (v == 1 && hq == 2) LF_CASE(1, 2);
-    else if (v == 2 && hq == 4) LF_CASE(2, 4);
-    else if (v == 4 && hq == 4) LF_CASE(4, 4);
+    // one node per wave.  Measured at 512 pairs: two nodes per wave at V = 1 (NPW = 2: both nodes' gathers in flight together, 80 VGPRs)
+    // 3.5 vs 3.0 ms for the level-2 launch beside the geometry stream, 89.7 vs 89.4 ms per step -- kept as a template parameter only
+#define LF_CASE(VV, QQ, NN) local_attn_fold_kernel<VV, QQ, NN><<<xcd_grid(div_up(a->M, 4 * NN)), 256, 0, stream>>>(*a)
+    if (v == 1 && hq == 2) LF_CASE(1, 2, 1);
+    else if (v == 2 && hq == 4) LF_CASE(2, 4, 1);
+    else if (v == 4 && hq == 4) LF_CASE(4, 4, 1);
     else { roitr_prof_end(ROITR_PROF_LOCAL_ATTN, stream); return ROITR_ERR_UNSUPPORTED; }
 #undef LF_CASE
     roitr_prof_end(ROITR_PROF_LOCAL_ATTN, stream);
