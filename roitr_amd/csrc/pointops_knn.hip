@@ -1226,7 +1226,8 @@ __global__ __launch_bounds__(256) void knn_lane_kernel(int m, int nsample, int b
                 const bool face = (r == 0) || (cy == c0[1] - r) || (cy == c0[1] + r) || (cz == c0[2] - r) || (cz == c0[2] + r);
                 // a row of cells whose (y, z) slab lies farther from the query than the current worst list entry (or than the cap
                 // of roitr_knn_within) cannot contribute: nothing in it passes `dd < d[L - 1]` (round 3; same rounding margin as
-                // the stop rule below).  Lanes of a wave walk neighbouring cells, so they mostly agree.
+                // the stop rule below).  Lanes of a wave walk neighbouring cells, so they mostly agree.  (Trimming the cells of a face
+                // row from both ends by the same bound costs more than it saves: kNN 16.5 vs 11.5 ms per 512-pair step.)
                 if (r > 0) {
                     const float ylo = __fmaf_rn((float)cy, g.h, g.oy), zlo = __fmaf_rn((float)cz, g.h, g.oz);
                     const float dy = fmaxf(fmaxf(ylo - qy, qy - (ylo + g.h)), 0.f), dz = fmaxf(fmaxf(zlo - qz, qz - (zlo + g.h)), 0.f);
