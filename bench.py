@@ -61,7 +61,9 @@ WORKLOADS = {
 
 def parse():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None,
+                    help="ranks = GPUs of this node (one process per GPU).  Without a launcher (no WORLD_SIZE in the environment) and N > 1 the "
+                         "script starts the N ranks itself through torch.distributed.run; under a launcher it must equal WORLD_SIZE")
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=6)
     ap.add_argument("--config", type=int, default=2, choices=sorted(WORKLOADS))
@@ -81,17 +83,82 @@ def parse():
     return ap.parse_args()
 
 
+def test_engine_hook():
+    """ROITR_BENCH_TEST_ENGINE=/path/to/file.py (tests only): a module with `make(rank, world) -> (model, make_pool)` that stands in for
+    the HIP engine on CPU tensors, so that the launcher / sharding / aggregation logic of THIS script runs where there is no GPU
+    (tests/test_bench_launch_cpu.py; backend gloo).  The line it prints is marked `"data": "stub engine (test hook)"` and carries no
+    roofline -- never a measurement.  Unset (always, outside tests/): the HIP engine, and no GPU is an error."""
+    path = os.environ.get("ROITR_BENCH_TEST_ENGINE")
+    if not path:
+        return None
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("roitr_bench_test_engine", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher: start the N ranks (one process per GPU) through
+    torch.distributed.run on this node -- the same command line the driver's torchrun form uses -- and exit with its status.
+    The reference does the same job with mp/torchrun around main.py:27-30 (init_process_group per local rank)."""
+    import subprocess
+    if not os.environ.get("ROITR_BENCH_TEST_ENGINE"):
+        import torch
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < args.gpus:
+            raise SystemExit(f"bench.py --gpus {args.gpus}: this node shows {have} GPU(s); refusing to run a mislabeled job")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: what RCCL needs on this driver
+    env.setdefault("OMP_NUM_THREADS", "8")
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
 def main():
     args = parse()
+    launched = "WORLD_SIZE" in os.environ
+    if args.gpus is None:
+        args.gpus = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if not launched and args.gpus > 1:
+        launch_ranks(args)          # does not return
     import torch
     import torch.distributed as dist
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks; they must agree "
+                         "(n_gpus of the JSON line is the number of ranks that really ran)")
     distributed = world > 1
+    hook = test_engine_hook()
+    if hook is not None:
+        args.test_engine = hook
+        if distributed:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("gloo")
+        out = forward_bench(args, rank, world, distributed)
+        if distributed:
+            dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps(out), flush=True)
+        return
+    args.test_engine = None
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback in roitr_amd)")
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"bench.py: local rank {local_rank} has no GPU ({torch.cuda.device_count()} visible)")
     torch.cuda.set_device(local_rank)
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -138,11 +205,17 @@ def forward_bench(args, rank, world, distributed):
     N = args.n_points or wl["n_points"]
     weights = args.weights or wl.get("weights", "plain")
     normals = "field" if weights == "selective" else "random"
-    model = build_model(wl["benchmark"], operand_dtype=dtype, weights=weights)
+    stub = args.test_engine is not None
     # distinct resident pairs, cycled; pair ids are sharded over ranks exactly like the test loop would
     n_resident = max(B + B // 2, 16)
     ids = pairs_for_rank(n_resident * world, rank, world)
-    pool = [pair_to_device(make_pair(N, config=wl["seed_config"], pair_index=i, normals=normals)) for i in ids]
+    if stub:     # tests only (test_engine_hook): CPU stand-in for the engine, launcher / sharding / aggregation are the real ones
+        model, make_pool = args.test_engine.make(rank, world)
+        pool = make_pool(ids)
+        args.no_profile_pass = args.no_single_pair = args.no_cpu_baseline = True
+    else:
+        model = build_model(wl["benchmark"], operand_dtype=dtype, weights=weights)
+        pool = [pair_to_device(make_pair(N, config=wl["seed_config"], pair_index=i, normals=normals)) for i in ids]
 
     def batch(step):
         return [pool[(step * B + j) % len(pool)] for j in range(B)]
@@ -150,7 +223,8 @@ def forward_bench(args, rank, world, distributed):
     def barrier():
         if distributed:
             dist.barrier()
-        torch.cuda.synchronize()
+        if not stub:
+            torch.cuda.synchronize()
 
     spp = args.record_scores_per_pair
     trace = bool(os.environ.get("ROITR_BENCH_TRACE"))
@@ -214,7 +288,7 @@ def forward_bench(args, rank, world, distributed):
         "scaling": "weak",
         "vs_baseline": None,
         "dtype": dtype,
-        "data": "synthetic",
+        "data": "stub engine (test hook), not a measurement" if stub else "synthetic",
         "config": {
             "workload": wl["text"].format(N=N, B=B),
             "baseline_config": args.config,
@@ -225,7 +299,7 @@ def forward_bench(args, rank, world, distributed):
             "correspondences_found": agg["n_corr"],
         },
     }
-    gt = model.geo_table_info()
+    gt = None if stub else model.geo_table_info()
     out["config"]["geometric_embedding"] = (
         "function table (csrc/geo_table.hip): degree-7 polynomial per channel on intervals of %g, %d distance + %d angle intervals, "
         "float64 fit error %.1e / %.1e of the amplitude" % (gt["interval"], gt["n_int_d"], gt["n_int_a"], gt["fit_d"] / max(gt["amp_d"], 1e-30),
