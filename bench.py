@@ -43,10 +43,10 @@ MFMA_F32_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: fp32-input MFMA = the fp
 MFMA_BF16_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: ~2.5 PF dense bf16
 
 WORKLOADS = {
-    2: dict(benchmark="3DMatch", n_points=5000, pairs=512, dtype="f32", seed_config=2,
+    2: dict(benchmark="3DMatch", n_points=5000, pairs=512, dtype="f32", seed_config=2, weights="selective",
             text="3DMatch-sized synthetic pairs: {N} pts/cloud src+tgt, fp32, 3DMatch test settings (P=256 patches x 64 pts, "
                  "100 Sinkhorn iterations), full RIGA_v2 forward"),
-    3: dict(benchmark="3DLoMatch", n_points=5000, pairs=512, dtype="f32", seed_config=3,
+    3: dict(benchmark="3DLoMatch", n_points=5000, pairs=512, dtype="f32", seed_config=3, weights="selective",
             text="3DLoMatch-rotated synthetic pairs: {N} pts/cloud, seeded test-time SO(3) rotation of one cloud "
                  "(dataset/tdmatch.py:99-112), fp32, 3DMatch test settings, full RIGA_v2 forward"),
     4: dict(benchmark="4DMatch", n_points=8000, pairs=32, dtype="bf16", seed_config=4, weights="selective",
@@ -71,14 +71,15 @@ def parse():
     ap.add_argument("--n-points", type=int, default=None)
     ap.add_argument("--dtype", default=None, choices=["f32", "bf16"], help="operand storage of the dense layers (default: the config's)")
     ap.add_argument("--weights", default=None, choices=["plain", "selective"],
-                    help="closed-form weight variant (roitr_amd/weights.py); default: the config's (plain for 2 / 3, selective for 4)")
+                    help="closed-form weight variant (roitr_amd/weights.py); default: selective -- descriptors that discriminate, thousands of "
+                         "correspondences per pair (round 4; 'plain' ends in ~34 per pair, i.e. times the matching tail on near-empty outputs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-single-pair", action="store_true", help="skip the one-pair-per-call measurement (profiling passes)")
     ap.add_argument("--no-profile-pass", action="store_true", help="skip the instrumented repeat of the timed steps (no rooflines)")
     ap.add_argument("--no-rccl-selftest", action="store_true",
                     help="N=1 without torch.distributed.run: do NOT create the 1-rank RCCL group the result gather otherwise runs through")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=20.0)
-    ap.add_argument("--record-scores-per-pair", type=int, default=1020,
+    ap.add_argument("--record-scores-per-pair", type=int, default=4092,
                     help="average score capacity per pair of the gathered result block (shard.py); the block carries every timed step")
     return ap.parse_args()
 

@@ -27,6 +27,13 @@
     } while (0)
 
 void roitr_set_error(const char* msg, const char* file, int line);
+// error.cpp: raise a kernel's dynamic-LDS limit on the current device (once per kernel and device, checked)
+int roitr_grant_dynamic_lds(const void* kernel, int bytes);
+#define ROITR_GRANT_LDS(kernel, bytes)                                                  \
+    do {                                                                                \
+        const int g__ = roitr_grant_dynamic_lds(reinterpret_cast<const void*>(kernel), (int)(bytes)); \
+        if (g__ != ROITR_OK) return g__;                                                \
+    } while (0)
 
 static inline int div_up(long a, long b) { return (int)((a + b - 1) / b); }
 

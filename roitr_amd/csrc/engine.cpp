@@ -126,8 +126,9 @@ struct Engine {
     hipEvent_t pinned_ev[RING] = {nullptr, nullptr, nullptr, nullptr};
     int ring_pos = 0;
     hipStream_t side = nullptr;      // the geometry chain (FPS, grids, kNN + PPF of levels 2-4, 3-NN, embedding E, partition, GT outputs)
-    static constexpr int NEV = 8;
-    hipEvent_t ev[NEV] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    static constexpr int NEV = 9;    // [8]: the error-path join of roitr_engine_forward
+    hipEvent_t ev[NEV] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    bool side_forked = false;        // the current forward has issued work on `side` that `st` has not joined yet
     std::string err;
     hipStream_t fin_stream = nullptr;   // stream of the running finalize (weight conversions are queued on it)
     // ---- captured forwards (roitr_engine_forward_graph): one hipGraphExec per (sizes, io pointers) key
@@ -849,7 +850,26 @@ extern "C" int roitr_engine_geo_table_info(void* h, double* info)
     return 1;
 }
 
+static int forward_body(void* h, const RoitrForwardIO* io, hipStream_t st);
+
+/* One engine = one main stream at a time: the side stream and its events are per engine, so two forwards of the same engine must
+ * be ordered on the caller's stream (the Python side guarantees it: launch_batch uses torch's current stream).  An early return
+ * between the fork and the last join (arena exhausted, unsupported shape, a HIP error) would leave side-stream work un-joined --
+ * racing with the next forward's arena reuse, or ending a graph capture with an unjoined stream: the wrapper joins it. */
 extern "C" int roitr_engine_forward(void* h, const RoitrForwardIO* io, hipStream_t st)
+{
+    Engine& E = *(Engine*)h;
+    E.side_forked = false;
+    const int rc = forward_body(h, io, st);
+    if (rc != ROITR_OK && E.side_forked && E.side && E.ev[8]) {
+        if (hipEventRecord(E.ev[8], E.side) == hipSuccess) (void)hipStreamWaitEvent(st, E.ev[8], 0);
+        else (void)hipStreamSynchronize(E.side);
+    }
+    E.side_forked = false;
+    return rc;
+}
+
+static int forward_body(void* h, const RoitrForwardIO* io, hipStream_t st)
 {
     Engine& E = *(Engine*)h;
     if (!E.finalized) { roitr_set_error("engine not finalized", __FILE__, __LINE__); return ROITR_ERR_ARG; }
@@ -1009,6 +1029,7 @@ extern "C" int roitr_engine_forward(void* h, const RoitrForwardIO* io, hipStream
 
         // ---- side stream
         ROITR_HIP(hipStreamWaitEvent(sd, E.ev[0], 0));
+        E.side_forked = true;
         for (int l = 1; l < 4; ++l) {
             const int K = E.nsample[l];
             // tmp = 1e10 (functions/pointops.py:22)
@@ -1298,6 +1319,7 @@ extern "C" int roitr_engine_forward(void* h, const RoitrForwardIO* io, hipStream
     roitr_prof_begin(ROITR_PROF_PH_MATCH, 0.0, st);
     // ---------------- heads (RIGA_v2.py:64-68) and node coordinates (model/model.py:233-235)
     ROITR_HIP(hipStreamWaitEvent(st, E.ev[7], 0));   // node coordinates, partition and ground-truth side outputs (side stream)
+    E.side_forked = false;                           // last join: everything the side stream was given is ordered before `st` from here
     float* node_feats = io->node_feats ? io->node_feats : A.get<float>((size_t)T4 * C4);
     float* point_feats = io->point_feats ? io->point_feats : A.get<float>((size_t)T1 * C4);
     {

@@ -847,8 +847,7 @@ extern "C" int roitr_mha(const RoitrMha* a, hipStream_t stream)
     if (a->heads > 8 || a->C % a->heads || c % 4 || a->ldk % 4 || a->C % 4) return ROITR_ERR_UNSUPPORTED;
     size_t floats = (size_t)a->C + (a->E ? (size_t)a->heads * a->C : 0) + (size_t)a->heads * a->nk_max * (a->E ? 2 : 1) + 8;
     if (floats * 4 > 150 * 1024) return ROITR_ERR_UNSUPPORTED;
-    static const hipError_t attr_ = hipFuncSetAttribute((const void*)mha_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-    (void)attr_;
+    ROITR_GRANT_LDS(mha_kernel, 150 * 1024);
     roitr_prof_begin(ROITR_PROF_MHA, -1.0, stream);   // bytes: roitr_prof_next_bytes of the caller (0 otherwise)
     {   // factor-2 width (C = 512) and / or E stored in bf16: the wide kernels
         const bool lay = a->heads == 4 && a->ldq % 4 == 0 && a->ldk % 4 == 0 && a->nk_max <= 512;

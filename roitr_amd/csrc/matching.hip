@@ -831,8 +831,7 @@ extern "C" int roitr_coarse_matching(const RoitrCoarse* a, hipStream_t stream)
     while (cap < (long)a->max_ref * a->max_src) cap <<= 1;
     if (cap > COARSE_LDS_KEYS) cap = COARSE_LDS_KEYS;
     if (a->num_corr > 1024) return ROITR_ERR_UNSUPPORTED;   // winners per chunk of the chunked top-k
-    static const hipError_t attr_ = hipFuncSetAttribute((const void*)coarse_match_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-    (void)attr_;
+    ROITR_GRANT_LDS(coarse_match_kernel, 128 * 1024);
     RoitrCoarse c = *a;
     c.lds_cap = (int)cap;
     coarse_match_kernel<<<a->pairs, 1024, cap * 8, stream>>>(c);
@@ -848,8 +847,7 @@ extern "C" int roitr_adaptive_matching(const RoitrCoarse* a, int min_num, float 
     while (cap < (long)a->max_ref * a->max_src) cap <<= 1;
     if (cap > COARSE_LDS_KEYS) cap = COARSE_LDS_KEYS;
     if (min_num > 1024) return ROITR_ERR_UNSUPPORTED;
-    static const hipError_t attr_ = hipFuncSetAttribute((const void*)adaptive_match_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-    (void)attr_;
+    ROITR_GRANT_LDS(adaptive_match_kernel, 128 * 1024);
     RoitrCoarse c = *a;
     c.lds_cap = (int)cap;
     adaptive_match_kernel<<<a->pairs, 1024, cap * 8, stream>>>(c, min_num, threshold);

@@ -90,7 +90,7 @@ constexpr int FPS_PTS_CAP = 8192;    // clouds up to this size keep an xyz copy 
 // their first m' positions: the running minimum distances of the picked points are the same numbers (same coordinates, same
 // arithmetic), the maximum over the subset is the maximum over the whole cloud and it sits at the same, unique, point.  A tie
 // is the only place where the reference's block-tournament order (which depends on the cloud size) could choose differently.
-// `tie_out[cloud]` = first pick index at which the maximum was shared (INT_MAX: none among the first `track` picks);
+// `tie_out[cloud]` = first pick index at which the maximum was shared (`track`: none among the first `track` picks);
 // `prev_tie` != null: this launch samples the previous level's picks -- a cloud whose prev_tie covers all m picks writes the
 // prefix and leaves (passing the value on for the level after it), every other cloud runs the real thing.
 template <int BLOCK, int PPT>
@@ -218,7 +218,9 @@ __global__ __launch_bounds__(BLOCK) void fps_kernel(const float* __restrict__ xy
     }
     __syncthreads();
     for (int j = 1 + tid; j < end_m - start_m && j < FPS_IDX_CAP; j += BLOCK) idx[start_m + j] = sidx[j];
-    if (tie_out && tid == 0) tie_out[bid] = track > 0 ? first_tie : 0;   // nothing tracked: the next level must not assume anything
+    // min(first tie, tracked picks): the next level's shortcut test `prev_tie >= m'` can then only pass for m' <= track, i.e. for
+    // picks whose uniqueness WAS recorded, whatever divisor the caller of the next level uses (0: nothing tracked)
+    if (tie_out && tid == 0) tie_out[bid] = track > 0 ? (first_tie < track ? first_tie : track) : 0;
 
 #pragma unroll
     for (int j = 0; j < PPT; ++j) {
@@ -309,9 +311,7 @@ extern "C" int roitr_furthestsampling_ex(int b, int n_max, const float* xyz, con
     const int forced = b <= 16 && n_max <= 512 * 16 ? 512 : 0;
 #define FPS_CASE(BLK, P)                                                                              \
     if (n_max <= (BLK) * (P) && (forced == 0 || forced == (BLK))) {                                   \
-        static const hipError_t attr_ = hipFuncSetAttribute((const void*)fps_kernel<BLK, P>,          \
-            hipFuncAttributeMaxDynamicSharedMemorySize, (int)fps_lds_bytes(BLK, FPS_PTS_CAP));        \
-        (void)attr_;                                                                                  \
+        ROITR_GRANT_LDS((fps_kernel<BLK, P>), fps_lds_bytes(BLK, FPS_PTS_CAP));                       \
         roitr_prof_begin(ROITR_PROF_FPS, -1.0, stream);                                               \
         fps_kernel<BLK, P><<<b, BLK, fps_lds_bytes(BLK, lds_pts), stream>>>(xyz, offset, new_offset, tmp, idx, mask, bits, lds_pts, prev_tie, tie_out, \
                                                                             track_div);                                             \

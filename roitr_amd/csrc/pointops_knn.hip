@@ -1112,8 +1112,9 @@ __global__ __launch_bounds__(256) void knn_prefilter_kernel(int m, int nsample, 
         }
     if (cnt < nsample + 1 || cnt > CAP) {
         // too few: the (nsample + 1)-th neighbour may lie outside the radius; too many: the table column is full.
-        // A box that covers its whole cloud has dm = inf: every point is a survivor, `too few` then means the cloud itself has
-        // fewer than nsample + 1 points -- the ring kernel fills the tail like the reference (KNN_FILL, segment start).
+        // A box that covers its whole cloud has dm = inf, but tau = min(dm, r_est) = r_est still cuts at the density radius: a
+        // query with too few survivors there goes to the ring kernel like any other (a second pass, exact results); that kernel
+        // also fills the tail like the reference (KNN_FILL, segment start) when the cloud has fewer than nsample + 1 points.
         const int slot = atomicAdd(retry_count, 1);
         retry_list[slot] = q;
         return;
