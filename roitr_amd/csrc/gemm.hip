@@ -59,6 +59,7 @@ __device__ __forceinline__ void load8(const float* __restrict__ p, int k, int K,
 // keeps every use of the prefetched registers behind it, so nothing forces a vmcnt wait between issuing the
 // prefetch and the MFMAs.  The generic variant keeps bounds-checked scalar tails.
 constexpr int ZERO_ROW_LEN = 2048;
+constexpr int GEMM_IL_MIN_TILES = 3072;   // 2 tiles per CU-slot of the 6 resident blocks x 256 CUs: below, latency rules
 __device__ __attribute__((aligned(16))) float g_zero_row[ZERO_ROW_LEN];
 
 // TN: 32x32 accumulators per wave along N; the block tile is 64 x (64 TN).  TN = 1 is the GEMM of the path (see the
@@ -67,7 +68,9 @@ __device__ __attribute__((aligned(16))) float g_zero_row[ZERO_ROW_LEN];
 // LN: fused LayerNorm epilogue (RoitrGemm::ln_*), N == 64 TN: the finished tile is parked row-major in the staging LDS
 // and every wave normalises 16 full rows with exactly the arithmetic (and summation order) of add_layernorm_kernel<TN>,
 // so the result is bitwise that of the two-launch sequence while the (M, N) intermediate never touches HBM.
-template <bool FAST, int TN, bool LN>
+// HA2 (FAST only): the launch has an elementwise addend A2 -- a template parameter, because a run-time `if (A2)` around staging
+// loads that are spread over the MFMA stream would turn their registers into phi nodes (hipcc then copies behind the loads and waits).
+template <bool FAST, int TN, bool LN, bool HA2 = false, bool IL = false>
 __global__ __launch_bounds__(256) void gemm_kernel(RoitrGemm g, int nx, int ny, int T)
 {
     constexpr bool WIDE_STORE = GEMM_WIDE_STORE != 0;
@@ -156,7 +159,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(RoitrGemm g, int nx, int ny, 
             ld8((g.A_cat && k >= g.k_cat) ? arowc + (k - g.k_cat) : arow + k, av);   // slab-uniform: k_cat % 32 == 0
 #pragma unroll
             for (int v = 0; v < TN; ++v) ld8(wrow[v] + k, wv[v]);
-            if (A2) ld8(arow2 + k, a2v);  // kernel-argument uniform
+            if (HA2) ld8(arow2 + k, a2v);
         } else {
             load8(arow, k, g.K, a_vec, av);
             load8(arow2, k, g.K, a_vec, a2v);
@@ -176,7 +179,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(RoitrGemm g, int nx, int ny, 
     float4* bw1 = reinterpret_cast<float4*>(Bs + (1 * TBN + r) * LDR + (kq >> 1));
     for (int k0 = 0; k0 < g.K; k0 += BK) {
         __syncthreads();
-        if (!FAST || A2) {
+        if (FAST ? HA2 : true) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) av[i] += a2v[i];
         }
@@ -187,19 +190,74 @@ __global__ __launch_bounds__(256) void gemm_kernel(RoitrGemm g, int nx, int ny, 
             bw1[v * 64 * LDR / 4] = make_float4(wv[v][1], wv[v][3], wv[v][5], wv[v][7]);
         }
         __syncthreads();
-        if (k0 + BK < g.K) fetch(k0 + BK + kf);
-        if (TN == 1) {
-            float4 af[4], bf[4];
+        if (FAST && IL) {
+            // Round 4: the staging loads of the next slab are ISSUED ONE AT A TIME BETWEEN THE MFMAs of this one.  Measured
+            // (scripts/micro/gemm_gen2.hip): with the 4 loads issued back to back behind the barrier the kernel runs at 99-113
+            // TFLOP/s whether the data is cache-hot or not and whether anybody waits for it or not; without them at 121-129 -- a
+            // VMEM instruction occupies its wave's issue slot until the address path accepts it, and four waves of a block (one
+            // per SIMD) present theirs in the same cycles.  Spread over the 16 TN MFMAs every issue hides under a running MFMA
+            // (+7-13 % on the K >= 256 shapes alone, gemm family 38.3 -> 36.9 ms per 512-pair step in the forward; bitwise the same
+            // results).  All fragments of the slab are read first, so nothing but MFMAs and these loads remains in the stream.  The
+            // last slab re-fetches itself (no branch in the stream).  IL = false (grids below GEMM_IL_MIN_TILES: the one-pair-per-call
+            // launches, a few waves on the whole chip) keeps the burst: there a load between two MFMAs of the ONE accumulator chain
+            // a wave has only lengthens the chain (3.48 -> 3.60 ms per pair with the interleave everywhere).
+            constexpr bool UPFRONT = TN <= 2;   // TN = 4: 80 fragment registers would cost the third wave per SIMD -- read per quarter
+            float4 af[4], bf[TN][4];
+            if (UPFRONT) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { af[i] = ar[i]; bf[i] = br[i]; }
+                for (int q = 0; q < 4; ++q) {
+                    af[q] = ar[q];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[i].x, acc[0], 0, 0, 0);
-                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[i].y, acc[0], 0, 0, 0);
-                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[i].z, acc[0], 0, 0, 0);
-                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[i].w, acc[0], 0, 0, 0);
+                    for (int v = 0; v < TN; ++v) bf[v][q] = br[v * 32 * LDR / 4 + q];
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
+            const int kn = (k0 + BK < g.K ? k0 + BK : k0) + kf;
+            const float* an = (g.A_cat && kn >= g.k_cat) ? arowc + (kn - g.k_cat) : arow + kn;   // slab-uniform: k_cat % 32 == 0
+            constexpr int NS = 2 * (1 + (HA2 ? 1 : 0) + TN), TOT = 16 * TN;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (!UPFRONT) {
+                    af[q] = ar[q];
+#pragma unroll
+                    for (int v = 0; v < TN; ++v) bf[v][q] = br[v * 32 * LDR / 4 + q];
+                }
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int v = 0; v < TN; ++v) {
+                        const float a = c == 0 ? af[q].x : c == 1 ? af[q].y : c == 2 ? af[q].z : af[q].w;
+                        const float b = c == 0 ? bf[v][q].x : c == 1 ? bf[v][q].y : c == 2 ? bf[v][q].z : bf[v][q].w;
+                        acc[v] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[v], 0, 0, 0);
+                        const int n = (q * 4 + c) * TN + v;
+#pragma unroll
+                        for (int i = 0; i < NS; ++i)
+                            if (n == (i * TOT + TOT / 2) / NS) {
+                                __builtin_amdgcn_sched_barrier(0);
+                                const int h = i & 1, o = h ? (SPLIT16 ? 16 : 4) : 0, j = i >> 1;   // half h of staging row j
+                                const float* src = j == 0 ? an : (HA2 && j == 1) ? arow2 + kn : wrow[j - 1 - (HA2 ? 1 : 0)] + kn;
+                                const float4 x = *reinterpret_cast<const float4*>(src + o);
+                                float* dst = j == 0 ? av : (HA2 && j == 1) ? a2v : wv[j - 1 - (HA2 ? 1 : 0)];
+                                dst[4 * h] = x.x; dst[4 * h + 1] = x.y; dst[4 * h + 2] = x.z; dst[4 * h + 3] = x.w;
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
+                    }
+            }
+            __builtin_amdgcn_sched_barrier(0);  // consumers of the prefetched registers stay below the MFMAs
         } else {
+            if (k0 + BK < g.K) fetch(k0 + BK + kf);
+            if (FAST && TN == 1) {   // every operand of the slab in VGPRs before the 16 back-to-back MFMAs
+                float4 af[4], bf[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { af[i] = ar[i]; bf[i] = br[i]; }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[i].x, acc[0], 0, 0, 0);
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[i].y, acc[0], 0, 0, 0);
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[i].z, acc[0], 0, 0, 0);
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[i].w, acc[0], 0, 0, 0);
+                }
+            } else
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const float4 af = ar[q];
@@ -214,8 +272,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(RoitrGemm g, int nx, int ny, 
                     acc[v] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.w, bf[v].w, acc[v], 0, 0, 0);
                 }
             }
+            if (FAST) __builtin_amdgcn_sched_barrier(0);  // consumers of the prefetched registers stay below the MFMAs
         }
-        if (FAST) __builtin_amdgcn_sched_barrier(0);  // consumers of the prefetched registers stay below the MFMAs
     }
     if (LN) {
         float* tile_ = smem;   // [RP][TBN + 1]
@@ -429,13 +487,23 @@ extern "C" int roitr_gemm(const RoitrGemm* g, hipStream_t stream)
     static const bool shapes = getenv("ROITR_GEMM_SHAPES") != nullptr;  // debug: per-shape timing table at exit (synchronous)
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (shapes) { hipEventCreate(&e0); hipEventCreate(&e1); hipEventRecord(e0, stream); }
+    const bool a2 = g->A2 != nullptr;
+    const bool il = T >= GEMM_IL_MIN_TILES;   // staging loads spread over the MFMA stream (see the kernel): large grids only
+#define GEMM_LAUNCH(F, TN_, LN_) \
+    do { \
+        if (a2 && il) gemm_kernel<F, TN_, LN_, true, true><<<grid, 256, 0, stream>>>(*g, nx, ny, T); \
+        else if (a2) gemm_kernel<F, TN_, LN_, true, false><<<grid, 256, 0, stream>>>(*g, nx, ny, T); \
+        else if (il) gemm_kernel<F, TN_, LN_, false, true><<<grid, 256, 0, stream>>>(*g, nx, ny, T); \
+        else gemm_kernel<F, TN_, LN_, false, false><<<grid, 256, 0, stream>>>(*g, nx, ny, T); \
+    } while (0)
     if (g->ln_gamma) {
         if (!fast) { if (tn != 1) return ROITR_ERR_UNSUPPORTED; gemm_kernel<false, 1, true><<<grid, 256, 0, stream>>>(*g, nx, ny, T); }
-        else if (tn == 1) gemm_kernel<true, 1, true><<<grid, 256, 0, stream>>>(*g, nx, ny, T);
-        else if (tn == 2) gemm_kernel<true, 2, true><<<grid, 256, 0, stream>>>(*g, nx, ny, T);
-        else gemm_kernel<true, 4, true><<<grid, 256, 0, stream>>>(*g, nx, ny, T);
-    } else if (fast) gemm_kernel<true, 1, false><<<grid, 256, 0, stream>>>(*g, nx, ny, T);
+        else if (tn == 1) GEMM_LAUNCH(true, 1, true);
+        else if (tn == 2) GEMM_LAUNCH(true, 2, true);
+        else GEMM_LAUNCH(true, 4, true);
+    } else if (fast) GEMM_LAUNCH(true, 1, false);
     else gemm_kernel<false, 1, false><<<grid, 256, 0, stream>>>(*g, nx, ny, T);
+#undef GEMM_LAUNCH
     if (shapes) {
         hipEventRecord(e1, stream); hipEventSynchronize(e1);
         float ms = 0; hipEventElapsedTime(&ms, e0, e1); hipEventDestroy(e0); hipEventDestroy(e1);
