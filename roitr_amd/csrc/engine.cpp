@@ -850,6 +850,19 @@ extern "C" int roitr_engine_geo_table_info(void* h, double* info)
     return 1;
 }
 
+// mean points per grid cell of level l (experiment switch ROITR_GRID_OCC="a,b,c,d")
+static float grid_occ(int l)
+{
+    static float occ[4] = {6.f, 6.f, 6.f, 6.f};
+    static const bool init = [] {
+        const char* e = getenv("ROITR_GRID_OCC");
+        if (e) sscanf(e, "%f,%f,%f,%f", &occ[0], &occ[1], &occ[2], &occ[3]);
+        return true;
+    }();
+    (void)init;
+    return occ[l];
+}
+
 static int forward_body(void* h, const RoitrForwardIO* io, hipStream_t st);
 
 /* One engine = one main stream at a time: the side stream and its events are per engine, so two forwards of the same engine must
@@ -1019,7 +1032,7 @@ static int forward_body(void* h, const RoitrForwardIO* io, hipStream_t st)
         if (grid[0]) {
             // 6 points per cell on average: at level 1 (k = 8) the sphere of one cell size then holds ~2.5 (k + 2) points, what
             // the prefilter kNN kernel's radius rule needs
-            CHK(roitr_knn_build_grid_ex(NC, V.T[0], T1, p[0], D.off[0], knn_ws[0], 6.0f, st));
+            CHK(roitr_knn_build_grid_ex(NC, V.T[0], T1, p[0], D.off[0], knn_ws[0], grid_occ(0), st));
             order[0] = roitr_knn_sorted_points(NC, V.T[0], T1, knn_ws[0]);
         }
         ROITR_HIP(hipEventRecord(E.ev[0], st));  // inputs + descriptors are in place
@@ -1043,7 +1056,7 @@ static int forward_body(void* h, const RoitrForwardIO* io, hipStream_t st)
             CHK(roitr_gather_rows(V.T[l], 3, nrm[l - 1], down[l], 0, (float*)nrm[l], sd));
             // grid over this level's points (refs for: own self-kNN, next level's TD query, finer level's 3-NN)
             if (grid[l]) {
-                CHK(roitr_knn_build_grid_ex(NC, V.T[l], V.T[l - 1], p[l], D.off[l], knn_ws[l], 6.0f, sd));
+                CHK(roitr_knn_build_grid_ex(NC, V.T[l], V.T[l - 1], p[l], D.off[l], knn_ws[l], grid_occ(l), sd));
                 order[l] = roitr_knn_sorted_points(NC, V.T[l], V.T[l - 1], knn_ws[l]);
             }
             CHK(roitr_knnquery_ex(NC, V.T[l], V.T[l], K + 1, p[l], p[l], D.off[l], D.off[l], nullptr, nullptr, g_self[l], ppf_self[l], nrm[l],

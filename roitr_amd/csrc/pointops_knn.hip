@@ -257,9 +257,15 @@ __global__ __launch_bounds__(1024) void grid_build_kernel(const float* __restric
         const float lo = -wave_max(-mn[a]), hi = wave_max(mx[a]);
         if (lane == 0) { red[a][wave] = lo; red[3 + a][wave] = hi; }
     }
-    for (int k = tid; k < GRID_MAX_CELLS; k += 1024) cnt[k] = 0;
+    __shared__ int occ_cells;
+    __shared__ int refine;
+    if (tid == 0) occ_cells = 0;
     __syncthreads();
-    if (tid == 0) {
+    // cell size: from the bounding box first (h^3 = volume * target / n), then -- round 4 -- corrected by what the first histogram
+    // says: a cloud is not its bounding box (a rotated cube fills a third of it, a scanned surface a few per cent), the cells that
+    // hold points at all then carry 3 - 20 x the target and every query scans that many more candidates.  The second (third) pass
+    // sizes the cells so that the OCCUPIED ones hold the target on average.
+    auto choose = [&](float h_want) {   // thread 0: dims for a cell size (>= the 255-per-axis and GRID_MAX_CELLS limits)
         float lo[3], ext[3], me = 0.f;
         for (int a = 0; a < 3; ++a) {
             float l = red[a][0], h = red[3 + a][0];
@@ -268,9 +274,12 @@ __global__ __launch_bounds__(1024) void grid_build_kernel(const float* __restric
             lo[a] = l; ext[a] = h - l; me = fmaxf(me, ext[a]);
         }
         if (!(me > 0.f)) me = 1.f;
-        float vol = 1.f;
-        for (int a = 0; a < 3; ++a) vol *= fmaxf(ext[a], 1e-3f * me);
-        float h = cbrtf(vol * target_occupancy / (float)(n > 0 ? n : 1));
+        float h = h_want;
+        if (!(h > 0.f)) {
+            float vol = 1.f;
+            for (int a = 0; a < 3; ++a) vol *= fmaxf(ext[a], 1e-3f * me);
+            h = cbrtf(vol * target_occupancy / (float)(n > 0 ? n : 1));
+        }
         h = fmaxf(h, me / (float)GRID_MAX_DIM);
         int d[3];
         for (;;) {
@@ -284,9 +293,45 @@ __global__ __launch_bounds__(1024) void grid_build_kernel(const float* __restric
             h *= 1.26f;
         }
         G.ox = lo[0]; G.oy = lo[1]; G.oz = lo[2]; G.h = h; G.inv_h = 1.0f / h; G.nx = d[0]; G.ny = d[1]; G.nz = d[2];
-        grids[c] = G;
-    }
+    };
+    if (tid == 0) choose(0.f);
     __syncthreads();
+    for (int k = tid; k < G.nx * G.ny * G.nz; k += 1024) cnt[k] = 0;   // only the cells in use (not all 16384 counters)
+    __syncthreads();
+    auto cell_of_g = [&](float x, float y, float z) {
+        int cx = (int)floorf((x - G.ox) * G.inv_h), cy = (int)floorf((y - G.oy) * G.inv_h), cz = (int)floorf((z - G.oz) * G.inv_h);
+        cx = min(max(cx, 0), G.nx - 1); cy = min(max(cy, 0), G.ny - 1); cz = min(max(cz, 0), G.nz - 1);
+        return (cz * G.ny + cy) * G.nx + cx;
+    };
+    for (int pass = 0; pass < 3; ++pass) {
+        for (int k = start + tid; k < end; k += 1024)
+            atomicAdd(&cnt[cell_of_g(xyz[(size_t)k * 3], xyz[(size_t)k * 3 + 1], xyz[(size_t)k * 3 + 2])], 1);
+        __syncthreads();
+        if (pass == 2) break;
+        const int nc_ = G.nx * G.ny * G.nz;
+        int occ_l = 0;
+        for (int k = tid; k < nc_; k += 1024) occ_l += cnt[k] > 0 ? 1 : 0;
+        occ_l = (int)wave_sum((float)occ_l);       // <= 1024 * 16 / 16 per wave: exact in fp32
+        if (lane == 0 && occ_l) atomicAdd(&occ_cells, occ_l);
+        __syncthreads();
+        if (tid == 0) {
+            // points per occupied cell now vs the target: shrink the cells when they hold more than 1.3 x the target
+            const float have = (float)n / (float)max(occ_cells, 1);
+            refine = 0;
+            if (n > 0 && have > 1.3f * target_occupancy) {
+                const float h_old = G.h;
+                choose(h_old * cbrtf(target_occupancy / have));
+                refine = G.h < 0.97f * h_old ? 1 : 0;
+                if (!refine) choose(h_old);
+            }
+            occ_cells = 0;
+        }
+        __syncthreads();
+        if (!refine) break;
+        for (int k = tid; k < G.nx * G.ny * G.nz; k += 1024) cnt[k] = 0;
+        __syncthreads();
+    }
+    if (tid == 0) grids[c] = G;
     const RoitrGrid g = G;
     const int ncell = g.nx * g.ny * g.nz;
     auto cell_of = [&](float x, float y, float z) {
@@ -294,9 +339,6 @@ __global__ __launch_bounds__(1024) void grid_build_kernel(const float* __restric
         cx = min(max(cx, 0), g.nx - 1); cy = min(max(cy, 0), g.ny - 1); cz = min(max(cz, 0), g.nz - 1);
         return (cz * g.ny + cy) * g.nx + cx;
     };
-    for (int k = start + tid; k < end; k += 1024)
-        atomicAdd(&cnt[cell_of(xyz[(size_t)k * 3], xyz[(size_t)k * 3 + 1], xyz[(size_t)k * 3 + 2])], 1);
-    __syncthreads();
     // exclusive scan of cnt[0..ncell) : 16 cells per thread
     {
         constexpr int PER = GRID_MAX_CELLS / 1024;
@@ -960,7 +1002,7 @@ __global__ __launch_bounds__(1024) void sort_queries_kernel(const float* __restr
         const int cz = (int)fminf(fmaxf((z - g.oz) * g.inv_h, 0.f), (float)(g.nz - 1));
         return (cz * g.ny + cy) * g.nx + cx;
     };
-    for (int k = tid; k < GRID_MAX_CELLS; k += 1024) cnt[k] = 0;
+    for (int k = tid; k < ncell; k += 1024) cnt[k] = 0;
     __syncthreads();
     for (int k = start + tid; k < end; k += 1024) atomicAdd(&cnt[cell_of(k)], 1);
     __syncthreads();
