@@ -54,6 +54,10 @@ typedef struct RoitrGemm {
      *   C[r,:] += sum_k w_k ip_feat[ip_idx[3 r + k], :],   w_k = (1 / (sqrt(ip_dist2[3 r + k]) + 1e-8)) / sum of the three,
      * ip_feat rows N floats, dense: `linear1(x1) + interpolation(...)` in the launch that computes linear1. */
     const float* ip_feat; const int* ip_idx; const float* ip_dist2;
+    /* optional with A_cat: its own row gather (A_cat row of output row r = a_cat_idx[r]; A keeps a_idx / the identity) -- the
+     * `linear(att) + in_proj(x[node_idx])` of a TransitionDown transformer as one GEMM (model/model.py:59-62 samples the rows).
+     * With A_cat an addend A2 applies to the A part only (columns k < k_cat). */
+    const int* a_cat_idx;
 } RoitrGemm;
 #define ROITR_BF16_W 1
 #define ROITR_BF16_A 2

@@ -222,7 +222,7 @@ bool ln_fuses(int N, int K, int lda, int ldw)
 // dimension lda_cat (fp32 kernels only)
 int gemm_ln(hipStream_t st, int M, const float* A, const Lin& l, const float* res, const int* res_idx, const float* gamma,
             const float* beta, const float* post, bool relu, float* tmp, float* out, int bf = 0, const float* A_cat = nullptr,
-            int lda_cat = 0, int k_cat = 0, const float* A2 = nullptr, const Interp3* ip = nullptr)
+            int lda_cat = 0, int k_cat = 0, const float* A2 = nullptr, const Interp3* ip = nullptr, const int* a_cat_idx = nullptr)
 {
     const float* w = l.w;
     const float* b = l.b;
@@ -236,6 +236,7 @@ int gemm_ln(hipStream_t st, int M, const float* A, const Lin& l, const float* re
         g.M = M; g.N = N; g.K = K; g.A = A; g.lda = lda; g.W = w; g.ldw = ldw; g.bias = b; g.alpha = 1.0f; g.C = out; g.ldc = N; g.batch = 1;
         g.ln_gamma = gamma; g.ln_beta = beta; g.ln_res = res; g.ln_res_idx = res_idx; g.ln_post = post; g.ln_relu = relu ? 1 : 0; g.ln_eps = 1e-5f;
         g.A_cat = A_cat; g.lda_cat = lda_cat; g.k_cat = k_cat; g.A2 = A2;   // A2 (optional): the operand is A + A2
+        g.a_cat_idx = a_cat_idx;
         if (ip) { g.ip_feat = ip->feat; g.ip_idx = ip->idx; g.ip_dist2 = ip->dist2; }
         CHK(use_bf16(g, w, l.wb, bf));
         return roitr_gemm(&g, st);
@@ -245,7 +246,7 @@ int gemm_ln(hipStream_t st, int M, const float* A, const Lin& l, const float* re
         RoitrGemm g;
         memset(&g, 0, sizeof(g));
         g.M = M; g.N = N; g.K = K; g.A = A; g.lda = lda; g.W = w; g.ldw = ldw; g.bias = b; g.alpha = 1.0f; g.C = tmp; g.ldc = N; g.batch = 1;
-        g.A_cat = A_cat; g.lda_cat = lda_cat; g.k_cat = k_cat;
+        g.A_cat = A_cat; g.lda_cat = lda_cat; g.k_cat = k_cat; g.A2 = A2; g.a_cat_idx = a_cat_idx;
         CHK(roitr_gemm(&g, st));
     } else
     CHK(gemm(st, M, N, K, A, lda, w, ldw, b, tmp, N, false, nullptr, A2, 1.0f, l.wb, bf));
@@ -420,13 +421,17 @@ int local_transformer(Engine& E, hipStream_t st, const LocalT& L, int N_in, cons
         A.off = mark;
         return 0;
     }
-    float* f = catf ? nullptr : A.get<float>((size_t)(folded ? M : N_in) * H);
-    if (catf) {}
+    // TransitionDown in the folded-attention form below with the K-concatenated `linear`: f = in_proj(x[node_idx]) -- only ever the
+    // LayerNorm residual -- rides in that GEMM as its second K part (round 4), the gathered (M, H) tensor is never formed
+    const bool td_fold = folded && L.wkT_x && NQ == 0 && roitr_local_attention_fold_supported(L.in_dim, H, K);
+    const bool td_cat = td_fold && L.wcat != nullptr;
+    float* f = (catf || td_cat) ? nullptr : A.get<float>((size_t)(folded ? M : N_in) * H);
+    if (catf || td_cat) {}
     else if (folded) CHK(gemm(st, M, x, L.in_proj, f, false, node_idx));
     else CHK(gemm(st, N_in, x, L.in_proj, f));
     // TransitionDown in fp32: the k | v projections folded into the query side (csrc/local_attn.hip local_attn_fold_kernel) --
     // q~ = Wk'^T q per head in front, Wv' applied to the attention-weighted INPUT rows behind; the (N_in, 2H) tensor is never formed
-    if (folded && L.wkT_x && NQ == 0 && roitr_local_attention_fold_supported(L.in_dim, H, K)) {
+    if (td_fold) {
         const int I = L.in_dim, c = H / HEADS;
         float* qe = A.get<float>((size_t)M * H);
         float* qt = A.get<float>((size_t)M * HEADS * I);
@@ -455,6 +460,10 @@ int local_transformer(Engine& E, hipStream_t st, const LocalT& L, int N_in, cons
             CHK(roitr_gemm(&gv, st));
         }
         // linear(att) + f -> LayerNorm, att = vpart + val (the sum is formed while the operand is staged)
+        if (td_cat) {   // LN([vpart + val | x[node_idx]] [Wlin | Win]^T + b_lin + b_in)
+            Lin lc; lc.w = L.wcat; lc.b = L.bcat; lc.out = H; lc.in = H + I;
+            CHK(gemm_ln(st, M, vpart, lc, nullptr, nullptr, L.norm_w, L.norm_b, nullptr, false, hid, y, 0, x, I, H, val, nullptr, node_idx));
+        } else
         CHK(gemm_ln(st, M, vpart, L.lin, f, nullptr, L.norm_w, L.norm_b, nullptr, false, hid, y, 0, nullptr, 0, 0, val));
         if (bn2_res) {
             float* t = A.get<float>((size_t)M * L.out_dim);

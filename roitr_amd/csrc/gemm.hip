@@ -118,7 +118,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(RoitrGemm g, int nx, int ny, 
             if (src >= 0 && (g.a_limit <= 0 || src < g.a_limit)) {
                 arow = A + (size_t)src * g.lda;
                 if (A2) arow2 = A2 + (size_t)src * g.lda;
-                if (FAST && g.A_cat) arowc = g.A_cat + (size_t)src * g.lda_cat;   // column k >= k_cat of the product = A_cat[k - k_cat]
+                // column k >= k_cat of the product = A_cat[k - k_cat]; its row: the A row's, or its own gather (a_cat_idx)
+                if (FAST && g.A_cat) arowc = g.A_cat + (size_t)(g.a_cat_idx ? g.a_cat_idx[am] : src) * g.lda_cat;
             }
         }
 #pragma unroll
@@ -159,7 +160,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(RoitrGemm g, int nx, int ny, 
             ld8((g.A_cat && k >= g.k_cat) ? arowc + (k - g.k_cat) : arow + k, av);   // slab-uniform: k_cat % 32 == 0
 #pragma unroll
             for (int v = 0; v < TN; ++v) ld8(wrow[v] + k, wv[v]);
-            if (HA2) ld8(arow2 + k, a2v);
+            if (HA2) ld8((g.A_cat && k >= g.k_cat) ? g_zero_row + (k & 31) : arow2 + k, a2v);   // the addend covers the A part only
         } else {
             load8(arow, k, g.K, a_vec, av);
             load8(arow2, k, g.K, a_vec, a2v);
@@ -235,7 +236,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(RoitrGemm g, int nx, int ny, 
                             if (n == (i * TOT + TOT / 2) / NS) {
                                 __builtin_amdgcn_sched_barrier(0);
                                 const int h = i & 1, o = h ? (SPLIT16 ? 16 : 4) : 0, j = i >> 1;   // half h of staging row j
-                                const float* src = j == 0 ? an : (HA2 && j == 1) ? arow2 + kn : wrow[j - 1 - (HA2 ? 1 : 0)] + kn;
+                                const float* src = j == 0 ? an : (HA2 && j == 1) ? ((g.A_cat && kn >= g.k_cat) ? g_zero_row + (kn & 31) : arow2 + kn)
+                                                                  : wrow[j - 1 - (HA2 ? 1 : 0)] + kn;
                                 const float4 x = *reinterpret_cast<const float4*>(src + o);
                                 float* dst = j == 0 ? av : (HA2 && j == 1) ? a2v : wv[j - 1 - (HA2 ? 1 : 0)];
                                 dst[4 * h] = x.x; dst[4 * h + 1] = x.y; dst[4 * h + 2] = x.z; dst[4 * h + 3] = x.w;
@@ -443,11 +445,12 @@ extern "C" int roitr_gemm(const RoitrGemm* g, hipStream_t stream)
     auto al16 = [](const void* p, long stride_floats) { return ((uintptr_t)p & 15) == 0 && (stride_floats % 4) == 0; };
     const bool fast = g->K % BK == 0 && g->K <= ZERO_ROW_LEN && g->lda % 4 == 0 && g->ldw % 4 == 0 && al16(g->A, g->sA) && al16(g->W, g->sW) &&
                       (!g->A2 || al16(g->A2, g->sA));
-    if (g->A_cat && (!fast || g->A2 || g->batch != 1 || g->seg_off || g->k_cat % BK || g->k_cat <= 0 || g->k_cat >= g->K || g->lda_cat % 4 ||
+    if (g->A_cat && (!fast || g->batch != 1 || g->seg_off || g->k_cat % BK || g->k_cat <= 0 || g->k_cat >= g->K || g->lda_cat % 4 ||
                      ((uintptr_t)g->A_cat & 15))) {
-        roitr_set_error("roitr_gemm: K-concatenated A needs the fast path (K % 32, 16-byte rows), k_cat % 32 == 0, no addend / batching", __FILE__, __LINE__);
+        roitr_set_error("roitr_gemm: K-concatenated A needs the fast path (K % 32, 16-byte rows), k_cat % 32 == 0, no batching", __FILE__, __LINE__);
         return ROITR_ERR_UNSUPPORTED;
     }
+    if (g->a_cat_idx && !g->A_cat) { roitr_set_error("roitr_gemm: a_cat_idx without A_cat", __FILE__, __LINE__); return ROITR_ERR_ARG; }
     const int tn = g->ln_gamma ? g->N / BN : 1;   // LayerNorm epilogue: one block spans the row
     if (g->ln_gamma && (g->N % BN || (tn != 1 && tn != 2 && tn != 4) || g->batch != 1 || g->seg_off || g->relu || !g->ln_beta)) return ROITR_ERR_UNSUPPORTED;
     if (g->ip_feat && (!g->ln_gamma || !g->ip_idx || !g->ip_dist2)) { roitr_set_error("roitr_gemm: the interpolation addend rides in the fused LayerNorm epilogue only", __FILE__, __LINE__); return ROITR_ERR_UNSUPPORTED; }

@@ -154,7 +154,7 @@ class _Gemm(ctypes.Structure):
                 ("ln_gamma", _P), ("ln_beta", _P), ("ln_res", _P), ("ln_res_idx", _P), ("ln_post", _P),
                 ("ln_relu", ctypes.c_int), ("ln_eps", ctypes.c_float), ("bf16", ctypes.c_int),
                 ("A_cat", _P), ("lda_cat", ctypes.c_int), ("k_cat", ctypes.c_int),
-                ("ip_feat", _P), ("ip_idx", _P), ("ip_dist2", _P)]
+                ("ip_feat", _P), ("ip_idx", _P), ("ip_dist2", _P), ("a_cat_idx", _P)]
 
 
 BF16_W, BF16_A, BF16_C = 1, 2, 4   # RoitrGemm::bf16 flags (include/roitr_engine.h)
@@ -172,17 +172,26 @@ def _bf16_flags(bf16, x, weight, out_bf16):
     return x.contiguous().float(), w, flags
 
 
-def _k_cat(g, x, x_cat, keep):
-    """RoitrGemm::A_cat: the product reads [x | x_cat] along K without the concatenation ever existing (fp32 fast path only)."""
+def _k_cat(g, x, x_cat, keep, x_cat_idx=None, addend=None):
+    """RoitrGemm::A_cat: the product reads [x | x_cat] along K without the concatenation ever existing (fp32 fast path only).
+    x_cat_idx: row gather of x_cat alone (RoitrGemm::a_cat_idx); addend: RoitrGemm::A2, added to the x part."""
+    if addend is not None:
+        ad = addend.contiguous().float()
+        keep.append(ad)
+        g.A2 = L.ptr(ad)
     if x_cat is None:
         return
     xc = x_cat.contiguous().float()
     keep.append(xc)
     g.A_cat, g.lda_cat, g.k_cat = L.ptr(xc), xc.shape[1], x.shape[1]
     g.K = x.shape[1] + xc.shape[1]
+    if x_cat_idx is not None:
+        ix = x_cat_idx.contiguous().to(torch.int32)
+        keep.append(ix)
+        g.a_cat_idx = L.ptr(ix)
 
 
-def linear(x, weight, bias=None, relu=False, alpha=1.0, bf16=False, out_bf16=False, x_cat=None):
+def linear(x, weight, bias=None, relu=False, alpha=1.0, bf16=False, out_bf16=False, x_cat=None, x_cat_idx=None, addend=None):
     """act(alpha * x @ weight.T + bias): the kernel behind every nn.Linear of the path.  Default: the fp32 MFMA GEMM.
     bf16=True: the bf16-operand kernel (csrc/gemm_bf16.hip; weights stored bf16, fp32 accumulate); x may be a bfloat16
     tensor (stored-bf16 activation), out_bf16 stores the result in bf16.  x_cat: a second operand block, the product is
@@ -196,14 +205,14 @@ def linear(x, weight, bias=None, relu=False, alpha=1.0, bf16=False, out_bf16=Fal
               L.ptr(out), N, 1, 0, 0, 0, 0, 0, 0, L.ptr(None), 0, 0)
     g.bf16 = flags
     keep = []
-    _k_cat(g, x, x_cat, keep)
+    _k_cat(g, x, x_cat, keep, x_cat_idx, addend)
     g.ldw = weight.shape[1]
     L.check(L.lib().roitr_gemm(ctypes.byref(g), L.stream_ptr()), "gemm")
     return out
 
 
 def linear_layernorm(x, weight, bias, gamma, beta, res=None, res_idx=None, post=None, relu=False, eps=1e-5, bf16=False, out_bf16=False,
-                     x_cat=None, interp=None):
+                     x_cat=None, interp=None, x_cat_idx=None, addend=None):
     """[relu](LayerNorm(x @ weight.T + bias + res[res_idx]) * gamma + beta + post) in ONE launch (64 / 128 / 256 output
     channels): the nn.Linear -> (+ residual) -> nn.LayerNorm call sites of attention.py:319, model/model.py:89-97,138-140.
     bf16 / out_bf16 as in linear().  interp = (feat (R, N), idx (M, 3) int32, dist2 (M, 3)): TransitionUp's three-nearest-neighbour
@@ -218,7 +227,7 @@ def linear_layernorm(x, weight, bias, gamma, beta, res=None, res_idx=None, post=
               L.ptr(out), N, 1, 0, 0, 0, 0, 0, 0, L.ptr(None), 0, 0, L.ptr(gm), L.ptr(bt), L.ptr(rs), L.ptr(ri), L.ptr(po), int(relu), float(eps))
     g.bf16 = flags
     keep = []
-    _k_cat(g, x, x_cat, keep)
+    _k_cat(g, x, x_cat, keep, x_cat_idx, addend)
     g.ldw = weight.shape[1]
     if interp is not None:
         keep += [c(interp[0]), c(interp[1], torch.int32), c(interp[2])]

@@ -446,6 +446,28 @@ def test_gemm_k_concatenated_operand(N, K, Kc):
     assert (ops.linear(x, w, b, relu=True, x_cat=xc)[:2048].double() - ref).abs().max().item() < 1e-4
 
 
+@pytest.mark.parametrize("N,K,Kc,M", [(128, 128, 64, 70037), (256, 256, 128, 5000), (128, 128, 64, 100)])
+def test_gemm_k_concatenated_operand_with_its_own_gather_and_an_addend(N, K, Kc, M):
+    """RoitrGemm::a_cat_idx + A2 beside A_cat (round 4: `linear(vpart + val) + in_proj(x[node_idx])` of the TransitionDown transformers
+    as ONE GEMM): [x + addend | x_cat[idx]] @ W^T -- bitwise the product of the materialised operand (both row counts: the
+    interleaved-load form of large grids and the burst form), with and without the LayerNorm epilogue, and against float64."""
+    from roitr_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(7 + N + K + M)
+    R = 4 * M + 3
+    x, ad = torch.randn((M, K), generator=g).cuda(), torch.randn((M, K), generator=g).cuda()
+    xc = torch.randn((R, Kc), generator=g).cuda()
+    idx = torch.randint(0, R, (M,), generator=g).to(torch.int32).cuda()
+    w = (torch.randn((N, K + Kc), generator=g) / (K + Kc) ** 0.5).cuda()
+    b, gam, bet = (torch.randn((N,), generator=g).cuda() for _ in range(3))
+    xx = torch.cat([x + ad, xc[idx.long()]], 1).contiguous()
+    got = ops.linear(x, w, b, x_cat=xc, x_cat_idx=idx, addend=ad)
+    assert torch.equal(got, ops.linear(xx, w, b))
+    if N <= 128:
+        assert torch.equal(ops.linear_layernorm(x, w, b, gam, bet, x_cat=xc, x_cat_idx=idx, addend=ad), ops.linear_layernorm(xx, w, b, gam, bet))
+    ref = xx[:2048].double() @ w.double().T + b.double()
+    assert (got[:2048].double() - ref).abs().max().item() < 1e-4
+
+
 @pytest.mark.parametrize("H,K,M,order", [(64, 8, 1000, True), (64, 16, 333, False), (128, 16, 777, True), (128, 8, 65, False)])
 def test_local_block_against_float64(H, K, M, order):
     """csrc/local_block.hip (the fused block transformer of levels 1-2) against a float64 restatement of its formulas from the
