@@ -73,6 +73,8 @@ def parse():
     ap.add_argument("--weights", default=None, choices=["plain", "selective"],
                     help="closed-form weight variant (roitr_amd/weights.py); default: selective -- descriptors that discriminate, thousands of "
                          "correspondences per pair (round 4; 'plain' ends in ~34 per pair, i.e. times the matching tail on near-empty outputs)")
+    ap.add_argument("--cloud", default="uniform", choices=["uniform", "surface"],
+                    help="synthetic geometry (roitr_amd/synthetic.py): points ~ U[0,2)^3, or room-like piecewise-planar surfaces with sensor noise")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-single-pair", action="store_true", help="skip the one-pair-per-call measurement (profiling passes)")
     ap.add_argument("--no-profile-pass", action="store_true", help="skip the instrumented repeat of the timed steps (no rooflines)")
@@ -216,7 +218,7 @@ def forward_bench(args, rank, world, distributed):
         args.no_profile_pass = args.no_single_pair = args.no_cpu_baseline = True
     else:
         model = build_model(wl["benchmark"], operand_dtype=dtype, weights=weights)
-        pool = [pair_to_device(make_pair(N, config=wl["seed_config"], pair_index=i, normals=normals)) for i in ids]
+        pool = [pair_to_device(make_pair(N, config=wl["seed_config"], pair_index=i, normals=normals, cloud=args.cloud)) for i in ids]
 
     def batch(step):
         return [pool[(step * B + j) % len(pool)] for j in range(B)]
@@ -296,6 +298,7 @@ def forward_bench(args, rank, world, distributed):
             "pairs_per_step": B,
             "n_points": N,
             "weights": f"closed-form, variant '{weights}' (roitr_amd/weights.py); normals: {normals}",
+            "cloud": args.cloud,
             "sharding": f"pairs over {world} rank(s), no data-path collective; one gather of the result records of all timed steps at the end",
             "correspondences_found": agg["n_corr"],
         },
@@ -303,9 +306,11 @@ def forward_bench(args, rank, world, distributed):
     gt = None if stub else model.geo_table_info()
     out["config"]["geometric_embedding"] = (
         "function table (csrc/geo_table.hip): degree-7 polynomial per channel on intervals of %g, %d distance + %d angle intervals, "
-        "float64 fit error %.1e / %.1e of the amplitude" % (gt["interval"], gt["n_int_d"], gt["n_int_a"], gt["fit_d"] / max(gt["amp_d"], 1e-30),
-                                                             gt["fit_a"] / max(gt["amp_a"], 1e-30))
+        "largest per-channel relative fit error %.1e / %.1e (gate 3.0e-08), %d bytes of LDS per workgroup"
+        % (gt["interval"], gt["n_int_d"], gt["n_int_a"], gt["rel_d"], gt["rel_a"], gt["lds_bytes"])
         if gt else "fp32 MFMA GEMM form (geo_embed_kernel)")
+    if gt:
+        out["config"]["geometric_embedding_table"] = {"interval": gt["interval"], "lds_bytes": gt["lds_bytes"], "rel_fit_d": gt["rel_d"], "rel_fit_a": gt["rel_a"]}
     if rank == 0:
         if records is not None:
             out["result_gather"] = benchloop.gather_summary(records, B, args.steps, spp)
@@ -320,7 +325,7 @@ def forward_bench(args, rank, world, distributed):
         if single:
             out["single_pair_mode"] = single
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(N, args.cpu_baseline_seconds, wl["benchmark"], wl["seed_config"], weights, normals)
+            out["cpu_baseline"] = cpu_baseline(N, args.cpu_baseline_seconds, wl["benchmark"], wl["seed_config"], weights, normals, args.cloud)
     return out
 
 
@@ -510,13 +515,13 @@ def attach_traffic(roofs, B, config):
     return pmc
 
 
-def cpu_baseline(N, budget_s, benchmark, seed_config, weights="plain", normals="random"):
+def cpu_baseline(N, budget_s, benchmark, seed_config, weights="plain", normals="random", cloud="uniform"):
     """The CPU oracle (oracle/, 'port' kind) on this host: full forwards of pairs of the same workload, per-stage ms included."""
     try:
         from oracle import roitr_ref
     except Exception as e:  # oracle model restatement not available
         return {"value": None, "unit": "pairs/s", "cores": 0, "kind": "port", "sample": f"unavailable: {e}"}
-    return roitr_ref.timed_baseline(N, budget_s, benchmark=benchmark, seed_config=seed_config, weights=weights, normals=normals)
+    return roitr_ref.timed_baseline(N, budget_s, benchmark=benchmark, seed_config=seed_config, weights=weights, normals=normals, cloud=cloud)
 
 
 def cpu_baseline_knn(N, K, budget_s):

@@ -112,7 +112,8 @@ int roitr_geo_embed_bf16_out(long rows, int C, int angle_k, const float* d_idx, 
  * the scalar v per output channel (positional_encoding.py:38-62 feeds ONE value per row into the sinusoid), so it is fitted once
  * per weight set by a degree-7 polynomial per channel on intervals of width `interval` (float64 Chebyshev interpolation on the
  * HOST) and evaluated from LDS.  roitr_geo_table_build: all pointers are HOST memory; table holds roitr_geo_table_floats()
- * floats; fit[0..3] = {max |poly - g_d| between the nodes, max |g_d|, the same for the angle projection}.
+ * floats; fit[0..5] = {max |poly - g_d| over a dense probe (64 points per interval), max |g_d|, the same for the angle projection,
+ * the largest per-channel relative error of the distance / of the angle projection}.
  * roitr_geo_embed_table: device pointers; values outside [0, n_int * interval) are evaluated directly from div_term / W / b, so
  * any input is served; angle_k must be 3, C a multiple of 64; out is fp32 (rows, C), or bf16 when out_bf16. */
 size_t roitr_geo_table_floats(int C, int n_int_d, int n_int_a);
@@ -386,8 +387,10 @@ void* roitr_engine_create(const RoitrEngineConfig* cfg);
 void roitr_engine_destroy(void* engine);
 int roitr_engine_set_param(void* engine, const char* name, const float* device_ptr, long numel);
 int roitr_engine_finalize(void* engine, roitr_stream_t stream);
-/* The function table of the geometric embedding chosen by finalize (see roitr_geo_table_build): info[0..6] = {interval, n_int_d,
- * n_int_a, fit error d, amplitude d, fit error a, amplitude a}; returns 1 when a table is in use, 0 when the GEMM form is. */
+/* The function table of the geometric embedding chosen by finalize (see roitr_geo_table_build): info[0..8] = {interval, n_int_d,
+ * n_int_a, fit error d, amplitude d, fit error a, amplitude a, largest per-channel relative error d, a}; returns 1 when a table is
+ * in use, 0 when the GEMM form is.  finalize accepts the widest interval of {2, 1, 0.5} whose per-channel relative errors are both
+ * below 2^-25, the GEMM form (geo_embed_kernel) otherwise. */
 int roitr_engine_geo_table_info(void* engine, double* info);
 int roitr_engine_forward(void* engine, const RoitrForwardIO* io, roitr_stream_t stream);
 /* Same forward, replayed as ONE hipGraphLaunch once the same (sizes, io buffers) combination has been seen twice

@@ -435,7 +435,8 @@ def closed_form_state(factor=1, variant="plain"):
 FDMATCH_CFG = {"adaptive": True, "num_est_coarse_corr": 128, "fine_matching_topk": 2}   # configs/test/fdmatch.yaml
 
 
-def timed_baseline(n_points, budget_s=20.0, max_pairs=16, benchmark="3DMatch", seed_config=2, weights="plain", normals="random"):
+def timed_baseline(n_points, budget_s=20.0, max_pairs=16, benchmark="3DMatch", seed_config=2, weights="plain", normals="random",
+                   cloud="uniform"):
     """bench.py cpu_baseline ('port'): full forwards of pairs of the bench workload on this host's cores.
 
     FPS/kNN run in the C restatement (kNN split over all cores with threads; FPS is inherently serial per
@@ -452,7 +453,7 @@ def timed_baseline(n_points, budget_s=20.0, max_pairs=16, benchmark="3DMatch", s
     dt = 0.0
     stages = {}
     while pairs < max_pairs and (pairs == 0 or dt < budget_s):
-        pair = make_pair(n_points, config=seed_config, pair_index=pairs, normals=normals)
+        pair = make_pair(n_points, config=seed_config, pair_index=pairs, normals=normals, cloud=cloud)
         t0 = time.perf_counter()
         out = forward(sd, pair, cfg=cfg, threads=cores, timings=stages)
         dt += time.perf_counter() - t0

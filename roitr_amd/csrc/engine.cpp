@@ -114,7 +114,7 @@ struct Engine {
     const float* geo_div = nullptr;
     float* geo_div_own = nullptr;
     // function-table form of the embedding (geo_table.hip): built at finalize unless ROITR_GEO_TABLE=0
-    float* geo_tab = nullptr; float geo_tab_h = 0.f; int geo_tab_nd = 0, geo_tab_na = 0; double geo_tab_fit[4] = {0, 0, 0, 0};
+    float* geo_tab = nullptr; float geo_tab_h = 0.f; int geo_tab_nd = 0, geo_tab_na = 0; double geo_tab_fit[6] = {0, 0, 0, 0, 0, 0};
     std::vector<GeoLayer> geo;
     const float* ot_alpha = nullptr;
     // rank-1 form of the first local transformer (in_planes = 1): constants of csrc/local_block.hip local_first_kernel
@@ -824,20 +824,27 @@ extern "C" int roitr_engine_finalize(void* h, hipStream_t st)
             ROITR_HIP(hipMemcpy(hbd.data(), E.proj_d.b, sizeof(float) * C4, hipMemcpyDeviceToHost));
             ROITR_HIP(hipMemcpy(hba.data(), E.proj_a.b, sizeof(float) * C4, hipMemcpyDeviceToHost));
             ROITR_HIP(hipMemcpy(hdiv.data(), E.geo_div, sizeof(float) * (C4 / 2), hipMemcpyDeviceToHost));
+            // ROITR_GEO_TABLE_H (diagnostic; tests/test_stages_gpu.py): start the search at this interval instead of 2
+            const char* hv = getenv("ROITR_GEO_TABLE_H");
+            const float h_first = hv && atof(hv) > 0 ? (float)atof(hv) : 2.0f;
             for (float h : {2.0f, 1.0f, 0.5f}) {
+                if (h > h_first) continue;
                 const int nd = (int)ceil(d_range / h), na = (int)floor(a_range / h) + 1;
                 const size_t nf = roitr_geo_table_floats(C4, nd, na);
                 if ((size_t)(nd + na) * 8 * 64 * sizeof(float) > 160 * 1024) break;
                 std::vector<float> tab(nf);
-                double fit[4];
+                double fit[6];
                 CHK(roitr_geo_table_build(C4, hdiv.data(), hd.data(), hbd.data(), ha.data(), hba.data(), h, nd, na, tab.data(), fit));
+                // accepted when EVERY channel's measured error (64 probe points per interval) is below 2^-25 of that channel's
+                // amplitude: trained weights that load the top frequencies fail h = 2 (degree 7 on sin(x): 2^-22) and get h = 1
+                // (2^-30); near-cancelling coefficients can fail every interval -> the GEMM form
                 const double tol = 1.0 / (double)(1 << 25);
-                if (fit[0] <= tol * fit[1] && fit[2] <= tol * fit[3]) {
+                if (fit[4] <= tol && fit[5] <= tol) {
                     float* dev = E.warena.get<float>(nf);
                     if (E.warena.fail) break;
                     ROITR_HIP(hipMemcpy(dev, tab.data(), sizeof(float) * nf, hipMemcpyHostToDevice));
                     E.geo_tab = dev; E.geo_tab_h = h; E.geo_tab_nd = nd; E.geo_tab_na = na;
-                    for (int q = 0; q < 4; ++q) E.geo_tab_fit[q] = fit[q];
+                    for (int q = 0; q < 6; ++q) E.geo_tab_fit[q] = fit[q];
                     break;
                 }
             }
@@ -848,14 +855,15 @@ extern "C" int roitr_engine_finalize(void* h, hipStream_t st)
     return 0;
 }
 
-/* The function table of the geometric embedding chosen at finalize: info = {interval, n_int_d, n_int_a, fit error of the
- * distance projection, its amplitude, fit error of the angle projection, its amplitude}; returns 0 when no table is in use. */
+/* The function table of the geometric embedding chosen at finalize: info[0..8] = {interval, n_int_d, n_int_a, fit error of the
+ * distance projection, its amplitude, fit error of the angle projection, its amplitude, largest per-channel relative error of
+ * the two}; returns 0 when no table is in use. */
 extern "C" int roitr_engine_geo_table_info(void* h, double* info)
 {
     Engine& E = *(Engine*)h;
     if (!E.geo_tab) return 0;
     info[0] = E.geo_tab_h; info[1] = E.geo_tab_nd; info[2] = E.geo_tab_na;
-    for (int q = 0; q < 4; ++q) info[3 + q] = E.geo_tab_fit[q];
+    for (int q = 0; q < 6; ++q) info[3 + q] = E.geo_tab_fit[q];
     return 1;
 }
 

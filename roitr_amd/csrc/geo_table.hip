@@ -184,8 +184,8 @@ extern "C" size_t roitr_geo_table_floats(int C, int n_int_d, int n_int_a)
 
 /* HOST: fits the table (see the header of this file).  All pointers are HOST memory: div_term (C/2), Wd / Wa (C, C) row-major
  * (out_features, in_features), bd / ba (C), table = roitr_geo_table_floats() floats.  interval = h (a power of two).
- * fit[0..3] = {max |poly - g| of the distance projection between the interpolation nodes (float64), max |g_d|, the same two
- * for the angle projection}. */
+ * fit[0..5] = {max |poly - g| of the distance projection over a dense probe of every interval (float64, 64 points), max |g_d|, the same two for the angle projection, then the largest PER-CHANNEL relative error (error of a channel
+ * over that channel's own amplitude) of the distance and of the angle projection -- what roitr_engine_finalize gates on}. */
 extern "C" int roitr_geo_table_build(int C, const float* div_term, const float* Wd, const float* bd, const float* Wa, const float* ba,
                                      float interval, int n_int_d, int n_int_a, float* table, double* fit)
 {
@@ -202,10 +202,13 @@ extern "C" int roitr_geo_table_build(int C, const float* div_term, const float* 
     tm[0][0] = 1.0; tm[1][1] = 1.0;
     for (int m = 2; m < NCOEF; ++m)
         for (int p = 0; p < NCOEF; ++p) tm[m][p] = (p > 0 ? 2.0 * tm[m - 1][p - 1] : 0.0) - tm[m - 2][p];
-    static const double probe[] = {-1.0, -0.93, -0.55, -0.2, 0.2, 0.55, 0.93, 1.0};
+    // the fit is MEASURED, densely: NPROBE points per interval (end points included) against the float64 function, per channel
+    constexpr int NPROBE = 64;
     std::vector<double> f((size_t)NCOEF * C), mono((size_t)NCOEF * C), ref(C);
+    std::vector<double> err_c[2] = {std::vector<double>(C, 0.0), std::vector<double>(C, 0.0)};
+    std::vector<double> amp_c[2] = {std::vector<double>(C, 0.0), std::vector<double>(C, 0.0)};
     const int nint = n_int_d + n_int_a;
-    for (int q = 0; q < 4; ++q) fit[q] = 0.0;
+    for (int q = 0; q < 6; ++q) fit[q] = 0.0;
     for (int J = 0; J < nint; ++J) {
         const bool dist = J < n_int_d;
         const float* W = dist ? Wd : Wa; const float* b = dist ? bd : ba;
@@ -225,14 +228,29 @@ extern "C" int roitr_geo_table_build(int C, const float* div_term, const float* 
                 table[(((size_t)(c / CS) * nint + J) * NCOEF + p) * CS + (c % CS)] = (float)s;
             }
         }
-        for (double t : probe) {
+        for (int pi = 0; pi < NPROBE; ++pi) {
+            const double t = -1.0 + 2.0 * pi / (double)(NPROBE - 1);
             exact_rows(x0 + 0.5 * h * t, div, W, b, C, emb, ref.data());
             for (int c = 0; c < C; ++c) {
+                // the TRUNCATION error of the degree-7 fit (float64 coefficients): the fp32 rounding of the stored coefficients and of
+                // the Horner steps is the same 2^-24-class noise any fp32 evaluation carries (tests/test_geo_table_cpu.py bounds it)
                 double v = mono[(size_t)(NCOEF - 1) * C + c];
                 for (int p = NCOEF - 2; p >= 0; --p) v = v * t + mono[(size_t)p * C + c];
                 double& e = fit[dist ? 0 : 2]; double& amp = fit[dist ? 1 : 3];
-                e = fmax(e, fabs(v - ref[c])); amp = fmax(amp, fabs(ref[c]));
+                const double d = fabs(v - ref[c]);
+                e = fmax(e, d); amp = fmax(amp, fabs(ref[c]));
+                err_c[dist ? 0 : 1][c] = fmax(err_c[dist ? 0 : 1][c], d);
+                amp_c[dist ? 0 : 1][c] = fmax(amp_c[dist ? 0 : 1][c], fabs(ref[c]));
             }
+        }
+    }
+    // per channel: error relative to the channel's own amplitude (a channel that is 2^-10 of the projection's largest or less is
+    // measured against that floor: it cannot matter more than that to anything downstream)
+    for (int q = 0; q < 2; ++q) {
+        const double floor_ = fit[q ? 3 : 1] / 1024.0;
+        for (int c = 0; c < C; ++c) {
+            const double a_ = fmax(amp_c[q][c], floor_);
+            if (a_ > 0.0) fit[4 + q] = fmax(fit[4 + q], err_c[q][c] / a_);
         }
     }
     return ROITR_OK;

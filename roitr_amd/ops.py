@@ -276,7 +276,8 @@ def adaptive_superpoint_matching(src_feats, tgt_feats, src_masks, tgt_masks, min
 
 def geo_table_build(div_term, w_d, b_d, w_a, b_a, interval=2.0, d_range=48.0, a_range=12.0):
     """Host fit of the function table of the geometric embedding (csrc/geo_table.hip): returns (table on the weights' device,
-    n_int_d, n_int_a, fit) with fit = [fit error d, amplitude d, fit error a, amplitude a] measured in float64."""
+    n_int_d, n_int_a, fit) with fit = [fit error d, amplitude d, fit error a, amplitude a, largest per-channel relative error d, a]
+    measured in float64 on 64 probe points per interval."""
     import math
     C = int(w_d.shape[0])
     nd, na = int(math.ceil(d_range / interval)), int(math.floor(a_range / interval)) + 1
@@ -284,7 +285,7 @@ def geo_table_build(div_term, w_d, b_d, w_a, b_a, interval=2.0, d_range=48.0, a_
     h = lambda t: t.detach().float().cpu().contiguous()
     div_h, wd_h, bd_h, wa_h, ba_h = map(h, (div_term, w_d, b_d, w_a, b_a))
     table = torch.empty(int(lib.roitr_geo_table_floats(C, nd, na)), dtype=torch.float32)
-    fit = (ctypes.c_double * 4)()
+    fit = (ctypes.c_double * 6)()
     hp = L.host_ptr
     L.check(lib.roitr_geo_table_build(C, hp(div_h), hp(wd_h), hp(bd_h), hp(wa_h), hp(ba_h), L.c_float(interval), nd, na,
                                       hp(table), fit), "geo_table_build")

@@ -297,13 +297,16 @@ class RIGA_v2(nn.Module):
 
     def geo_table_info(self):
         """The function table the engine evaluates the geometric embedding from (csrc/geo_table.hip), or None when the GEMM form is
-        in use: {interval, n_int_d, n_int_a, fit_d, amp_d, fit_a, amp_a} (fit = float64 |polynomial - function| between the nodes)."""
+        in use: {interval, n_int_d, n_int_a, fit_d, amp_d, fit_a, amp_a, rel_d, rel_a, lds_bytes} (fit = float64 |polynomial - function|
+        on 64 probe points per interval, rel = the largest per-channel error over that channel's amplitude: the acceptance gate)."""
         self._ensure_engine()
-        info = (ctypes.c_double * 7)()
+        info = (ctypes.c_double * 9)()
         if not L.lib().roitr_engine_geo_table_info(self._engine, info):
             return None
-        keys = ("interval", "n_int_d", "n_int_a", "fit_d", "amp_d", "fit_a", "amp_a")
-        return dict(zip(keys, list(info)))
+        keys = ("interval", "n_int_d", "n_int_a", "fit_d", "amp_d", "fit_a", "amp_a", "rel_d", "rel_a")
+        out = dict(zip(keys, list(info)))
+        out["lds_bytes"] = int((out["n_int_d"] + out["n_int_a"]) * 8 * 64 * 4)   # per workgroup: one 64-channel slice of the table
+        return out
 
     def __del__(self):
         try:

@@ -51,19 +51,56 @@ def euler_zyx(a):
     return rx @ ry @ rz
 
 
-def make_pair(n_src, n_tgt=None, config=2, pair_index=0, overlap=0.6, jitter=0.002, rotated=None, normals="random"):
+def surface_points(rng, n, x_lo, x_hi, noise=0.003):
+    """n points on the surfaces of a room-like scene between x_lo and x_hi (round 4: scan-like geometry -- 3DMatch fragments are
+    2-D surfaces, dataset/tdmatch.py:50-135 loads depth-fused scans): floor, ceiling and the two long walls of a 2 x 2 corridor
+    along x, a wall across at every end, and box-shaped furniture standing on the floor; area-proportional sampling, Gaussian
+    sensor noise.  Deterministic in rng."""
+    L = x_hi - x_lo
+    # axis-aligned rectangles: (origin, edge u, edge v)
+    rects = [((x_lo, 0, 0), (L, 0, 0), (0, 2, 0)), ((x_lo, 0, 2), (L, 0, 0), (0, 2, 0)),        # floor, ceiling
+             ((x_lo, 0, 0), (L, 0, 0), (0, 0, 2)), ((x_lo, 2, 0), (L, 0, 0), (0, 0, 2)),        # long walls
+             ((x_lo, 0, 0), (0, 2, 0), (0, 0, 2)), ((x_hi, 0, 0), (0, 2, 0), (0, 0, 2))]        # end walls
+    # furniture: boxes on a fixed lattice of the corridor (the same physical boxes whatever window [x_lo, x_hi] looks at them)
+    for cx in np.arange(np.floor(x_lo / 0.9) * 0.9, x_hi + 0.9, 0.9):
+        for cy, w, d, hgt in ((0.45, 0.5, 0.4, 0.8), (1.5, 0.35, 0.6, 0.45)):
+            x0, y0 = cx + 0.15, cy - d / 2
+            if x0 + w <= x_lo or x0 >= x_hi:
+                continue
+            xa, xb = max(x0, x_lo), min(x0 + w, x_hi)
+            rects += [((xa, y0, hgt), (xb - xa, 0, 0), (0, d, 0)), ((xa, y0, 0), (xb - xa, 0, 0), (0, 0, hgt)),
+                      ((xa, y0 + d, 0), (xb - xa, 0, 0), (0, 0, hgt))]
+            if x0 >= x_lo:
+                rects.append(((x0, y0, 0), (0, d, 0), (0, 0, hgt)))
+            if x0 + w <= x_hi:
+                rects.append(((x0 + w, y0, 0), (0, d, 0), (0, 0, hgt)))
+    o = np.array([r[0] for r in rects], float); u = np.array([r[1] for r in rects], float); v = np.array([r[2] for r in rects], float)
+    area = np.linalg.norm(np.cross(u, v), axis=1)
+    pick = rng.choice(len(rects), size=n, p=area / area.sum())
+    a, b = rng.random((n, 1)), rng.random((n, 1))
+    return o[pick] + a * u[pick] + b * v[pick] + rng.normal(0.0, noise, (n, 3))
+
+
+def make_pair(n_src, n_tgt=None, config=2, pair_index=0, overlap=0.6, jitter=0.002, rotated=None, normals="random", cloud="uniform"):
     """Returns a dict of float32 numpy arrays following the reference input contract.
     normals: 'random' (independent unit vectors per cloud, flipped toward the origin like dataset/common.py:312-320) or 'field'
     (field_normals of the scene position, carried through the pair's rigid transform: corresponding points share their normal).
     rotated (default: config == 3, BASELINE config 3 "3DLoMatch rotated"): the test-time rotation of dataset/tdmatch.py:99-112 --
-    a seeded full-range euler rotation applied to the source or the target cloud, folded into rot / trans."""
+    a seeded full-range euler rotation applied to the source or the target cloud, folded into rot / trans.
+    cloud: 'uniform' (points ~ U[0,2)^3) or 'surface' (surface_points: piecewise-planar room-like scans with sensor noise)."""
     n_tgt = n_src if n_tgt is None else n_tgt
     rng = np.random.default_rng(1000 * config + pair_index)
     # one scene, two crops along x that share `overlap` of their extent
     shift = 2.0 * (1.0 - overlap)
-    src = rng.random((n_src, 3)) * 2.0
-    tgt_scene = rng.random((n_tgt, 3)) * 2.0
-    tgt_scene[:, 0] += shift
+    if cloud == "surface":
+        src = surface_points(rng, n_src, 0.0, 2.0)
+        tgt_scene = surface_points(rng, n_tgt, shift, 2.0 + shift)
+    elif cloud == "uniform":
+        src = rng.random((n_src, 3)) * 2.0
+        tgt_scene = rng.random((n_tgt, 3)) * 2.0
+        tgt_scene[:, 0] += shift
+    else:
+        raise ValueError(f"cloud must be 'uniform' or 'surface', got {cloud!r}")
     # inside the shared slab, tgt re-observes jittered src points (real correspondences)
     shared_src = np.nonzero(src[:, 0] >= shift)[0]
     shared_tgt = np.nonzero(tgt_scene[:, 0] < 2.0)[0]

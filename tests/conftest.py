@@ -27,15 +27,15 @@ def golden_stages():
 _ORACLE_CACHE = {}
 
 
-def oracle_forward(benchmark, n, config, pair_index, weights="selective", normals="field"):
+def oracle_forward(benchmark, n, config, pair_index, weights="selective", normals="field", cloud="uniform"):
     """(pair, CPU-oracle forward of it), cached for the session: several GPU test modules check the engine against the same
     full-size oracle result (an N = 8000 4DMatch forward is ~1 min of host time)."""
-    key = (benchmark, n, config, pair_index, weights, normals)
+    key = (benchmark, n, config, pair_index, weights, normals, cloud)
     if key not in _ORACLE_CACHE:
         from oracle import roitr_ref as R  # checker only
         from roitr_amd.synthetic import make_pair
         fd = benchmark in ("4DMatch", "4DLoMatch")
-        pair = make_pair(n, config=config, pair_index=pair_index, normals=normals)
+        pair = make_pair(n, config=config, pair_index=pair_index, normals=normals, cloud=cloud)
         ref = R.forward(R.closed_form_state(2 if fd else 1, weights), pair, cfg=dict(R.FDMATCH_CFG) if fd else None,
                         threads=len(os.sched_getaffinity(0)))
         _ORACLE_CACHE[key] = (pair, ref)

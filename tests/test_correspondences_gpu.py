@@ -95,6 +95,18 @@ def test_3dmatch_correspondences_at_5000_match_oracle():
     assert abs(ir_g - ir_o) <= 1e-3
 
 
+def test_3dmatch_correspondences_on_a_scan_like_pair_match_oracle():
+    """Round 4: piecewise-planar, room-like clouds with sensor noise (synthetic.surface_points) -- the geometry of real 3DMatch
+    fragments: grid cells are mostly empty, the occupied ones dense, kNN ties and plane-degenerate PPFs are frequent.  Same checks
+    as on the uniform clouds: nodes, partition, descriptors, coarse and fine correspondences against the CPU oracle."""
+    pair, ref = oracle_forward("3DMatch", 5000, 2, 3, cloud="surface")
+    model = build_model("3DMatch", weights="selective")
+    with torch.no_grad():
+        out = model.forward(**pair_to_device(pair))
+    ir_g, ir_o = _check_against_oracle(out, ref, pair, coarse_exact=False)
+    assert abs(ir_g - ir_o) <= 1e-3
+
+
 def test_4dmatch_correspondences_at_8000_match_oracle():
     """BASELINE config 4 sizes in fp32.  The coarse stage is selective here: a few percent of the 15 625 node pairs lie under the
     0.75 threshold (with the plain weights it was all of them), so the set comparison is a real one."""

@@ -78,7 +78,7 @@ def test_builder_rejects_bad_arguments():
     import ctypes
     lib = L.lib()
     z = torch.zeros(C * C)
-    fit = (ctypes.c_double * 4)()
+    fit = (ctypes.c_double * 6)()
     out = torch.zeros(int(lib.roitr_geo_table_floats(C, 4, 4)))
     hp = L.host_ptr   # the table builder is a host function
     args = lambda h, nd: (C, hp(z), hp(z), hp(z), hp(z), hp(z), L.c_float(h), nd, 4, hp(out), fit)

@@ -355,6 +355,7 @@ def test_engine_uses_the_table_and_agrees_with_the_gemm_form():
     info = model.geo_table_info()
     assert info is not None and info["interval"] in (2.0, 1.0, 0.5)
     assert info["fit_d"] < 2.0 ** -25 * info["amp_d"] and info["fit_a"] < 2.0 ** -25 * info["amp_a"]
+    assert info["rel_d"] <= 2.0 ** -25 and info["rel_a"] <= 2.0 ** -25 and info["lds_bytes"] <= 160 * 1024   # the per-channel gate
     with torch.no_grad():
         out = model.forward(**pair)
     os.environ["ROITR_GEO_TABLE"] = "0"
@@ -381,6 +382,62 @@ def test_engine_uses_the_table_and_agrees_with_the_gemm_form():
         del os.environ["ROITR_GEO_TABLE_RANGE"]
     for k in ("src_node_feats", "tgt_node_feats", "src_point_feats", "tgt_point_feats"):
         assert (out[k] - got[k]).abs().max().item() < 2e-5, k
+
+
+def _top_frequency_embedding(sd_np):
+    """proj_d / proj_a with ALL their mass on the top frequency of the sinusoid (div_term[0] = 1 rad per unit) at amplitude ~2: what
+    a trained embedding could look like at worst.  Degree 7 on an interval of 2 then leaves 2^-22 of the amplitude (gate: 2^-25),
+    an interval of 1 leaves 2^-30."""
+    rng = np.random.default_rng(77)
+    for name in ("proj_d", "proj_a"):
+        k = f"backbone.global_transformer.embedding.{name}.weight"
+        w = np.zeros_like(sd_np[k])
+        w[:, 0] = rng.uniform(1.0, 2.0, w.shape[0]) * rng.choice([-1.0, 1.0], w.shape[0])
+        w[:, 1] = rng.uniform(1.0, 2.0, w.shape[0]) * rng.choice([-1.0, 1.0], w.shape[0])
+        sd_np[k] = w.astype(np.float32)
+    return sd_np
+
+
+@pytest.mark.parametrize("env,expect_h", [({}, 1.0), ({"ROITR_GEO_TABLE_H": "0.5", "ROITR_GEO_TABLE_RANGE": "24"}, 0.5), ({"ROITR_GEO_TABLE": "0"}, None)])
+def test_function_table_with_top_frequency_weights_against_the_oracle(env, expect_h):
+    """the table's acceptance depends on the weights.  With embedding projections that load only the top
+    frequency the engine must REJECT the interval of 2 (dense per-channel probe) and take 1; the interval of 0.5 (diagnostic switch)
+    and the GEMM form serve the same weights.  In every form the descriptors agree with the CPU oracle on the same weights."""
+    from gpu_util import build_model, pair_to_device
+    from oracle import roitr_ref as R
+    from roitr_amd import synthetic
+    raw = synthetic.make_pair(1024, config=1, pair_index=4, normals="field")
+    sd_np = _top_frequency_embedding(R.closed_form_state(1, "selective"))
+    ref = R.forward(sd_np, raw, threads=4)
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        model = build_model("3DMatch", weights="selective")
+        sd = model.state_dict()
+        for name in ("proj_d", "proj_a"):
+            k = f"backbone.global_transformer.embedding.{name}.weight"
+            sd[k].copy_(torch.from_numpy(sd_np[k]))
+        model.sync_engine()
+        info = model.geo_table_info()
+        if expect_h is None:
+            assert info is None
+        else:
+            assert info is not None and info["interval"] == expect_h, info
+            assert info["rel_d"] <= 2.0 ** -25 and info["rel_a"] <= 2.0 ** -25
+        with torch.no_grad():
+            out = model.forward(**pair_to_device(raw))
+    finally:
+        for k, v in old.items():
+            if v is None:
+                del os.environ[k]
+            else:
+                os.environ[k] = v
+    for k in ("src_nodes", "tgt_nodes"):
+        assert np.array_equal(out[k].cpu().numpy(), ref[k])
+    for k in ("src_node_feats", "tgt_node_feats", "src_point_feats", "tgt_point_feats"):
+        got = out[k].cpu().numpy()
+        err = float((np.abs(got - ref[k]) / np.maximum(1.0, np.abs(ref[k]))).max())
+        assert err < 1e-4, (k, err)
 
 
 def test_gemm_rows_do_not_depend_on_the_row_count():
