@@ -59,7 +59,7 @@ __device__ __forceinline__ void load8(const float* __restrict__ p, int k, int K,
 // keeps every use of the prefetched registers behind it, so nothing forces a vmcnt wait between issuing the
 // prefetch and the MFMAs.  The generic variant keeps bounds-checked scalar tails.
 constexpr int ZERO_ROW_LEN = 2048;
-constexpr int GEMM_IL_MIN_TILES = 3072;   // 2 tiles per CU-slot of the 6 resident blocks x 256 CUs: below, latency rules
+constexpr int GEMM_IL_MIN_TILES = 1024;   // below: a few tiles per CU, the one accumulator chain of a wave is the critical path (one-pair-per-call launches: <= 628 tiles)
 __device__ __attribute__((aligned(16))) float g_zero_row[ZERO_ROW_LEN];
 
 // TN: 32x32 accumulators per wave along N; the block tile is 64 x (64 TN).  TN = 1 is the GEMM of the path (see the
