@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round profile collection on the GPU box (run through gpurun from the repo root):
-#   bash scripts/collect_profiles.sh r03
+#   bash scripts/collect_profiles.sh r04
 # 1) rocprofv3 --kernel-trace --stats (csv) of the default bench,
 # 2) two separate --pmc passes (FETCH_SIZE, WRITE_SIZE; kernel-trace only) of the default bench -> profiles/pmc_traffic.json,
 # 3) bench.py JSON lines (config 2 default, one pair per step, config 3, config 4 bf16 / f32, the driver's command),
@@ -24,6 +24,10 @@ python bench.py > $out/bench.log 2>&1
 tail -1 $out/bench.log > $out/${tag}_bench.json
 python bench.py --pairs-per-step 1 --steps 200 --warmup 20 --no-cpu-baseline > $out/bench_b1.log 2>&1
 tail -1 $out/bench_b1.log > $out/${tag}_bench_pairs1.json
+python bench.py --cloud surface --no-cpu-baseline --no-single-pair > $out/bench_surface.log 2>&1
+tail -1 $out/bench_surface.log > $out/${tag}_bench_surface.json
+python bench.py --weights plain --no-cpu-baseline --no-single-pair > $out/bench_plain.log 2>&1
+tail -1 $out/bench_plain.log > $out/${tag}_bench_plain_weights.json
 python bench.py --config 3 --no-cpu-baseline --no-single-pair > $out/bench_c3.log 2>&1
 tail -1 $out/bench_c3.log > $out/${tag}_bench_config3.json
 python bench.py --config 4 --no-single-pair > $out/bench_c4.log 2>&1
