@@ -773,9 +773,12 @@ __global__ __launch_bounds__(256) void fine_emit_kernel(RoitrFine a)
     if (a.counts[patch] == 0) return;
     const unsigned char* fl = a.flags + (size_t)patch * L * L;
     const float* sc = a.ot + (size_t)patch * (L + 1) * (L + 1);
-    const int per = (L * L) / 256;  // 16 consecutive entries per thread
+    constexpr int per = 16;         // (L * L) / 256 consecutive entries per thread, L == 64 (checked by the launcher): ONE 16-byte load
+    const uint4 f16 = reinterpret_cast<const uint4*>(fl)[tid];
+    const unsigned fw[4] = {f16.x, f16.y, f16.z, f16.w};
     int c = 0;
-    for (int u = 0; u < per; ++u) c += fl[tid * per + u];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) c += __popc(fw[u]);   // a flag byte is 0 or 1
     int incl = c;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
@@ -785,9 +788,10 @@ __global__ __launch_bounds__(256) void fine_emit_kernel(RoitrFine a)
     for (int w = 0; w < wave; ++w) pos += wsum[w];
     const float g = a.global_scores ? a.global_scores[patch] : 1.0f;
     const long cap = a.out_cap > 0 ? a.out_cap : 0x7fffffffL;
+#pragma unroll
     for (int u = 0; u < per; ++u) {
         const int e = tid * per + u;
-        if (fl[e] && pos < cap) {
+        if (((fw[u >> 2] >> (8 * (u & 3))) & 1u) && pos < cap) {
             const int i = e / L, j = e % L;
             const float* rp = a.row_pts + ((size_t)patch * L + i) * 3;
             const float* cp = a.col_pts + ((size_t)patch * L + j) * 3;

@@ -1176,7 +1176,10 @@ __global__ __launch_bounds__(256) void knn_prefilter_kernel(int m, int nsample, 
         for (int u = 0; u < NS; ++u) {
             const float dd = j0 + u < cnt ? sqdist3(qx, qy, qz, c[u].x, c[u].y, c[u].z) : INFINITY;
             const int ci = __float_as_int(c[u].w);
-            if (dd < d[L - 1]) {
+            // no `if (dd < d[L - 1])` around the chain (round 4): nearly every survivor is inserted by SOME lane of the wave, so the
+            // guard only added a divergent branch whose join made hipcc copy the whole list every step (27 v_mov of ~100
+            // instructions per step in the ISA); dd = inf changes nothing
+            {
 #pragma unroll
                 for (int v = L - 1; v > 0; --v) {
                     const bool sh = d[v - 1] > dd, here = d[v] > dd;
