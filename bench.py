@@ -49,7 +49,7 @@ WORKLOADS = {
     3: dict(benchmark="3DLoMatch", n_points=5000, pairs=512, dtype="f32", seed_config=3, weights="selective",
             text="3DLoMatch-rotated synthetic pairs: {N} pts/cloud, seeded test-time SO(3) rotation of one cloud "
                  "(dataset/tdmatch.py:99-112), fp32, 3DMatch test settings, full RIGA_v2 forward"),
-    4: dict(benchmark="4DMatch", n_points=8000, pairs=32, dtype="bf16", seed_config=4, weights="selective",
+    4: dict(benchmark="4DMatch", n_points=8000, pairs=64, dtype="bf16", seed_config=4, weights="selective", record_scores=12288,
             text="4DMatch-sized synthetic pairs: {N} pts/cloud, 4DMatch test settings (factor 2 widths, adaptive coarse matching "
                  "min 128 / thr 0.75, top-2 fine matching), bf16 operand storage in the dense layers (fp32 accumulate; FPS / kNN / "
                  "PPF / OT in fp32), full RIGA_v2 forward"),
@@ -81,8 +81,9 @@ def parse():
     ap.add_argument("--no-rccl-selftest", action="store_true",
                     help="N=1 without torch.distributed.run: do NOT create the 1-rank RCCL group the result gather otherwise runs through")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=20.0)
-    ap.add_argument("--record-scores-per-pair", type=int, default=4092,
-                    help="average score capacity per pair of the gathered result block (shard.py); the block carries every timed step")
+    ap.add_argument("--record-scores-per-pair", type=int, default=None,
+                    help="average score capacity per pair of the gathered result block (shard.py); the block carries every timed step "
+                         "(default 4092; config 4: 12288 -- the adaptive matching emits ~10 k correspondences per pair)")
     return ap.parse_args()
 
 
@@ -229,7 +230,7 @@ def forward_bench(args, rank, world, distributed):
         if not stub:
             torch.cuda.synchronize()
 
-    spp = args.record_scores_per_pair
+    spp = args.record_scores_per_pair or wl.get("record_scores", 4092)
     trace = bool(os.environ.get("ROITR_BENCH_TRACE"))
     with torch.no_grad():
         # warm-up with the SAME loop as the timed region (two batches in flight, the collective at the end): the caching
