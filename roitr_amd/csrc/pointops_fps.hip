@@ -304,7 +304,11 @@ extern "C" int roitr_furthestsampling_ex(int b, int n_max, const float* xyz, con
     const int mask = ref_block_size(n_max) - 1;
     int bits = 0;
     while ((1 << bits) <= mask) ++bits;
-    const int lds_pts = n_max <= FPS_PTS_CAP ? n_max : 0;
+    // the LDS copy of xyz (winner lookup without a memory round trip) is what a FEW clouds on an empty chip want; in a large batch it
+    // only takes LDS away from everybody else: 76 KB per cloud = two clouds per CU and nothing left for the feature path's
+    // workgroups beside them (ROITR_FPS_LDS_MAX_CLOUDS: experiment switch)
+    static const int lds_max_b = getenv("ROITR_FPS_LDS_MAX_CLOUDS") ? atoi(getenv("ROITR_FPS_LDS_MAX_CLOUDS")) : 64;
+    const int lds_pts = (n_max <= FPS_PTS_CAP && b <= lds_max_b) ? n_max : 0;
     // few clouds (the one-pair-per-call mode): the chain of m dependent arg-max iterations is the critical path of the whole
     // forward and the chip is empty -- 8 waves per cloud halve the per-lane work of an iteration (4.36 vs 4.48 ms per pair;
     // 16 waves: 5.03, the cross-wave stage grows faster than the lane work shrinks).  Same indices for every block size.

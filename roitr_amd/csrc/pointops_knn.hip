@@ -229,11 +229,15 @@ __global__ __launch_bounds__(256) void knn_brute_kernel(int m, int nsample, cons
 }
 
 // ---------------------------------------------------------------- grid build (one workgroup per cloud)
+// CAP: cells a cloud may get (LDS counters: 4 CAP bytes).  Small clouds are built with CAP = 4096 (16 KB instead of 64 KB of LDS:
+// the kernel runs on the geometry stream beside the feature path, whose workgroups need the LDS -- round 4); the cell size
+// adapts to the cap either way (the `tot <= CAP` loop below), cell_start keeps its GRID_MAX_CELLS + 1 stride per cloud.
+template <int CAP>
 __global__ __launch_bounds__(1024) void grid_build_kernel(const float* __restrict__ xyz, const int* __restrict__ offset,
                                                           RoitrGrid* __restrict__ grids, int* __restrict__ cell_start,
                                                           float4* __restrict__ sorted, float target_occupancy)
 {
-    __shared__ int cnt[GRID_MAX_CELLS];
+    __shared__ int cnt[CAP];
     __shared__ float red[6][16];
     __shared__ RoitrGrid G;
     __shared__ int wave_tot[16];
@@ -289,7 +293,7 @@ __global__ __launch_bounds__(1024) void grid_build_kernel(const float* __restric
                 d[a] = v < 1 ? 1 : (v > GRID_MAX_DIM ? GRID_MAX_DIM : v);
                 tot *= d[a];
             }
-            if (tot <= GRID_MAX_CELLS) break;
+            if (tot <= CAP) break;
             h *= 1.26f;
         }
         G.ox = lo[0]; G.oy = lo[1]; G.oz = lo[2]; G.h = h; G.inv_h = 1.0f / h; G.nx = d[0]; G.ny = d[1]; G.nz = d[2];
@@ -341,7 +345,7 @@ __global__ __launch_bounds__(1024) void grid_build_kernel(const float* __restric
     };
     // exclusive scan of cnt[0..ncell) : 16 cells per thread
     {
-        constexpr int PER = GRID_MAX_CELLS / 1024;
+        constexpr int PER = CAP / 1024;
         int loc[PER], s = 0;
 #pragma unroll
         for (int j = 0; j < PER; ++j) { const int k = tid * PER + j; loc[j] = k < ncell ? cnt[k] : 0; s += loc[j]; }
@@ -985,10 +989,11 @@ __global__ __launch_bounds__(256) void knn_cell_kernel(int nsample, const float*
 
 // Queries that are not the reference points themselves: counting-sort their indices by the cell of the REFERENCE grid
 // they fall into (one workgroup per cloud), so that the lane kernel walks them in cell order too.
+template <int CAP>   // cells of the reference grid (the cap it was built with: grid_build_kernel<CAP>)
 __global__ __launch_bounds__(1024) void sort_queries_kernel(const float* __restrict__ new_xyz, const int* __restrict__ new_offset,
                                                             const RoitrGrid* __restrict__ grids, int* __restrict__ qorder)
 {
-    __shared__ int cnt[GRID_MAX_CELLS];
+    __shared__ int cnt[CAP];
     __shared__ int wave_tot[16];
     const int c = blockIdx.x;
     const int start = c == 0 ? 0 : new_offset[c - 1], end = new_offset[c];
@@ -1006,7 +1011,7 @@ __global__ __launch_bounds__(1024) void sort_queries_kernel(const float* __restr
     __syncthreads();
     for (int k = start + tid; k < end; k += 1024) atomicAdd(&cnt[cell_of(k)], 1);
     __syncthreads();
-    constexpr int PER = GRID_MAX_CELLS / 1024;
+    constexpr int PER = CAP / 1024;
     int loc[PER], sum = 0;
 #pragma unroll
     for (int j = 0; j < PER; ++j) { const int k = tid * PER + j; loc[j] = k < ncell ? cnt[k] : 0; sum += loc[j]; }
@@ -1539,7 +1544,8 @@ extern "C" int roitr_knn_build_grid_ex(int b, int n, int m_capacity, const float
     WsView v = carve(ws, b, n, m_capacity);
     const float rho = target_occupancy > 0.f ? target_occupancy : 6.0f;
     roitr_prof_begin(ROITR_PROF_GRID, 12.0 * n + 16.0 * n, stream);
-    grid_build_kernel<<<b, 1024, 0, stream>>>(xyz, offset, v.grids, v.cell_start, v.sorted, rho);
+    if ((long)n <= 6144L * b) grid_build_kernel<4096><<<b, 1024, 0, stream>>>(xyz, offset, v.grids, v.cell_start, v.sorted, rho);
+    else grid_build_kernel<GRID_MAX_CELLS><<<b, 1024, 0, stream>>>(xyz, offset, v.grids, v.cell_start, v.sorted, rho);
     roitr_prof_end(ROITR_PROF_GRID, stream);
     ROITR_LAUNCH_CHECK();
     return ROITR_OK;
@@ -1586,7 +1592,8 @@ int knnquery_impl(int b, int n, int m, int nsample, const float* xyz, const floa
     int* qorder = nullptr;
     if (lane_ok && !self_sorted && v.qorder) {
         qorder = v.qorder;
-        sort_queries_kernel<<<b, 1024, 0, stream>>>(new_xyz, new_offset, v.grids, qorder);
+        if ((long)n <= 6144L * b) sort_queries_kernel<4096><<<b, 1024, 0, stream>>>(new_xyz, new_offset, v.grids, qorder);   // the rule of roitr_knn_build_grid_ex
+        else sort_queries_kernel<GRID_MAX_CELLS><<<b, 1024, 0, stream>>>(new_xyz, new_offset, v.grids, qorder);
     }
 #define LANE_CASE(LC)                                                                                                        \
     knn_lane_kernel<LC><<<div_up(m, 256), 256, 0, stream>>>(m, nsample, b, xyz, new_xyz, offset, new_offset, v.grids, v.cell_start, \
