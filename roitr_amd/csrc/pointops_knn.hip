@@ -1325,10 +1325,12 @@ __global__ __launch_bounds__(256) void knn_lane_kernel(int m, int nsample, int b
 template <int L>
 __global__ __launch_bounds__(64) void knn_lane_brute_kernel(int m, int nsample, int b, const float* __restrict__ xyz,
                                                              const float* __restrict__ new_xyz, const int* __restrict__ offset,
-                                                             const int* __restrict__ new_offset, KnnOut o)
+                                                             const int* __restrict__ new_offset, KnnOut o, int CH)
 {
-    constexpr int CH = 1024;
-    __shared__ float4 cand[CH];
+    // CH candidates per staging chunk: dynamic LDS sized by the launcher from the mean cloud (16 CH bytes; a 312-point cloud needs 5 KB,
+    // not the 16 KB of a fixed 1024 -- one wave per workgroup: the LDS decides how many of them a CU holds, and what is left for
+    // the feature path beside them)
+    extern __shared__ __attribute__((aligned(16))) float4 cand[];
     __shared__ int seg_range[2];
     const int tid = threadIdx.x;
     const int q = blockIdx.x * 64 + tid;   // one wave per block: many small blocks interleave their insertion chains
@@ -1640,7 +1642,10 @@ int knnquery_impl(int b, int n, int m, int nsample, const float* xyz, const floa
 #undef LANE_CASE
 #undef PREF_CASE
     if (!use_grid && nsample + 1 <= 34 && (!ppf || group_idx) && m >= lane_brute_min) {
-#define LB_CASE(LC) knn_lane_brute_kernel<LC><<<div_up(m, 64), 64, 0, stream>>>(m, nsample, b, xyz, new_xyz, offset, new_offset, o)
+        // staging chunk: the mean cloud rounded up to 64 points, 64 .. 1024 (a larger cloud takes several chunks)
+        int ch = b > 0 ? (int)(((long)n / b + 63) / 64 * 64) : 1024;
+        ch = ch < 64 ? 64 : (ch > 1024 ? 1024 : ch);
+#define LB_CASE(LC) knn_lane_brute_kernel<LC><<<div_up(m, 64), 64, (size_t)ch * 16, stream>>>(m, nsample, b, xyz, new_xyz, offset, new_offset, o, ch)
         const int need = nsample + 1;
         if (need <= 2) LB_CASE(2); else if (need <= 4) LB_CASE(4); else if (need <= 10) LB_CASE(10);
         else if (need <= 18) LB_CASE(18); else LB_CASE(34);
