@@ -77,6 +77,9 @@ def parse():
                     help="synthetic geometry (roitr_amd/synthetic.py): points ~ U[0,2)^3, or room-like piecewise-planar surfaces with sensor noise")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-single-pair", action="store_true", help="skip the one-pair-per-call measurement (profiling passes)")
+    ap.add_argument("--no-sampling-ahead", action="store_true",
+                    help="order the inputs of every forward on the main stream (the pool is resident, so by default the engine gets an "
+                         "event instead and starts the first sampling level of call s+1 beside call s: RoitrForwardIO::inputs_ready)")
     ap.add_argument("--no-profile-pass", action="store_true", help="skip the instrumented repeat of the timed steps (no rooflines)")
     ap.add_argument("--no-rccl-selftest", action="store_true",
                     help="N=1 without torch.distributed.run: do NOT create the 1-rank RCCL group the result gather otherwise runs through")
@@ -220,6 +223,8 @@ def forward_bench(args, rank, world, distributed):
     else:
         model = build_model(wl["benchmark"], operand_dtype=dtype, weights=weights)
         pool = [pair_to_device(make_pair(N, config=wl["seed_config"], pair_index=i, normals=normals, cloud=args.cloud)) for i in ids]
+        torch.cuda.synchronize()                                   # the pool is resident: nothing pending on any stream
+        model.inputs_resident = not args.no_sampling_ahead
 
     def batch(step):
         return [pool[(step * B + j) % len(pool)] for j in range(B)]
@@ -273,8 +278,17 @@ def forward_bench(args, rank, world, distributed):
                 h1 = nx1
             torch.cuda.synchronize()
             d1 = time.perf_counter() - t1
+            # and the latency of a call with nothing else in flight (launch, wait, unpack; no overlap between calls)
+            t2 = time.perf_counter()
+            n2 = 30
+            for s in range(n2):
+                model.forward_batch([pool[s % len(pool)]], want_gt=True)
+            torch.cuda.synchronize()
+            d2 = time.perf_counter() - t2
         single = {"pairs_per_step": 1, "pairs_per_s": round(n1 / d1, 2), "ms_per_pair": round(1e3 * d1 / n1, 3),
-                  "note": "one pair per engine call (the reference's DataLoader batch size), two calls in flight"}
+                  "ms_per_pair_one_call_in_flight": round(1e3 * d2 / n2, 3), "sampling_ahead": bool(model.inputs_resident),
+                  "note": "one pair per engine call (the reference's DataLoader batch size), two calls in flight; "
+                          "ms_per_pair_one_call_in_flight = latency of a call issued alone"}
 
     # max over ranks of the timed region; total work = pairs of all ranks
     agg = benchloop.aggregate(dt, n_corr_total, B, args.steps)

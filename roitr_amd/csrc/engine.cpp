@@ -121,13 +121,18 @@ struct Engine {
     float* first_consts = nullptr;   // head_consts (64) | G (64 x 32) | zero bias (64)
     Arena warena;  // derived weights
     Arena arena;   // per-forward scratch
+    // sampling-ahead mode (RoitrForwardIO::inputs_ready): descriptors, FPS scratch, pick indices and the coarser levels' coordinates /
+    // normals of forward s+1 are written on the geometry stream while forward s still runs on the main one, so they cannot live in
+    // the (stream-ordered, single) scratch arena: two small arenas used alternately
+    Arena garena[2];
+    int gpar = 0;
     static constexpr int RING = 4;   // descriptor staging slots: the host may run RING forwards ahead
     char* pinned[RING] = {nullptr, nullptr, nullptr, nullptr}; size_t pinned_cap[RING] = {0, 0, 0, 0};
     hipEvent_t pinned_ev[RING] = {nullptr, nullptr, nullptr, nullptr};
     int ring_pos = 0;
     hipStream_t side = nullptr;      // the geometry chain (FPS, grids, kNN + PPF of levels 2-4, 3-NN, embedding E, partition, GT outputs)
-    static constexpr int NEV = 9;    // [8]: the error-path join of roitr_engine_forward
-    hipEvent_t ev[NEV] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    static constexpr int NEV = 10;   // [8]: the error-path join of roitr_engine_forward; [9]: descriptors copied on the geometry stream
+    hipEvent_t ev[NEV] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     bool side_forked = false;        // the current forward has issued work on `side` that `st` has not joined yet
     std::string err;
     hipStream_t fin_stream = nullptr;   // stream of the running finalize (weight conversions are queued on it)
@@ -647,6 +652,7 @@ extern "C" void roitr_engine_destroy(void* h)
     if (!E) return;
     if (E->warena.base) (void)hipFree(E->warena.base);
     if (E->arena.base) (void)hipFree(E->arena.base);
+    for (int i = 0; i < 2; ++i) if (E->garena[i].base) (void)hipFree(E->garena[i].base);
     for (auto& g : E->graphs) {
         if (g.exec) (void)hipGraphExecDestroy(g.exec);
         if (g.graph) (void)hipGraphDestroy(g.graph);
@@ -949,10 +955,41 @@ static int forward_body(void* h, const RoitrForwardIO* io, hipStream_t st)
         E.arena.off = 0; E.arena.fail = false;
     }
     Arena& A = E.arena;
+    if (!E.side) {
+        // (a lower or higher queue priority for this stream changes nothing measurable: 97.3 / 98.2 / 98.2 ms per 512-pair step)
+        ROITR_HIP(hipStreamCreateWithFlags(&E.side, hipStreamNonBlocking));
+        for (int i = 0; i < Engine::NEV; ++i) ROITR_HIP(hipEventCreateWithFlags(&E.ev[i], hipEventDisableTiming));
+    }
+    hipStream_t sd = E.side;
 
     // descriptors: off[4][NC], cloud_of_node[T4], partner[NC], eoff[NC] (long), cloud_ids for rows of level 4
     const size_t desc_ints = (size_t)4 * NC + T4 + NC + 8;
     const size_t desc_bytes = ((desc_ints * 4 + 15) & ~(size_t)15) + (size_t)NC * 8;
+    // ---------------- sampling ahead of the previous forward's tail (io->inputs_ready, include/roitr_engine.h).  `st` is in order,
+    // so everything queued on it for this forward starts after the previous forward has left it -- but the first sampling level
+    // (one serial chain per cloud: 0.9 ms for a 5000-point pair, 1/3 of a one-pair forward) needs the input coordinates only.
+    // With the inputs ordered by an event instead of by `st`, the geometry stream copies the descriptors and runs that level
+    // at once, beside the previous forward; the rest of the geometry chain writes scratch of the shared arena and waits, as
+    // before, for the point of `st` where this forward begins.
+    const bool ahead = io->inputs_ready != nullptr && E.capture_pin == nullptr;
+    Arena& G = ahead ? E.garena[E.gpar] : E.arena;
+    if (ahead) {
+        size_t need = desc_bytes + (size_t)T1 * 4 + (size_t)2 * NC * 4 + 8192;
+        for (int l = 1; l < 4; ++l) need += (size_t)V.T[l] * (4 + 12 + 12) + 1024;
+        if (need > G.cap) {
+            ROITR_HIP(hipStreamSynchronize(st));
+            ROITR_HIP(hipStreamSynchronize(sd));
+            if (G.base) ROITR_HIP(hipFree(G.base));
+            G.base = nullptr; G.cap = 0;
+            ROITR_HIP(hipMalloc((void**)&G.base, need * 2));
+            G.cap = need * 2;
+        }
+        G.off = 0; G.fail = false;
+        E.gpar ^= 1;
+        ROITR_HIP(hipStreamWaitEvent(sd, (hipEvent_t)io->inputs_ready, 0));
+        E.side_forked = true;
+    }
+    hipStream_t st_desc = ahead ? sd : st;   // the stream that stages the descriptors
     const int slot = E.ring_pos;
     char* pin = E.capture_pin;   // a captured forward owns its staging buffer (the graph re-reads it at every launch)
     if (!pin) {
@@ -974,9 +1011,13 @@ static int forward_body(void* h, const RoitrForwardIO* io, hipStream_t st)
     for (int c = 0; c < NC; ++c) h_partner[c] = c < B ? c + B : c - B;
     long* h_eoff = (long*)(pin + ((desc_ints * 4 + 15) & ~(size_t)15));
     memcpy(h_eoff, eoff.data(), sizeof(long) * NC);
-    char* ddesc = A.get<char>(desc_bytes);
-    ROITR_HIP(hipMemcpyAsync(ddesc, pin, desc_bytes, hipMemcpyHostToDevice, st));
-    if (!E.capture_pin) ROITR_HIP(hipEventRecord(E.pinned_ev[slot], st));
+    char* ddesc = G.get<char>(desc_bytes);
+    ROITR_HIP(hipMemcpyAsync(ddesc, pin, desc_bytes, hipMemcpyHostToDevice, st_desc));
+    if (!E.capture_pin) ROITR_HIP(hipEventRecord(E.pinned_ev[slot], st_desc));
+    if (ahead) {   // `st` reads the descriptors (and the inputs) from here on
+        ROITR_HIP(hipEventRecord(E.ev[9], sd));
+        ROITR_HIP(hipStreamWaitEvent(st, E.ev[9], 0));
+    }
     Dev D;
     for (int l = 0; l < 4; ++l) D.off[l] = (int*)ddesc + (size_t)l * NC;
     D.cloud_of_node = (int*)ddesc + (size_t)4 * NC;
@@ -1001,12 +1042,6 @@ static int forward_body(void* h, const RoitrForwardIO* io, hipStream_t st)
     bool grid[4];
     const void* order[4] = {nullptr, nullptr, nullptr, nullptr};  // cell-order visiting order of each level's points
     float* xe[4];
-    if (!E.side) {
-        // (a lower or higher queue priority for this stream changes nothing measurable: 97.3 / 98.2 / 98.2 ms per 512-pair step)
-        ROITR_HIP(hipStreamCreateWithFlags(&E.side, hipStreamNonBlocking));
-        for (int i = 0; i < Engine::NEV; ++i) ROITR_HIP(hipEventCreateWithFlags(&E.ev[i], hipEventDisableTiming));
-    }
-    hipStream_t sd = E.side;
     const float* pts_out = io->points_out ? io->points_out : io->points_geom;
     float* node_xyz = io->node_xyz ? io->node_xyz : A.get<float>((size_t)T4 * 3);
     int* node_masks = io->node_masks ? io->node_masks : A.get<int>(T4);
@@ -1017,13 +1052,28 @@ static int forward_body(void* h, const RoitrForwardIO* io, hipStream_t st)
     // attention kernel for this width reads it (C = 256 / 512, 4 heads, <= 512 superpoints)
     const bool e_h = E.cfg.operand_dtype == 1 && E.proj_d.wb && E.proj_a.wb && (C4 == 256 || C4 == 512) && V.nmax[3] <= 512;
     {
-        float* fps_tmp = A.get<float>(T1);
-        int* fps_tie[4] = {nullptr, A.get<int>(NC), A.get<int>(NC), nullptr};   // per cloud: first pick with a shared arg-max
+        float* fps_tmp = G.get<float>(T1);
+        int* fps_tie[4] = {nullptr, G.get<int>(NC), G.get<int>(NC), nullptr};   // per cloud: first pick with a shared arg-max
         for (int l = 1; l < 4; ++l) {
-            down[l] = A.get<int>(V.T[l]);
-            p[l] = A.get<float>((size_t)V.T[l] * 3);
-            nrm[l] = A.get<float>((size_t)V.T[l] * 3);
+            down[l] = G.get<int>(V.T[l]);
+            p[l] = G.get<float>((size_t)V.T[l] * 3);
+            nrm[l] = G.get<float>((size_t)V.T[l] * 3);
         }
+        if (G.fail) { roitr_set_error("arena exhausted (sampling)", __FILE__, __LINE__); return ROITR_ERR_ARG; }
+        // level l's picks and their coordinates / normals: the part of the geometry chain that touches none of the shared scratch
+        auto sample_level = [&](int l) -> int {
+            // tmp = 1e10 (functions/pointops.py:22)
+            ROITR_HIP(hipMemsetD32Async((hipDeviceptr_t)fps_tmp, 0x501502F9 /* bits of 1e10f */, V.T[l - 1], sd));
+            roitr_prof_next_bytes(ROITR_PROF_FPS, 12.0 * V.T[l - 1] + 4.0 * V.T[l] + 8.0 * V.T[l - 1]);
+            // levels 2 and 3 sample the previous level's picks in pick order: answered with the prefix while no arg-max was
+            // shared (pointops_fps.hip), the serial chain of 312 + 78 dependent iterations otherwise
+            CHK(roitr_furthestsampling_ex(NC, V.nmax[l - 1], p[l - 1], D.off[l - 1], D.off[l], fps_tmp, down[l], l > 1 ? fps_tie[l - 1] : nullptr,
+                                          l < 3 ? fps_tie[l] : nullptr, 4, sd));
+            CHK(roitr_gather_rows(V.T[l], 3, p[l - 1], down[l], 0, (float*)p[l], sd));
+            CHK(roitr_gather_rows(V.T[l], 3, nrm[l - 1], down[l], 0, (float*)nrm[l], sd));
+            return ROITR_OK;
+        };
+        if (ahead) CHK(sample_level(1));
         // every buffer the side stream writes is carved here, before the encoder's mark / release scopes
         for (int l = 0; l < 4; ++l) {
             const int K = E.nsample[l];
@@ -1062,15 +1112,7 @@ static int forward_body(void* h, const RoitrForwardIO* io, hipStream_t st)
         E.side_forked = true;
         for (int l = 1; l < 4; ++l) {
             const int K = E.nsample[l];
-            // tmp = 1e10 (functions/pointops.py:22)
-            ROITR_HIP(hipMemsetD32Async((hipDeviceptr_t)fps_tmp, 0x501502F9 /* bits of 1e10f */, V.T[l - 1], sd));
-            roitr_prof_next_bytes(ROITR_PROF_FPS, 12.0 * V.T[l - 1] + 4.0 * V.T[l] + 8.0 * V.T[l - 1]);
-            // levels 2 and 3 sample the previous level's picks in pick order: answered with the prefix while no arg-max was
-            // shared (pointops_fps.hip), the serial chain of 312 + 78 dependent iterations otherwise
-            CHK(roitr_furthestsampling_ex(NC, V.nmax[l - 1], p[l - 1], D.off[l - 1], D.off[l], fps_tmp, down[l], l > 1 ? fps_tie[l - 1] : nullptr,
-                                          l < 3 ? fps_tie[l] : nullptr, 4, sd));
-            CHK(roitr_gather_rows(V.T[l], 3, p[l - 1], down[l], 0, (float*)p[l], sd));
-            CHK(roitr_gather_rows(V.T[l], 3, nrm[l - 1], down[l], 0, (float*)nrm[l], sd));
+            if (!(ahead && l == 1)) CHK(sample_level(l));
             // grid over this level's points (refs for: own self-kNN, next level's TD query, finer level's 3-NN)
             if (grid[l]) {
                 CHK(roitr_knn_build_grid_ex(NC, V.T[l], V.T[l - 1], p[l], D.off[l], knn_ws[l], grid_occ(l), sd));

@@ -32,34 +32,71 @@ struct Slot {
     float x, y, z, pad;
 };
 
-// ---- cross-lane maxima with DPP row shifts / row broadcasts (VALU-rate; a __shfl_xor butterfly lowers to
-// ds_bpermute = one LDS round trip per step on this serial critical path).  Lanes without a DPP source keep
-// their own value (old = src, bound_ctrl = 0), harmless for an idempotent max.  After the row_shr steps lane 15
-// of every 16-lane row holds the row max; row_bcast:15 / :31 fold the rows; lane 63 ends with the wave max.
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ float dpp_fmax(float v)
-{
-    const int i = __float_as_int(v);
-    return fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(i, i, CTRL, ROW_MASK, 0xf, false)));
-}
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ unsigned dpp_umax(unsigned v)
-{
-    const unsigned w = (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, ROW_MASK, 0xf, false);
-    return w > v ? w : v;
-}
+// ---- cross-lane reductions as FUSED DPP instructions: one VALU op per butterfly step (`v_max_f32_dpp v, v, v row_shr:1`).  The
+// compiler's lowering of update_dpp + fmaxf is four (copy, v_mov_dpp, a NaN-quieting v_max v,v,v, v_max), and every instruction of
+// this loop is on the serial critical path of the sampling chain (a wave issues one instruction per 4 cycles whatever its kind).
+// Lanes without a DPP source (bound_ctrl 0) and rows outside row_mask keep their value -- harmless for max, and for the sums below
+// the lane that is read back always has all its sources.  `s_nop 1`: the two wait states between a VALU write and a DPP read of
+// the same VGPR, which nobody inserts inside an asm statement.  After row_shr 1/2/4/8 lane 15 of every 16-lane row holds the row's
+// result; row_bcast:15 / :31 fold the rows; lane 63 ends with the wave's.
+#define ROITR_DPP(op, v, ctrl) asm("s_nop 1\n\t" op " %0, %0, %0 " ctrl : "+v"(v))
+#define ROITR_DPP_WAVE(op, v)                                    \
+    ROITR_DPP(op, v, "row_shr:1 row_mask:0xf bank_mask:0xf");    \
+    ROITR_DPP(op, v, "row_shr:2 row_mask:0xf bank_mask:0xf");    \
+    ROITR_DPP(op, v, "row_shr:4 row_mask:0xf bank_mask:0xf");    \
+    ROITR_DPP(op, v, "row_shr:8 row_mask:0xf bank_mask:0xf");    \
+    ROITR_DPP(op, v, "row_bcast:15 row_mask:0xa bank_mask:0xf"); \
+    ROITR_DPP(op, v, "row_bcast:31 row_mask:0xc bank_mask:0xf"); \
+    asm("s_nop 1" ::: )
 __device__ __forceinline__ float wave_fmax(float v)
 {
-    v = dpp_fmax<0x111, 0xf>(v); v = dpp_fmax<0x112, 0xf>(v); v = dpp_fmax<0x114, 0xf>(v); v = dpp_fmax<0x118, 0xf>(v);
-    v = dpp_fmax<0x142, 0xa>(v); v = dpp_fmax<0x143, 0xc>(v);
+    ROITR_DPP_WAVE("v_max_f32_dpp", v);
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 __device__ __forceinline__ unsigned wave_umax(unsigned v)
 {
-    v = dpp_umax<0x111, 0xf>(v); v = dpp_umax<0x112, 0xf>(v); v = dpp_umax<0x114, 0xf>(v); v = dpp_umax<0x118, 0xf>(v);
-    v = dpp_umax<0x142, 0xa>(v); v = dpp_umax<0x143, 0xc>(v);
+    ROITR_DPP_WAVE("v_max_u32_dpp", v);
     return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
 }
+// the same over groups of G = 2, 4, 8 or 16 consecutive lanes: lane G-1 of the first group ends with the group's result
+template <int G, typename T>
+__device__ __forceinline__ T group_reduce_read(T v, const int kind)   // kind 0: fmax, 1: umax, 2: uadd
+{
+#define ROITR_DPP_G(op)                                                          \
+    if (G > 1) ROITR_DPP(op, v, "row_shr:1 row_mask:0xf bank_mask:0xf");         \
+    if (G > 2) ROITR_DPP(op, v, "row_shr:2 row_mask:0xf bank_mask:0xf");         \
+    if (G > 4) ROITR_DPP(op, v, "row_shr:4 row_mask:0xf bank_mask:0xf");         \
+    if (G > 8) ROITR_DPP(op, v, "row_shr:8 row_mask:0xf bank_mask:0xf");
+    if (kind == 0) { ROITR_DPP_G("v_max_f32_dpp") } else if (kind == 1) { ROITR_DPP_G("v_max_u32_dpp") } else { ROITR_DPP_G("v_add_u32_dpp") }
+#undef ROITR_DPP_G
+    asm("s_nop 1" ::: );
+    int bits;
+    __builtin_memcpy(&bits, &v, 4);
+    bits = __builtin_amdgcn_readlane(bits, G - 1);
+    T r;
+    __builtin_memcpy(&r, &bits, 4);
+    return r;
+}
+// v_min_f32 / v_max3 as written: fminf / fmaxf on a loop-carried register put a NaN-quieting `v_max_f32 v, v, v` in front of every use
+__device__ __forceinline__ float vmin_f32(float a, float b)
+{
+    float r;
+    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float vmax3_f32(float a, float b, float c)
+{
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ unsigned vmax3_u32(unsigned a, unsigned b, unsigned c)
+{
+    unsigned r;
+    asm("v_max3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ long long wave_max_i64(long long v)
 {
 #pragma unroll
@@ -100,12 +137,13 @@ __global__ __launch_bounds__(BLOCK) void fps_kernel(const float* __restrict__ xy
                                                     const int* __restrict__ prev_tie, int* __restrict__ tie_out, int track_div)
 {
     constexpr int NW = BLOCK / 64;
+    constexpr int NP = PPT / 2;                                            // two points per packed-fp32 register pair
+    static_assert(PPT % 2 == 0 && NW <= 16, "points are held in pairs; the cross-wave stage is one DPP group");
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float2* slots = reinterpret_cast<float2*>(smem);                       // [2][NW] : (max d2, tie word as float bits)
-    __shared__ int wcnt[2][NW];                                            // points attaining the wave maximum (tracked picks only)
-    int* sidx = reinterpret_cast<int*>(smem + 2 * NW * sizeof(float2));    // [FPS_IDX_CAP]
+    float4* slots = reinterpret_cast<float4*>(smem);                       // [2][NW] : (max d2, tie word, points attaining it, -)
+    int* sidx = reinterpret_cast<int*>(smem + 2 * NW * sizeof(float4));    // [FPS_IDX_CAP]
     // xyz copy for the winner lookup, three planes of lds_pts floats (12 B per point: two 5000-point clouds share a CU)
-    float* spts = reinterpret_cast<float*>(smem + 2 * NW * sizeof(float2) + FPS_IDX_CAP * sizeof(int));
+    float* spts = reinterpret_cast<float*>(smem + 2 * NW * sizeof(float4) + FPS_IDX_CAP * sizeof(int));
 
     const int bid = blockIdx.x;
     const int start_n = bid == 0 ? 0 : offset[bid - 1];
@@ -129,7 +167,11 @@ __global__ __launch_bounds__(BLOCK) void fps_kernel(const float* __restrict__ xy
     const int track = (tie_out && track_div > 0) ? (end_m - start_m) / track_div : 0;
     int first_tie = 0x7fffffff;
 
-    float px[PPT], py[PPT], pz[PPT], pt[PPT];
+    // register slot j of thread tid holds point tid + j * BLOCK; slots 2p and 2p+1 share a register pair so that the three
+    // differences, the square and the two fused multiply-adds of a distance are v_pk_*_f32 instructions on two points at once
+    // (same IEEE operations per element as sqdist3: bit-identical, 6 instructions per two points instead of 12)
+    f32x2 px[NP], py[NP], pz[NP];
+    float pt[PPT];
     // (k-start) mod bs_ref only depends on j mod 4 because bs_ref <= 4*BLOCK for every dispatch below
     unsigned tba[4];
 #pragma unroll
@@ -137,15 +179,15 @@ __global__ __launch_bounds__(BLOCK) void fps_kernel(const float* __restrict__ xy
 #pragma unroll
     for (int j = 0; j < PPT; ++j) {
         const int koff = tid + j * BLOCK;
+        float x = 0.f, y = 0.f, z = 0.f;
+        pt[j] = -1.f;
         if (koff < n) {
             const float* p = xyz + (size_t)(start_n + koff) * 3;
-            px[j] = p[0]; py[j] = p[1]; pz[j] = p[2];
+            x = p[0]; y = p[1]; z = p[2];
             pt[j] = tmp[start_n + koff];
-            if (pts_in_lds) { spts[koff] = px[j]; spts[lds_pts + koff] = py[j]; spts[2 * lds_pts + koff] = pz[j]; }
-        } else {
-            px[j] = py[j] = pz[j] = 0.f;
-            pt[j] = -1.f;
+            if (pts_in_lds) { spts[koff] = x; spts[lds_pts + koff] = y; spts[2 * lds_pts + koff] = z; }
         }
+        px[j >> 1][j & 1] = x; py[j >> 1][j & 1] = y; pz[j >> 1][j & 1] = z;
     }
 
     if (tid == 0 && start_m < end_m) idx[start_m] = start_n;
@@ -158,49 +200,46 @@ __global__ __launch_bounds__(BLOCK) void fps_kernel(const float* __restrict__ xy
 
     for (int jm = start_m + 1; jm < end_m; ++jm) {
         float dmax = -1.f;
+        const f32x2 o2x = {ox, ox}, o2y = {oy, oy}, o2z = {oz, oz};
 #pragma unroll
-        for (int j = 0; j < PPT; ++j) {
-            const float d2 = fminf(sqdist3(px[j], py[j], pz[j], ox, oy, oz), pt[j]);
-            pt[j] = d2;
-            dmax = fmaxf(dmax, d2);
+        for (int p = 0; p < NP; ++p) {
+            const f32x2 dx = px[p] - o2x, dy = py[p] - o2y, dz = pz[p] - o2z;
+            const f32x2 d = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
+            pt[2 * p] = vmin_f32(d[0], pt[2 * p]);
+            pt[2 * p + 1] = vmin_f32(d[1], pt[2 * p + 1]);
+            dmax = vmax3_f32(dmax, pt[2 * p], pt[2 * p + 1]);
         }
         const float wd = wave_fmax(dmax);
         const bool tracked = jm - start_m < track;           // block-uniform
         unsigned btb = 0u;
-        int nat = 0;
+        unsigned long long at[PPT];                          // lanes whose slot j attains the wave maximum: the compare's SGPR pair
 #pragma unroll
-        for (int j = 0; j < PPT; ++j) {
-            const unsigned tb = tba[j & 3] - (unsigned)(j * BLOCK);
-            const bool at = pt[j] == wd;
-            const unsigned c = at ? tb : 0u;
-            btb = c > btb ? c : btb;
-            if (tracked) nat += at ? 1 : 0;
+        for (int p = 0; p < NP; ++p) {
+            at[2 * p] = __builtin_amdgcn_ballot_w64(pt[2 * p] == wd);
+            at[2 * p + 1] = __builtin_amdgcn_ballot_w64(pt[2 * p + 1] == wd);
+            const unsigned c0 = pt[2 * p] == wd ? tba[(2 * p) & 3] - (unsigned)(2 * p * BLOCK) : 0u;
+            const unsigned c1 = pt[2 * p + 1] == wd ? tba[(2 * p + 1) & 3] - (unsigned)((2 * p + 1) * BLOCK) : 0u;
+            btb = vmax3_u32(btb, c0, c1);
+        }
+        int wn = 0;                                          // points of this wave that attain its maximum (scalar unit, tracked picks only)
+        if (tracked) {
+#pragma unroll
+            for (int j = 0; j < PPT; ++j) wn += __builtin_popcountll(at[j]);
         }
         const unsigned wtb = wave_umax(btb);
-        float2* buf = slots + (jm & 1) * NW;
-        if (tracked) {
-            const int wn = (int)wave_sum((float)nat);          // <= 64 * PPT: exact in fp32
-            if (lane == 0) wcnt[jm & 1][wave] = wn;
-        }
-        if (lane == 0) buf[wave] = make_float2(wd, __uint_as_float(wtb));
+        float4* buf = slots + (jm & 1) * NW;
+        if (lane == 0) buf[wave] = make_float4(wd, __uint_as_float(wtb), __int_as_float(wn), 0.f);
         // LDS-only barrier: wait for this wave's LDS write, not for outstanding global traffic
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        float gd = -1.f;
-        float2 sl[NW];
-#pragma unroll
-        for (int w = 0; w < NW; ++w) { sl[w] = buf[w]; gd = fmaxf(gd, sl[w].x); }
-        unsigned gtb = 0u;
-#pragma unroll
-        for (int w = 0; w < NW; ++w) {
-            const unsigned c = sl[w].x == gd ? __float_as_uint(sl[w].y) : 0u;
-            gtb = c > gtb ? c : gtb;
-        }
+        // cross-wave stage: lane l takes the slot of wave l mod NW (one ds_read_b128), the NW slots are folded with DPP steps
+        const float4 sl = buf[lane & (NW - 1)];
+        const float gd = group_reduce_read<NW>(sl.x, 0);
+        const bool top = sl.x == gd;
+        const unsigned gtb = group_reduce_read<NW>(top ? __float_as_uint(sl.y) : 0u, 1);
         if (tracked) {
-            int tot = 0;
-#pragma unroll
-            for (int w = 0; w < NW; ++w) tot += sl[w].x == gd ? wcnt[jm & 1][w] : 0;
-            if (tot != 1 && first_tie == 0x7fffffff) first_tie = jm - start_m;
+            const unsigned tot = group_reduce_read<NW>(top ? __float_as_uint(sl.z) : 0u, 2);
+            if (tot != 1u && first_tie == 0x7fffffff) first_tie = jm - start_m;
         }
         int old = start_n;
         if (gd >= 0.f) old = start_n + (int)(0x1FFFFFu - ((gtb - 1u) & 0x1FFFFFu));
@@ -272,7 +311,7 @@ __global__ __launch_bounds__(BLOCK) void fps_stream_kernel(const float* __restri
 
 size_t fps_lds_bytes(int block, int lds_pts)
 {
-    return (size_t)2 * (block / 64) * sizeof(float2) + FPS_IDX_CAP * sizeof(int) + (size_t)lds_pts * 3 * sizeof(float);
+    return (size_t)2 * (block / 64) * sizeof(float4) + FPS_IDX_CAP * sizeof(int) + (size_t)lds_pts * 3 * sizeof(float);
 }
 
 // cuda_utils.h:11-14: the block size the reference would launch, same double-precision formula
@@ -312,7 +351,8 @@ extern "C" int roitr_furthestsampling_ex(int b, int n_max, const float* xyz, con
     // few clouds (the one-pair-per-call mode): the chain of m dependent arg-max iterations is the critical path of the whole
     // forward and the chip is empty -- 8 waves per cloud halve the per-lane work of an iteration (4.36 vs 4.48 ms per pair;
     // 16 waves: 5.03, the cross-wave stage grows faster than the lane work shrinks).  Same indices for every block size.
-    const int forced = b <= 16 && n_max <= 512 * 16 ? 512 : 0;
+    static const int small_batch_block = getenv("ROITR_FPS_SMALL_BATCH_BLOCK") ? atoi(getenv("ROITR_FPS_SMALL_BATCH_BLOCK")) : 512;   // experiment switch
+    const int forced = b <= 16 && n_max <= 512 * 16 && small_batch_block == 512 ? 512 : 0;
 #define FPS_CASE(BLK, P)                                                                              \
     if (n_max <= (BLK) * (P) && (forced == 0 || forced == (BLK))) {                                   \
         ROITR_GRANT_LDS((fps_kernel<BLK, P>), fps_lds_bytes(BLK, FPS_PTS_CAP));                       \

@@ -142,7 +142,7 @@ class _CForwardIO(ctypes.Structure):
                 ("tgt_knn_pts", _P), ("src_knn_pts", _P), ("tgt_knn_masks", _P), ("src_knn_masks", _P),
                 ("matching_scores", _P), ("out_tgt_pts", _P), ("out_src_pts", _P), ("out_scores", _P), ("out_patch", _P),
                 ("fine_offsets", _P), ("n_out", _P), ("gt_node_occ", _P), ("gt_corr_idx", _P), ("gt_corr_overlaps", _P),
-                ("gt_corr_count", _P)]
+                ("gt_corr_count", _P), ("inputs_ready", _P)]
 
 
 def _cfg_get(config, key, default=None):
@@ -208,6 +208,10 @@ class RIGA_v2(nn.Module):
                 t = torch.tensor(1.0)
             _attach(self, key, t, kind)
         self._engine = None
+        # launch_batch default: True = the pairs handed to it are complete device tensors with nothing pending on the current
+        # stream (a resident pool, a loader that synchronised its copies) -- see launch_batch(inputs_resident=...)
+        self.inputs_resident = False
+        self._pack_stream = None
         self._engine_sig = None
 
     # ---------------------------------------------------------------- engine plumbing
@@ -342,7 +346,7 @@ class RIGA_v2(nn.Module):
                                "every pair its ground-truth transform")
         return all(flags)
 
-    def launch_batch(self, pairs, want_gt=True, graph=False):
+    def launch_batch(self, pairs, want_gt=True, graph=False, inputs_resident=None):
         """Enqueue the batched forward on the current stream and return a handle for finish_batch().  Nothing here waits
         for the GPU: a caller may launch batch s+1 before finishing batch s, so the device never idles while the host
         unpacks results (outputs are per-call tensors, the engine's scratch arena is re-used in stream order).
@@ -350,7 +354,12 @@ class RIGA_v2(nn.Module):
         graph=True: the forward of a repeated shape is replayed as ONE HIP graph launch (roitr_engine_forward_graph)
         instead of ~800 kernel launches -- what makes the one-pair-per-call mode fast.  The inputs are copied into, and the
         results live in, persistent buffers that are re-used every GRAPH_RING-th call of the same shape: consume a
-        result before launching GRAPH_RING more batches of that shape."""
+        result before launching GRAPH_RING more batches of that shape.
+
+        inputs_resident (default: self.inputs_resident): the caller states that the tensors of `pairs` are complete -- no copy
+        or kernel producing them is still pending on the current stream.  The inputs are then packed on a side stream and the
+        engine starts this forward's first sampling level beside the previous forward instead of behind it
+        (RoitrForwardIO::inputs_ready): one pair per call 3.26 -> see DESIGN.md.  Same results."""
         self._ensure_engine()
         if graph:
             return self._launch_graph(pairs, want_gt)
@@ -361,11 +370,30 @@ class RIGA_v2(nn.Module):
         n_tgt = [int(p["tgt_pcd"].shape[0]) for p in pairs]
         n_all = n_src + n_tgt
         T = sum(n_all)
+        have_gt = self._have_gt(pairs, want_gt)
         cat = lambda ks, kt: torch.cat([p[ks].to(f32) for p in pairs] + [p[kt].to(f32) for p in pairs], 0).contiguous()
-        geom = cat("src_raw_pcd", "tgt_pcd")
-        pout = cat("src_pcd", "tgt_pcd")
-        nrm = cat("src_normals", "tgt_normals")
-        feats = cat("src_feats", "tgt_feats")
+
+        def pack_inputs():
+            rot = trans = None
+            if have_gt:
+                rot = torch.stack([p["rot"].reshape(3, 3).to(f32) for p in pairs]).contiguous()
+                trans = torch.stack([p["trans"].reshape(3).to(f32) for p in pairs]).contiguous()
+            return (cat("src_raw_pcd", "tgt_pcd"), cat("src_pcd", "tgt_pcd"), cat("src_normals", "tgt_normals"), cat("src_feats", "tgt_feats"),
+                    rot, trans)
+
+        ready = None
+        if self.inputs_resident if inputs_resident is None else inputs_resident:
+            # the pairs are complete device tensors already (nothing pending on the current stream): pack them on a stream of their
+            # own and hand the engine an event, so the first sampling level of this forward starts beside the previous forward
+            # instead of behind it on the current stream (RoitrForwardIO::inputs_ready)
+            if self._pack_stream is None:
+                self._pack_stream = torch.cuda.Stream(device=dev)
+            with torch.cuda.stream(self._pack_stream):
+                geom, pout, nrm, feats, rot, trans = pack_inputs()
+                ready = torch.cuda.Event()
+                ready.record()
+        else:
+            geom, pout, nrm, feats, rot, trans = pack_inputs()
         n4 = [self.level_sizes(n)[3] for n in n_all]
         T4 = sum(n4)
         C = 256 * self.factor
@@ -381,7 +409,6 @@ class RIGA_v2(nn.Module):
                    tgt_knn_masks=z((B, P, Lm), i32), src_knn_masks=z((B, P, Lm), i32), matching_scores=z((B, P, Lm + 1, Lm + 1)),
                    out_tgt_pts=z((cap, 3)), out_src_pts=z((cap, 3)), out_scores=z((cap,)), out_patch=z((cap,), i32),
                    fine_offsets=z((B * P,), i32), n_out=z((1,), i32))
-        have_gt = self._have_gt(pairs, want_gt)
         if have_gt:
             out.update(gt_node_occ=z((T4,)), gt_corr_idx=z((B, n4max * n4max, 2), i32), gt_corr_overlaps=z((B, n4max * n4max)),
                        gt_corr_count=z((B,), i32))
@@ -390,11 +417,8 @@ class RIGA_v2(nn.Module):
         arr = (ctypes.c_int * (2 * B))(*n_all)
         io.n_points = ctypes.cast(arr, ctypes.POINTER(ctypes.c_int))
         io.points_geom, io.normals, io.feats, io.points_out = L.ptr(geom), L.ptr(nrm), L.ptr(feats), L.ptr(pout)
-        rot = trans = None
-        if have_gt:
-            rot = torch.stack([p["rot"].reshape(3, 3).to(f32) for p in pairs]).contiguous()
-            trans = torch.stack([p["trans"].reshape(3).to(f32) for p in pairs]).contiguous()
         io.rot, io.trans = L.ptr(rot), L.ptr(trans)
+        io.inputs_ready = ready.cuda_event if ready is not None else None
         for k, v in out.items():
             setattr(io, k, L.ptr(v))
         L.check(L.lib().roitr_engine_forward(self._engine, ctypes.byref(io), L.stream_ptr()), "engine_forward")
@@ -406,7 +430,7 @@ class RIGA_v2(nn.Module):
         meta_host.copy_(meta_dev, non_blocking=True)
         done = torch.cuda.Event()
         done.record()
-        keep = (geom, pout, nrm, feats, rot, trans, arr, meta_dev)   # inputs stay alive until the forward has run
+        keep = (geom, pout, nrm, feats, rot, trans, arr, meta_dev, ready)   # inputs stay alive until the forward has run
         return dict(pairs=pairs, out=out, B=B, P=P, n_all=n_all, n4=n4, have_gt=have_gt, meta_host=meta_host, done=done, keep=keep)
 
     def _launch_graph(self, pairs, want_gt):

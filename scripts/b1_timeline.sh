@@ -26,4 +26,12 @@ if len(marks)>22:
     for s,e,n,q in seg: t[n][0]+=e-s; t[n][1]+=1
     for n,(d,c) in sorted(t.items(),key=lambda kv:-kv[1][0])[:25]:
         print("%-42s calls/fwd %5.1f  us/fwd %7.1f  avg %6.1f"%(n,c/nf,d/1e3/nf,d/1e3/c))
+    # one forward, kernel by kernel: start offset, duration, gap to the previous end on the same queue, queue id
+    a,b=marks[-2],marks[-1]
+    t0=rows[a][0]; last={}
+    print("--- one forward (us): start  dur  gap_same_queue  queue  kernel")
+    for s,e,n,q in rows[a:b]:
+        g=(s-last[q])/1e3 if q in last else 0.0
+        last[q]=e
+        print("%8.1f %7.1f %6.1f  q%-3s %s"%((s-t0)/1e3,(e-s)/1e3,g,q,n))
 PY

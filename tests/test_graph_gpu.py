@@ -90,3 +90,32 @@ def test_batches_in_flight_do_not_interfere():
                 _same(x, y)
             for x, y in zip(got[2], ref_big):
                 assert torch.equal(x["corr_scores"], y["corr_scores"]) and torch.equal(x["src_corr_points"], y["src_corr_points"])
+
+
+def test_sampling_ahead_of_the_previous_forward_changes_nothing():
+    """launch_batch(inputs_resident=True) hands the engine an event instead of stream order for the inputs
+    (RoitrForwardIO::inputs_ready): the descriptors and the first sampling level of call s+1 then run on the geometry stream
+    while call s is still on the main one, in scratch of their own.  Four calls in flight, the modes mixed, big and small
+    batches alternating (so that a stale descriptor block, FPS scratch or pick list of the call before -- or of the call
+    before that, which shares the alternating arena -- would be read): every output bit-identical to the pairs run alone."""
+    from roitr_amd.synthetic import make_pair
+    from tests.gpu_util import build_model, pair_to_device
+    model = build_model("3DMatch")
+    small = [pair_to_device(make_pair(n, config=2, pair_index=i)) for i, n in enumerate((1024, 1500))]
+    big = [pair_to_device(make_pair(n, config=2, pair_index=10 + i)) for i, n in enumerate((5000, 4000, 3000, 5000, 2048, 4500))]
+    one = [pair_to_device(make_pair(5000, config=2, pair_index=30))]
+    with torch.no_grad():
+        ref_small, ref_big, ref_one = model.forward_batch(small), model.forward_batch(big), model.forward_batch(one)
+        torch.cuda.synchronize()
+        for rounds in range(3):
+            hs = [model.launch_batch(big, inputs_resident=True), model.launch_batch(small, inputs_resident=True),
+                  model.launch_batch(one, inputs_resident=rounds != 1), model.launch_batch(big, inputs_resident=True),
+                  model.launch_batch(one, inputs_resident=True), model.launch_batch(small, inputs_resident=rounds == 2)]
+            got = [model.finish_batch(h) for h in hs]
+            for g, ref in zip(got, (ref_big, ref_small, ref_one, ref_big, ref_one, ref_small)):
+                for x, y in zip(g, ref):
+                    _same(x, y)
+        # the default of the model object (what bench.py sets)
+        model.inputs_resident = True
+        h0, h1 = model.launch_batch(one), model.launch_batch(one)
+        _same(model.finish_batch(h0)[0], ref_one[0]); _same(model.finish_batch(h1)[0], ref_one[0])
