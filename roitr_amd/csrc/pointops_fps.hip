@@ -134,7 +134,7 @@ template <int BLOCK, int PPT>
 __global__ __launch_bounds__(BLOCK) void fps_kernel(const float* __restrict__ xyz, const int* __restrict__ offset,
                                                     const int* __restrict__ new_offset, float* __restrict__ tmp,
                                                     int* __restrict__ idx, int bs_ref_mask, int bs_ref_bits, int lds_pts,
-                                                    const int* __restrict__ prev_tie, int* __restrict__ tie_out, int track_div)
+                                                    const int* __restrict__ prev_tie, int* __restrict__ tie_out, int track_div, int b)
 {
     constexpr int NW = BLOCK / 64;
     constexpr int NP = PPT / 2;                                            // two points per packed-fp32 register pair
@@ -145,22 +145,24 @@ __global__ __launch_bounds__(BLOCK) void fps_kernel(const float* __restrict__ xy
     // xyz copy for the winner lookup, three planes of lds_pts floats (12 B per point: two 5000-point clouds share a CU)
     float* spts = reinterpret_cast<float*>(smem + 2 * NW * sizeof(float4) + FPS_IDX_CAP * sizeof(int));
 
-    const int bid = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    // a workgroup takes clouds blockIdx.x, + gridDim.x, ...: the launcher bounds the grid in large batches so that the sampling
+    // chains occupy a bounded share of every CU's registers (see roitr_furthestsampling_ex)
+  for (int bid = blockIdx.x; bid < b; bid += gridDim.x) {
     const int start_n = bid == 0 ? 0 : offset[bid - 1];
     const int end_n = offset[bid];
     const int start_m = bid == 0 ? 0 : new_offset[bid - 1];
     const int end_m = new_offset[bid];
     const int n = end_n - start_n;
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
     const bool pts_in_lds = n <= lds_pts;
     if (prev_tie) {
         const int pt_ = prev_tie[bid];
         if (pt_ >= end_m - start_m) {                       // block-uniform: the picks are the cloud's first m points
             for (int j = tid; j < end_m - start_m; j += BLOCK) idx[start_m + j] = start_n + j;
             if (tie_out && tid == 0) tie_out[bid] = pt_;
-            return;
+            continue;
         }
     }
     // picks whose arg-max uniqueness is recorded: the next level keeps (m / track_div) of this level's m picks
@@ -266,6 +268,8 @@ __global__ __launch_bounds__(BLOCK) void fps_kernel(const float* __restrict__ xy
         const int koff = tid + j * BLOCK;
         if (koff < n) tmp[start_n + koff] = pt[j];
     }
+    __syncthreads();   // the next cloud reuses the slots, the pick list and the xyz copy
+  }
 }
 
 // Clouds beyond the register-resident limit: same key scheme, `tmp` streamed through L2.
@@ -352,13 +356,16 @@ extern "C" int roitr_furthestsampling_ex(int b, int n_max, const float* xyz, con
     // forward and the chip is empty -- 8 waves per cloud halve the per-lane work of an iteration (4.36 vs 4.48 ms per pair;
     // 16 waves: 5.03, the cross-wave stage grows faster than the lane work shrinks).  Same indices for every block size.
     static const int small_batch_block = getenv("ROITR_FPS_SMALL_BATCH_BLOCK") ? atoi(getenv("ROITR_FPS_SMALL_BATCH_BLOCK")) : 512;   // experiment switch
-    const int forced = b <= 16 && n_max <= 512 * 16 && small_batch_block == 512 ? 512 : 0;
+    static const int big_batch_block = getenv("ROITR_FPS_BLOCK") ? atoi(getenv("ROITR_FPS_BLOCK")) : 0;                               // experiment switch
+    static const int grid_cap = getenv("ROITR_FPS_GRID") ? atoi(getenv("ROITR_FPS_GRID")) : 0;                                        // experiment switch
+    const int forced = n_max <= 512 * 16 && ((b <= 16 && small_batch_block == 512) || (b > 16 && big_batch_block == 512)) ? 512 : 0;
+    const int nblk = grid_cap > 0 && b > grid_cap ? grid_cap : b;
 #define FPS_CASE(BLK, P)                                                                              \
     if (n_max <= (BLK) * (P) && (forced == 0 || forced == (BLK))) {                                   \
         ROITR_GRANT_LDS((fps_kernel<BLK, P>), fps_lds_bytes(BLK, FPS_PTS_CAP));                       \
         roitr_prof_begin(ROITR_PROF_FPS, -1.0, stream);                                               \
-        fps_kernel<BLK, P><<<b, BLK, fps_lds_bytes(BLK, lds_pts), stream>>>(xyz, offset, new_offset, tmp, idx, mask, bits, lds_pts, prev_tie, tie_out, \
-                                                                            track_div);                                             \
+        fps_kernel<BLK, P><<<nblk, BLK, fps_lds_bytes(BLK, lds_pts), stream>>>(xyz, offset, new_offset, tmp, idx, mask, bits, lds_pts, prev_tie, tie_out, \
+                                                                               track_div, b);                                       \
         roitr_prof_end(ROITR_PROF_FPS, stream);                                                       \
         ROITR_LAUNCH_CHECK();                                                                         \
         return ROITR_OK;                                                                              \

@@ -1188,7 +1188,7 @@ __global__ __launch_bounds__(256) void knn_prefilter_kernel(int m, int nsample, 
 #pragma unroll
                 for (int v = L - 1; v > 0; --v) {
                     const bool sh = d[v - 1] > dd, here = d[v] > dd;
-                    d[v] = sh ? d[v - 1] : (here ? dd : d[v]);
+                    d[v] = __builtin_amdgcn_fmed3f(dd, d[v - 1], d[v]);   // ascending list: the median IS the shifted / inserted / kept value
                     id[v] = sh ? id[v - 1] : (here ? ci : id[v]);
                 }
                 const bool h0 = d[0] > dd;
@@ -1243,7 +1243,7 @@ __global__ __launch_bounds__(256) void knn_lane_kernel(int m, int nsample, int b
 #pragma unroll
             for (int j = L - 1; j > 0; --j) {
                 const bool sh = d[j - 1] > dd, here = d[j] > dd;
-                d[j] = sh ? d[j - 1] : (here ? dd : d[j]);
+                d[j] = __builtin_amdgcn_fmed3f(dd, d[j - 1], d[j]);   // ascending list: the median IS the shifted / inserted / kept value
                 id[j] = sh ? id[j - 1] : (here ? ci : id[j]);
             }
             const bool h0 = d[0] > dd;
@@ -1355,7 +1355,7 @@ __global__ __launch_bounds__(64) void knn_lane_brute_kernel(int m, int nsample, 
 #pragma unroll
             for (int j = L - 1; j > 0; --j) {
                 const bool sh = d[j - 1] > dd, here = d[j] > dd;
-                d[j] = sh ? d[j - 1] : (here ? dd : d[j]);
+                d[j] = __builtin_amdgcn_fmed3f(dd, d[j - 1], d[j]);   // ascending list: the median IS the shifted / inserted / kept value
                 id[j] = sh ? id[j - 1] : (here ? ci : id[j]);
             }
             const bool h0 = d[0] > dd;
