@@ -59,6 +59,7 @@ __device__ __forceinline__ void load8(const float* __restrict__ p, int k, int K,
 // keeps every use of the prefetched registers behind it, so nothing forces a vmcnt wait between issuing the
 // prefetch and the MFMAs.  The generic variant keeps bounds-checked scalar tails.
 constexpr int ZERO_ROW_LEN = 2048;
+constexpr int GEMM_SMALL_MAX_TILES = 512;  // 64 x 64 tiles below which gemm_small_kernel (32 x 32 tiles, v_mfma_f32_16x16x4_f32) takes the launch
 constexpr int GEMM_IL_MIN_TILES = 1024;   // below: a few tiles per CU, the one accumulator chain of a wave is the critical path (one-pair-per-call launches: <= 628 tiles)
 __device__ __attribute__((aligned(16))) float g_zero_row[ZERO_ROW_LEN];
 
@@ -414,6 +415,112 @@ __global__ __launch_bounds__(256) void gemm_kernel(RoitrGemm g, int nx, int ny, 
 }
 
 
+// ---------------------------------------------------------------- small grids: 32 x 32 tiles of v_mfma_f32_16x16x4_f32
+// The launches of a one-pair (or few-pair) call have a few dozen 64 x 64 tiles for 1024 SIMDs: what bounds them is the ONE
+// accumulator chain of a wave -- K / 2 dependent v_mfma_f32_32x32x2_f32 at 64 cycles each (3.4 us at K = 256) -- not the matrix
+// pipe's throughput.  v_mfma_f32_16x16x4_f32 sums 4 k per instruction in 32 cycles: the same FLOP rate, a quarter of the chain
+// for a quarter of the tile.  This kernel gives every wave a 16 x 16 tile (block = 32 x 32, four waves), i.e. spreads the same work
+// over 4x the waves, each with a 4x shorter chain.  Both instructions are exact fp32 FMA chains in ascending k order
+// (scripts/micro/mfma_korder.hip: bit-identical to a scalar fmaf loop, and therefore to each other), so a row's result does not
+// depend on which kernel its launch was given (the k order inside a slab is gemm_kernel's, see `ks`):
+// test_gemm_rows_do_not_depend_on_the_row_count covers grids on both sides of the switch.  Same operand options as gemm_kernel<FAST = true, TN = 1, LN = false>; LDS image row-major [32][36] per operand, a
+// lane (i = lane & 15, g = lane >> 4) reads element k = 4 s + g of its row for step s (16 single-dword reads per 32-k slab, all
+// before the 8 MFMAs of the slab).
+constexpr int SM = 32, SLD = 36;
+typedef float f32x4s __attribute__((ext_vector_type(4)));
+template <bool HA2>
+__global__ __launch_bounds__(256) void gemm_small_kernel(RoitrGemm g, int nx, int ny, int T)
+{
+    __shared__ __attribute__((aligned(16))) float As[SM * SLD];
+    __shared__ __attribute__((aligned(16))) float Bs[SM * SLD];
+    const int tile = xcd_block_id(T);
+    if (tile >= T) return;
+    const int bz = tile / (nx * ny);
+    const int rem = tile - bz * nx * ny;
+    const int by_ = rem / nx, bx_ = rem - by_ * nx;
+    const float* A = g.A + (size_t)bz * g.sA;
+    const float* A2 = g.A2 ? g.A2 + (size_t)bz * g.sA : nullptr;
+    const float* W = g.W + (size_t)bz * g.sW;
+    const float* bias = g.bias ? g.bias + (size_t)bz * g.sBias : nullptr;
+    float* C = g.C + (size_t)bz * g.sC;
+    const int* a_idx = g.a_idx ? g.a_idx + (size_t)bz * g.sAidx : nullptr;
+    const int* w_idx = g.w_idx ? g.w_idx + (size_t)bz * g.sWidx : nullptr;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = by_ * SM, n0 = bx_ * SM;
+    const int r = tid >> 3, kf = (tid & 7) * 4;
+    if (g.seg_off) {  // ragged batch: this batch's row segments of A and W
+        const int ia = g.seg_a0 + bz, iw = g.seg_w0 + bz;
+        const int a0 = ia == 0 ? 0 : g.seg_off[ia - 1], w0 = iw == 0 ? 0 : g.seg_off[iw - 1];
+        g.M = g.seg_off[ia] - a0; g.N = g.seg_off[iw] - w0;
+        A += (size_t)a0 * g.lda; W += (size_t)w0 * g.ldw;
+        if (A2) A2 += (size_t)a0 * g.lda;
+        if (m0 >= g.M || n0 >= g.N) return;  // block-uniform
+    }
+    const float* arow = g_zero_row; const float* arow2 = g_zero_row; const float* arowc = g_zero_row; const float* wrow = g_zero_row;
+    {
+        const int am = m0 + r;
+        if (am < g.M) {
+            const int src = a_idx ? a_idx[am] : am;
+            if (src >= 0 && (g.a_limit <= 0 || src < g.a_limit)) {
+                arow = A + (size_t)src * g.lda;
+                if (A2) arow2 = A2 + (size_t)src * g.lda;
+                if (g.A_cat) arowc = g.A_cat + (size_t)(g.a_cat_idx ? g.a_cat_idx[am] : src) * g.lda_cat;
+            }
+        }
+        const int wn_ = n0 + r;
+        if (wn_ < g.N) {
+            const int src = w_idx ? w_idx[wn_] : wn_;
+            if (src >= 0 && (g.w_limit <= 0 || src < g.w_limit)) wrow = W + (size_t)src * g.ldw;
+        }
+    }
+    f32x4s acc = {0.f, 0.f, 0.f, 0.f};
+    float4 av, wv, a2v = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto fetch = [&](int k) {   // k: slab start + kf; the K-concatenated part is slab-uniform (k_cat % 32 == 0)
+        const bool catp = g.A_cat && k >= g.k_cat;
+        av = *reinterpret_cast<const float4*>(catp ? arowc + (k - g.k_cat) : arow + k);
+        wv = *reinterpret_cast<const float4*>(wrow + k);
+        if (HA2) a2v = *reinterpret_cast<const float4*>(catp ? g_zero_row + (k & 31) : arow2 + k);   // the addend covers the A part only
+    };
+    fetch(kf);
+    const int i = lane & 15, gq = lane >> 4;
+    const float* ar = As + (wm * 16 + i) * SLD + gq;
+    const float* br = Bs + (wn * 16 + i) * SLD + gq;
+    // gemm_kernel's summation order inside a 32-k slab is the order of ITS LDS image, whose stager puts global k 4j..4j+3 and
+    // 16+4j..16+4j+3 into slots 8j..8j+7 (two fully used 64-byte segments per row); same slots here, or the two kernels round differently
+    const int ks = (tid & 7) < 4 ? (tid & 7) * 8 : ((tid & 7) - 4) * 8 + 4;
+    float4* aw = reinterpret_cast<float4*>(As + r * SLD + ks);
+    float4* bw = reinterpret_cast<float4*>(Bs + r * SLD + ks);
+    for (int k0 = 0; k0 < g.K; k0 += BK) {
+        __syncthreads();
+        if (HA2) { av.x += a2v.x; av.y += a2v.y; av.z += a2v.z; av.w += a2v.w; }
+        *aw = av; *bw = wv;
+        __syncthreads();
+        if (k0 + BK < g.K) fetch(k0 + BK + kf);
+        float af[8], bf[8];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) { af[s] = ar[4 * s]; bf[s] = br[4 * s]; }
+        __builtin_amdgcn_sched_barrier(0);   // one LDS round trip per slab: hipcc otherwise sinks the reads between the MFMAs, four waits per slab
+#pragma unroll
+        for (int s = 0; s < 8; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[s], bf[s], acc, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);   // consumers of the prefetched registers stay below the MFMAs
+    }
+    // 16x16 C/D map: col = lane & 15, row = 4 (lane >> 4) + reg
+    const int col = n0 + wn * 16 + i;
+    if (col < g.N) {
+        const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int row = m0 + wm * 16 + 4 * gq + q;
+            if (row < g.M) {
+                float x = acc[q] * g.alpha + bv;
+                if (g.relu) x = fmaxf(x, 0.f);
+                C[(size_t)row * g.ldc + col] = x;
+            }
+        }
+    }
+}
+
 }  // namespace
 
 namespace {
@@ -492,6 +599,13 @@ extern "C" int roitr_gemm(const RoitrGemm* g, hipStream_t stream)
     if (shapes) { hipEventCreate(&e0); hipEventCreate(&e1); hipEventRecord(e0, stream); }
     const bool a2 = g->A2 != nullptr;
     const bool il = T >= GEMM_IL_MIN_TILES;   // staging loads spread over the MFMA stream (see the kernel): large grids only
+    static const int small_max = getenv("ROITR_GEMM_SMALL_MAX") ? atoi(getenv("ROITR_GEMM_SMALL_MAX")) : GEMM_SMALL_MAX_TILES;   // experiment switch
+    if (fast && !g->ln_gamma && T < small_max) {   // a fraction of a tile per SIMD: 32 x 32 tiles with 4x shorter accumulator chains
+        const int sx = div_up(g->N, SM), sy = div_up(g->M, SM);
+        const int ST = sx * sy * g->batch;
+        if (a2) gemm_small_kernel<true><<<xcd_grid(ST), 256, 0, stream>>>(*g, sx, sy, ST);
+        else gemm_small_kernel<false><<<xcd_grid(ST), 256, 0, stream>>>(*g, sx, sy, ST);
+    } else
 #define GEMM_LAUNCH(F, TN_, LN_) \
     do { \
         if (a2 && il) gemm_kernel<F, TN_, LN_, true, true><<<grid, 256, 0, stream>>>(*g, nx, ny, T); \

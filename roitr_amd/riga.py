@@ -213,6 +213,7 @@ class RIGA_v2(nn.Module):
         self.inputs_resident = False
         self._pack_stream = None
         self._engine_sig = None
+        self._holders = []
 
     # ---------------------------------------------------------------- engine plumbing
     def _make_engine(self):
@@ -243,20 +244,25 @@ class RIGA_v2(nn.Module):
         lib = L.lib()
         if self._engine is None:
             self._engine = self._make_engine()
-        sig = []
         for k, v in self.state_dict(keep_vars=True).items():
             if not v.is_cuda:
                 raise L.RoitrError(f"parameter {k} is not on a ROCm device: call model.cuda() (no CPU fallback)")
             if v.dtype != torch.float32 or not v.is_contiguous():
                 raise L.RoitrError(f"parameter {k} must be contiguous float32")
             L.check(lib.roitr_engine_set_param(self._engine, k.encode(), L.ptr(v), ctypes.c_long(v.numel())), "set_param")
-            sig.append((v.data_ptr(), v._version))
         L.check(lib.roitr_engine_finalize(self._engine, L.stream_ptr()), "engine_finalize")
-        self._engine_sig = sig
+        self._holders = list(self.modules())       # the holder tree is fixed after construction; its tensors may be replaced or updated
+        self._engine_sig = self._weights_signature()
+
+    def _weights_signature(self):
+        """(address, version) of every parameter / buffer, read through the holder modules' own dicts: in-place updates
+        (load_state_dict, an optimizer step), .cuda() / .to() and a replaced Parameter object all change it.  This runs in front
+        of every forward: walking state_dict() instead (prefix strings, hooks, 409 modules) cost ~0.5 ms of the 2.3 ms a
+        one-pair call takes on the host."""
+        return [(t.data_ptr(), t._version) for m in self._holders for d in (m._parameters, m._buffers) for t in d.values() if t is not None]
 
     def _ensure_engine(self):
-        sig = [(v.data_ptr(), v._version) for v in self.state_dict(keep_vars=True).values()]
-        if self._engine is None or sig != self._engine_sig:
+        if self._engine is None or self._weights_signature() != self._engine_sig:
             self.sync_engine()
 
     def set_tap(self, name, tensor):

@@ -39,3 +39,30 @@ def test_closed_form_weights_are_stable():
     np.testing.assert_allclose(a[0, :3], closed_form_param("coarse_proj.weight", (256, 256))[0, :3])
     assert abs(float(a.mean())) < 1e-3 and 0.03 < float(a.std()) < 0.04
     assert closed_form_param("OT.alpha", ()).shape == ()
+
+
+def test_weight_signature_sees_every_kind_of_weight_change():
+    """RIGA_v2._weights_signature() decides in front of every forward whether the engine's registered pointers / derived
+    weights are stale (riga.py _ensure_engine).  It must cover every tensor of the state_dict and change on an in-place
+    update (load_state_dict / copy_), a moved storage (what .cuda() / .to() do: param.data replaced) and a replaced
+    Parameter object."""
+    import torch
+    from roitr_amd.config import test_config
+    from roitr_amd.riga import create_model
+    m = create_model(test_config("3DMatch"))
+    m._holders = list(m.modules())
+    sig0 = m._weights_signature()
+    assert len(sig0) == len(m.state_dict()) == 522
+    assert m._weights_signature() == sig0                       # stable while nothing changes
+    sd = m.state_dict()
+    k = "coarse_proj.weight"
+    sd[k].copy_(torch.zeros_like(sd[k]))                        # in place (load_state_dict does exactly this)
+    sig1 = m._weights_signature()
+    assert sig1 != sig0
+    m.coarse_proj.weight.data = torch.ones_like(m.coarse_proj.weight.data)   # new storage under the same Parameter
+    sig2 = m._weights_signature()
+    assert sig2 != sig1
+    m.coarse_proj.weight = torch.nn.Parameter(torch.zeros(256, 256))         # a new Parameter object
+    assert m._weights_signature() != sig2
+    m.load_state_dict(m.state_dict())                           # a full reload bumps every version
+    assert m._weights_signature() != sig2
