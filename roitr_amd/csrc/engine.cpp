@@ -18,6 +18,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <functional>
 #include <map>
 #include <string>
 #include <vector>
@@ -131,8 +132,8 @@ struct Engine {
     hipEvent_t pinned_ev[RING] = {nullptr, nullptr, nullptr, nullptr};
     int ring_pos = 0;
     hipStream_t side = nullptr;      // the geometry chain (FPS, grids, kNN + PPF of levels 2-4, 3-NN, embedding E, partition, GT outputs)
-    static constexpr int NEV = 10;   // [8]: the error-path join of roitr_engine_forward; [9]: descriptors copied on the geometry stream
-    hipEvent_t ev[NEV] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    static constexpr int NEV = 11;   // [8]: the error-path join of roitr_engine_forward; [9]: descriptors copied on the geometry stream; [10]: deferred side units
+    hipEvent_t ev[NEV] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     bool side_forked = false;        // the current forward has issued work on `side` that `st` has not joined yet
     std::string err;
     hipStream_t fin_stream = nullptr;   // stream of the running finalize (weight conversions are queued on it)
@@ -1042,6 +1043,9 @@ static int forward_body(void* h, const RoitrForwardIO* io, hipStream_t st)
     bool grid[4];
     const void* order[4] = {nullptr, nullptr, nullptr, nullptr};  // cell-order visiting order of each level's points
     float* xe[4];
+    std::function<int()> issue_geo, issue_tail;   // see the end of the side-stream section
+    static const int geo_after = getenv("ROITR_SIDE_GEO_AFTER") ? atoi(getenv("ROITR_SIDE_GEO_AFTER")) : -1;      // experiment switches
+    static const int tail_after = getenv("ROITR_SIDE_TAIL_AFTER") ? atoi(getenv("ROITR_SIDE_TAIL_AFTER")) : -1;
     const float* pts_out = io->points_out ? io->points_out : io->points_geom;
     float* node_xyz = io->node_xyz ? io->node_xyz : A.get<float>((size_t)T4 * 3);
     int* node_masks = io->node_masks ? io->node_masks : A.get<int>(T4);
@@ -1126,80 +1130,92 @@ static int forward_body(void* h, const RoitrForwardIO* io, hipStream_t st)
                                   ppf_td[l], nrm[l - 1], nrm[l], grid[l - 1] ? 1 : 0, mcap_prev, knn_ws[l - 1], sd));
             ROITR_HIP(hipEventRecord(E.ev[l], sd));
         }
-        // the embedding of the global transformer (positional_encoding.py:139-154): needs the level-4 coordinates only
-        CHK(roitr_geo_indices(T4, p[3], D.off[3], D.cloud_of_node, D.eoff, 0.2f, 15.0f, 3, V.nmax[3], d_idx, a_idx, sd));
-        if (E.geo_tab && roitr_geo_embed_table(etot, C4, 3, d_idx, a_idx, E.geo_tab, E.geo_tab_h, E.geo_tab_nd, E.geo_tab_na, E.geo_div,
-                                               E.proj_d.w, E.proj_d.b, E.proj_a.w, E.proj_a.b, Emb, e_h ? 1 : 0, sd) != ROITR_OK)
-            E.geo_tab = nullptr;   // e.g. a device that does not grant the table's LDS: this engine serves the GEMM form from now on
-        if (E.geo_tab) {}
-        else if (e_h)
-            CHK(roitr_geo_embed_bf16_out(etot, C4, 3, d_idx, a_idx, E.geo_div, E.proj_d.wb, E.proj_d.b, E.proj_a.wb, E.proj_a.b,
-                                         reinterpret_cast<unsigned short*>(Emb), sd));
-        else if (E.cfg.operand_dtype == 1 && E.proj_d.wb && E.proj_a.wb)
-            CHK(roitr_geo_embed_bf16(etot, C4, 3, d_idx, a_idx, E.geo_div, E.proj_d.wb, E.proj_d.b, E.proj_a.wb, E.proj_a.b, Emb, sd));
-        else
-            CHK(roitr_geo_embed(etot, C4, 3, d_idx, a_idx, E.geo_div, E.proj_d.w, E.proj_d.b, E.proj_a.w, E.proj_a.b, Emb, sd));
-        ROITR_HIP(hipEventRecord(E.ev[5], sd));
-        // the decoder's 3-NN (pointops.py:168-182 `interpolation`): level-l points among the level-(l+1) points
-        for (int l = 2; l >= 0; --l)
-            CHK(roitr_knnquery_ex(NC, V.T[l + 1], V.T[l], 3, p[l + 1], p[l], D.off[l + 1], D.off[l], i3[l], d3[l], nullptr, nullptr, nullptr,
-                                  nullptr, grid[l + 1] ? 1 : 0, V.T[l], knn_ws[l + 1], sd));
-        ROITR_HIP(hipEventRecord(E.ev[6], sd));
-        // node coordinates (model/model.py:233-235), point-to-node partition (lib/utils.py:428-471) and the ground-truth side
-        // outputs: coordinates, the FPS picks and the given transform only
-        {
-            int* c3 = A.get<int>(V.T[2]);
-            int* c4 = A.get<int>(T4);
-            int* p2n = A.get<int>(T1);
-            float* p2nd = A.get<float>(T1);
-            if (A.fail) { roitr_set_error("arena exhausted (partition)", __FILE__, __LINE__); return ROITR_ERR_ARG; }
-            CHK(roitr_compose_idx(V.T[2], down[1], down[2], c3, sd));  // level-3 nodes as level-1 rows
-            CHK(roitr_compose_idx(T4, c3, down[3], c4, sd));
-            CHK(roitr_gather_rows(T4, 3, pts_out, c4, 0, node_xyz, sd));
-            CHK(roitr_point_to_node_partition(NC, T1, T4, pts_out, D.off[0], node_xyz, D.off[3], D.cloud_of_node, LIM, p2n, p2nd, node_masks,
-                                              kidx, kmask, sd));
-        }
-        // ---------------- ground-truth side outputs (RIGA_v2.py:91-116), only when rot / trans are given
-        if (io->rot && io->trans && (io->gt_node_occ || io->gt_corr_idx)) {
-            const int Tp = T1 + NC;                  // padded rows
-            const int Ts = V.off[0][B - 1];          // source rows
-            const int Tsp = Ts + B, Ttp = Tp - Tsp;  // padded source / target rows
-            float* pad = A.get<float>((size_t)Tp * 3);
-            int* poff = A.get<int>((size_t)3 * B + 4);
-            float* d2p = A.get<float>(Tp);
-            void* ws_s = A.get<char>(roitr_knn_workspace_bytes(B, Tsp, Ttp));
-            void* ws_t = A.get<char>(roitr_knn_workspace_bytes(B, Ttp, Tsp));
-            if (A.fail) { roitr_set_error("arena exhausted (gt)", __FILE__, __LINE__); return ROITR_ERR_ARG; }
-            CHK(roitr_build_padded_clouds(B, T1, pts_out, D.off[0], io->rot, io->trans, pad, poff, sd));
-            const float* src_p = pad; const float* tgt_p = pad + (size_t)Tsp * 3;
-            const int* off_s = poff; const int* off_t = poff + 2 * B;
-            const int use_grid = (Tsp > GRID_MIN_POINTS * B) ? 1 : 0;
-            if (io->gt_node_occ) {
-                // kNN(1) of every padded target point among the transformed padded source points, and back (l.509-510)
-                if (use_grid) CHK(roitr_knn_build_grid(B, Tsp, Ttp, src_p, off_s, ws_s, sd));
-                const float occ_cap2 = E.cfg.occlusion_radius * E.cfg.occlusion_radius * 1.01f;   // only `distance < radius` is read
-                CHK(roitr_knn_within(B, Tsp, Ttp, src_p, tgt_p, off_s, off_t, occ_cap2, d2p + Tsp, use_grid, Ttp, ws_s, sd));
-                if (use_grid) CHK(roitr_knn_build_grid(B, Ttp, Tsp, tgt_p, off_t, ws_t, sd));
-                CHK(roitr_knn_within(B, Ttp, Tsp, tgt_p, src_p, off_t, off_s, occ_cap2, d2p, use_grid, Tsp, ws_t, sd));
-                CHK(roitr_node_occlusion_score(T4, LIM, D.cloud_of_node, D.off[0], kidx, kmask, node_masks, d2p, E.cfg.occlusion_radius,
-                                               io->gt_node_occ, sd));
+        // The embedding E and the chain's tail (3-NN, partition, ground-truth outputs) as two units that can be ENQUEUED later than
+        // the rest of the chain (ROITR_SIDE_GEO_AFTER / ROITR_SIDE_TAIL_AFTER = encoder level l: behind that level's feature work;
+        // default: here).  They are needed late (global transformer / decoder / matching), and what they run beside matters:
+        // geo_table_kernel holds 122 KB of LDS per CU, the tail's kernels take registers from the 227-VGPR block transformer of level 2.
+        issue_geo = [&]() -> int {
+            // the embedding of the global transformer (positional_encoding.py:139-154): needs the level-4 coordinates only
+            CHK(roitr_geo_indices(T4, p[3], D.off[3], D.cloud_of_node, D.eoff, 0.2f, 15.0f, 3, V.nmax[3], d_idx, a_idx, sd));
+            if (E.geo_tab && roitr_geo_embed_table(etot, C4, 3, d_idx, a_idx, E.geo_tab, E.geo_tab_h, E.geo_tab_nd, E.geo_tab_na, E.geo_div,
+                                                   E.proj_d.w, E.proj_d.b, E.proj_a.w, E.proj_a.b, Emb, e_h ? 1 : 0, sd) != ROITR_OK)
+                E.geo_tab = nullptr;   // e.g. a device that does not grant the table's LDS: this engine serves the GEMM form from now on
+            if (E.geo_tab) {}
+            else if (e_h)
+                CHK(roitr_geo_embed_bf16_out(etot, C4, 3, d_idx, a_idx, E.geo_div, E.proj_d.wb, E.proj_d.b, E.proj_a.wb, E.proj_a.b,
+                                             reinterpret_cast<unsigned short*>(Emb), sd));
+            else if (E.cfg.operand_dtype == 1 && E.proj_d.wb && E.proj_a.wb)
+                CHK(roitr_geo_embed_bf16(etot, C4, 3, d_idx, a_idx, E.geo_div, E.proj_d.wb, E.proj_d.b, E.proj_a.wb, E.proj_a.b, Emb, sd));
+            else
+                CHK(roitr_geo_embed(etot, C4, 3, d_idx, a_idx, E.geo_div, E.proj_d.w, E.proj_d.b, E.proj_a.w, E.proj_a.b, Emb, sd));
+            ROITR_HIP(hipEventRecord(E.ev[5], sd));
+            return ROITR_OK;
+        };
+        issue_tail = [&]() -> int {
+            // the decoder's 3-NN (pointops.py:168-182 `interpolation`): level-l points among the level-(l+1) points
+            for (int l = 2; l >= 0; --l)
+                CHK(roitr_knnquery_ex(NC, V.T[l + 1], V.T[l], 3, p[l + 1], p[l], D.off[l + 1], D.off[l], i3[l], d3[l], nullptr, nullptr, nullptr,
+                                      nullptr, grid[l + 1] ? 1 : 0, V.T[l], knn_ws[l + 1], sd));
+            ROITR_HIP(hipEventRecord(E.ev[6], sd));
+            // node coordinates (model/model.py:233-235), point-to-node partition (lib/utils.py:428-471) and the ground-truth side
+            // outputs: coordinates, the FPS picks and the given transform only
+            {
+                int* c3 = A.get<int>(V.T[2]);
+                int* c4 = A.get<int>(T4);
+                int* p2n = A.get<int>(T1);
+                float* p2nd = A.get<float>(T1);
+                if (A.fail) { roitr_set_error("arena exhausted (partition)", __FILE__, __LINE__); return ROITR_ERR_ARG; }
+                CHK(roitr_compose_idx(V.T[2], down[1], down[2], c3, sd));  // level-3 nodes as level-1 rows
+                CHK(roitr_compose_idx(T4, c3, down[3], c4, sd));
+                CHK(roitr_gather_rows(T4, 3, pts_out, c4, 0, node_xyz, sd));
+                CHK(roitr_point_to_node_partition(NC, T1, T4, pts_out, D.off[0], node_xyz, D.off[3], D.cloud_of_node, LIM, p2n, p2nd, node_masks,
+                                                  kidx, kmask, sd));
             }
-            if (io->gt_corr_idx && io->gt_corr_overlaps && io->gt_corr_count) {
-                const long ms = (long)V.nmax[3] * V.nmax[3];
-                float* om = A.get<float>((size_t)B * ms);
-                float* nt_ = A.get<float>((size_t)T4 * 3);
-                float* nr_ = A.get<float>(T4);
+            // ---------------- ground-truth side outputs (RIGA_v2.py:91-116), only when rot / trans are given
+            if (io->rot && io->trans && (io->gt_node_occ || io->gt_corr_idx)) {
+                const int Tp = T1 + NC;                  // padded rows
+                const int Ts = V.off[0][B - 1];          // source rows
+                const int Tsp = Ts + B, Ttp = Tp - Tsp;  // padded source / target rows
+                float* pad = A.get<float>((size_t)Tp * 3);
+                int* poff = A.get<int>((size_t)3 * B + 4);
+                float* d2p = A.get<float>(Tp);
+                void* ws_s = A.get<char>(roitr_knn_workspace_bytes(B, Tsp, Ttp));
+                void* ws_t = A.get<char>(roitr_knn_workspace_bytes(B, Ttp, Tsp));
                 if (A.fail) { roitr_set_error("arena exhausted (gt)", __FILE__, __LINE__); return ROITR_ERR_ARG; }
-                RoitrNodeCorr nc; memset(&nc, 0, sizeof(nc));
-                nc.pairs = B; nc.limit = LIM; nc.max_nodes = V.nmax[3]; nc.pos_radius = E.cfg.matching_radius;
-                nc.nodes = node_xyz; nc.node_offset = D.off[3]; nc.node_masks = node_masks; nc.points = pts_out; nc.pt_offset = D.off[0];
-                nc.knn_idx = kidx; nc.knn_mask = kmask; nc.rot = io->rot; nc.trans = io->trans; nc.overlap = om; nc.mat_stride = ms;
-                nc.out_idx = io->gt_corr_idx; nc.out_overlap = io->gt_corr_overlaps; nc.out_count = io->gt_corr_count;
-                nc.n_nodes = T4; nc.nodes_t = nt_; nc.radius = nr_;
-                CHK(roitr_node_correspondences(&nc, sd));
+                CHK(roitr_build_padded_clouds(B, T1, pts_out, D.off[0], io->rot, io->trans, pad, poff, sd));
+                const float* src_p = pad; const float* tgt_p = pad + (size_t)Tsp * 3;
+                const int* off_s = poff; const int* off_t = poff + 2 * B;
+                const int use_grid = (Tsp > GRID_MIN_POINTS * B) ? 1 : 0;
+                if (io->gt_node_occ) {
+                    // kNN(1) of every padded target point among the transformed padded source points, and back (l.509-510)
+                    if (use_grid) CHK(roitr_knn_build_grid(B, Tsp, Ttp, src_p, off_s, ws_s, sd));
+                    const float occ_cap2 = E.cfg.occlusion_radius * E.cfg.occlusion_radius * 1.01f;   // only `distance < radius` is read
+                    CHK(roitr_knn_within(B, Tsp, Ttp, src_p, tgt_p, off_s, off_t, occ_cap2, d2p + Tsp, use_grid, Ttp, ws_s, sd));
+                    if (use_grid) CHK(roitr_knn_build_grid(B, Ttp, Tsp, tgt_p, off_t, ws_t, sd));
+                    CHK(roitr_knn_within(B, Ttp, Tsp, tgt_p, src_p, off_t, off_s, occ_cap2, d2p, use_grid, Tsp, ws_t, sd));
+                    CHK(roitr_node_occlusion_score(T4, LIM, D.cloud_of_node, D.off[0], kidx, kmask, node_masks, d2p, E.cfg.occlusion_radius,
+                                                   io->gt_node_occ, sd));
+                }
+                if (io->gt_corr_idx && io->gt_corr_overlaps && io->gt_corr_count) {
+                    const long ms = (long)V.nmax[3] * V.nmax[3];
+                    float* om = A.get<float>((size_t)B * ms);
+                    float* nt_ = A.get<float>((size_t)T4 * 3);
+                    float* nr_ = A.get<float>(T4);
+                    if (A.fail) { roitr_set_error("arena exhausted (gt)", __FILE__, __LINE__); return ROITR_ERR_ARG; }
+                    RoitrNodeCorr nc; memset(&nc, 0, sizeof(nc));
+                    nc.pairs = B; nc.limit = LIM; nc.max_nodes = V.nmax[3]; nc.pos_radius = E.cfg.matching_radius;
+                    nc.nodes = node_xyz; nc.node_offset = D.off[3]; nc.node_masks = node_masks; nc.points = pts_out; nc.pt_offset = D.off[0];
+                    nc.knn_idx = kidx; nc.knn_mask = kmask; nc.rot = io->rot; nc.trans = io->trans; nc.overlap = om; nc.mat_stride = ms;
+                    nc.out_idx = io->gt_corr_idx; nc.out_overlap = io->gt_corr_overlaps; nc.out_count = io->gt_corr_count;
+                    nc.n_nodes = T4; nc.nodes_t = nt_; nc.radius = nr_;
+                    CHK(roitr_node_correspondences(&nc, sd));
+                }
             }
-        }
-        ROITR_HIP(hipEventRecord(E.ev[7], sd));
+            ROITR_HIP(hipEventRecord(E.ev[7], sd));
+            return ROITR_OK;
+        };
+        if (geo_after < 0) CHK(issue_geo());
+        if (tail_after < 0) CHK(issue_tail());
     }
     roitr_prof_begin(ROITR_PROF_PH_ENC, 0.0, st);
     {
@@ -1241,6 +1257,12 @@ static int forward_body(void* h, const RoitrForwardIO* io, hipStream_t st)
                 float* t = cur; cur = nxt; nxt = t;
             }
             xe[l] = cur; xin = cur;
+            if (l == geo_after || l == tail_after) {   // deferred side-stream units: enqueued behind this level's feature work
+                ROITR_HIP(hipEventRecord(E.ev[10], st));
+                ROITR_HIP(hipStreamWaitEvent(sd, E.ev[10], 0));
+                if (l == geo_after) CHK(issue_geo());
+                if (l == tail_after) CHK(issue_tail());
+            }
         }
     }
     if (A.fail) { roitr_set_error("arena exhausted (encoder)", __FILE__, __LINE__); return ROITR_ERR_ARG; }

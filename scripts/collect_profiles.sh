@@ -4,7 +4,8 @@
 # 1) rocprofv3 --kernel-trace --stats (csv) of the default bench,
 # 2) two separate --pmc passes (FETCH_SIZE, WRITE_SIZE; kernel-trace only) of the default bench -> profiles/pmc_traffic.json,
 # 3) bench.py JSON lines (config 2 default, one pair per step, config 3, config 4 bf16 / f32, the driver's command),
-# 4) bench.py --config 5 (kNN(64) + PPF stress) + its SQ counter pass (scripts/knn_config5_sq.sh) + the SQ pass of the forward.
+# 4) bench.py --config 5 (kNN(64) + PPF stress) + its SQ counter pass (scripts/knn_config5_sq.sh) + the SQ pass of the forward,
+# 5) the batch-size curve (scripts/batch_sweep.sh) and the one-pair device timeline (scripts/b1_timeline.sh).
 set -u
 tag=${1:-r02}
 export TMPDIR=/tmp
@@ -42,4 +43,6 @@ bash scripts/knn_config5_sq.sh $out/knn5sq > $out/${tag}_knn_config5_sq.txt 2>&1
 cp $out/knn5sq/sq_knn_config5.json $out/sq_knn_config5.json
 bash scripts/sq_pass.sh $out/sq > $out/${tag}_sq_pass.txt 2>&1
 python scripts/sq_forward_json.py $out/sq/a $out/sq_forward.json > /dev/null 2>&1
+bash scripts/batch_sweep.sh $out/sweep > $out/${tag}_batch_sweep.txt 2>&1
+bash scripts/b1_timeline.sh $out/b1 > $out/${tag}_b1_timeline.txt 2>&1
 for f in $out/${tag}_bench*.json; do echo $f; cut -c1-400 $f; done
