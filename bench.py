@@ -521,12 +521,17 @@ def attach_traffic(roofs, B, config):
                 roof["valu_issue_per_kernel"] = {n: v["valu_issue_frac"] for n, v in sq.get("kernels", {}).items() if n.startswith("knn_")}
                 roof["valu_issue_source"] = "profiles/sq_forward.json (" + sq.get("definition", "") + ")"
             continue
-        k = pmc.get("kernels", {}).get(name)
-        if k:
-            roof["traffic"] = k["hbm_bytes_per_launch"]
+        # the instrumented class `gemm_kernel` spans both kernels of csrc/gemm.hip (64 x 64 tiles and the small-grid gemm_small_kernel):
+        # launch-weighted mean over the two, like `achieved` and `algorithmic_bytes_per_launch`
+        names = ("gemm_kernel", "gemm_small_kernel") if name == "gemm_kernel" else (name,)
+        ks = [pmc.get("kernels", {}).get(n) for n in names]
+        ks = [k for k in ks if k]
+        n = sum(k["launches"] for k in ks)
+        if n:
+            roof["traffic"] = round(sum(k["hbm_bytes_per_launch"] * k["launches"] for k in ks) / n)
             roof["traffic_source"] = src
             if roof.get("algorithmic_bytes_per_launch"):
-                roof["traffic_over_algorithmic"] = round(k["hbm_bytes_per_launch"] / roof["algorithmic_bytes_per_launch"], 3)
+                roof["traffic_over_algorithmic"] = round(roof["traffic"] / roof["algorithmic_bytes_per_launch"], 3)
     return pmc
 
 
