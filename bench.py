@@ -251,15 +251,17 @@ def forward_bench(args, rank, world, distributed):
         gc.enable()
 
         # ---- the same steps once more with the HIP-event instrumentation on (not part of `value`)
-        prof, prof_steps = {}, 0
+        prof, prof_steps, ot_counts = {}, 0, [0, 0, 0]
         if not args.no_profile_pass:
             prof_steps = args.steps
             gc.disable()
             model.profile_reset()
+            ot_counts = ot_stats(enable=1)      # data-dependent work of the optimal-transport stage, counted over this pass only
             benchloop.run_steps(model, batch, B, args.warmup, prof_steps, rank, world, False, spp)
             torch.cuda.synchronize()
             gc.enable()
             prof = model.profile_read(kernels_only=False)
+            ot_counts = ot_stats(enable=0)
 
     # the reference's own loop feeds ONE pair per forward (DataLoader batch_size 1, lib/tester.py:24-53): report that mode
     # too (rank 0, outside the timed region above), so a batched headline can be read against it
@@ -337,6 +339,11 @@ def forward_bench(args, rank, world, distributed):
             out["whole_forward"] = whole_forward(prof, prof_steps, dtype, out["ms_per_step"], pmc)
             out["kernel_ms_per_step"] = {k: round(v["ms"] / prof_steps, 4) for k, v in prof.items() if k != "geo_embed_reference_flops"}
             out["profile_pass"] = {"steps": prof_steps, "note": "the timed steps repeated with HIP events on; `value` is timed with them off"}
+            live, skipped, logdom = ot_counts
+            # what the data-dependent tail of the forward actually did: patches that went through Sinkhorn, the share of
+            # their 100 iterations skipped by the bit-exact fixed-point exit, patches the exponential form handed to the log-domain kernel
+            out["optimal_transport"] = {"live_patches_per_step": round(live / prof_steps, 1), "log_domain_patches_per_step": round(logdom / prof_steps, 1),
+                                        "sinkhorn_iterations_skipped_frac": round(skipped / max(1.0, 100.0 * live), 4)}
         if single:
             out["single_pair_mode"] = single
         if world == 1 and not args.no_cpu_baseline:
@@ -411,6 +418,16 @@ def knn_stress(args, rank, world, distributed):
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline_knn(N, K, args.cpu_baseline_seconds)
     return out
+
+
+def ot_stats(enable):
+    """roitr_ot_stats: (live patches, Sinkhorn iterations skipped by the bit-exact fixed-point exit, patches served by the log-domain
+    kernel) since counting was switched on; then switches counting on (zeroed) or off."""
+    import ctypes
+    from roitr_amd import _lib as L
+    out = (ctypes.c_ulonglong * 3)()
+    L.check(L.lib().roitr_ot_stats(ctypes.c_int(enable), out), "ot_stats")
+    return [int(v) for v in out]
 
 
 def load_profile_json(name):

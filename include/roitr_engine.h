@@ -282,6 +282,10 @@ typedef struct RoitrOT {
     float* out;
 } RoitrOT;
 int roitr_optimal_transport(const RoitrOT* a, roitr_stream_t stream);
+/* Diagnostics of the data-dependent work of that stage (synchronous): reads out[0] = live patches, out[1] = Sinkhorn iterations skipped by
+ * the exact fixed-point exit, out[2] = patches served by the log-domain kernel, all since the last enable; then enable = 1 (re)starts
+ * counting from zero, 0 stops it, -1 leaves it.  out may be NULL. */
+int roitr_ot_stats(int enable, unsigned long long* out);
 
 /* model/modules.py:216-324 FineMatching (use_dustbin = False).  ot = the OT output; rows = tgt, cols = src.
  * Emits correspondences in (patch, row, col) order; offsets[patch] = first output slot of the patch. */

@@ -583,7 +583,7 @@ __device__ __forceinline__ float ot_lse_wave(float x, float extra)
     return mx + __logf(wave_sum(__expf(x - mx)) + __expf(extra - mx));
 }
 
-__global__ __launch_bounds__(64) void ot_log_kernel(RoitrOT a)
+__global__ __launch_bounds__(64) void ot_log_kernel(RoitrOT a, unsigned long long* stats)
 {
     __shared__ float T[64][65];
     const int patch = blockIdx.x;
@@ -595,6 +595,7 @@ __global__ __launch_bounds__(64) void ot_log_kernel(RoitrOT a)
         const float corner = out[64 * OTN + 64];
         if (corner == corner) return;   // ot_kernel served this patch
     }
+    if (stats && lane == 0) atomicAdd(stats + 2, 1ull);
     const float alpha = *a.alpha;
     const float NINF = -1e6f;
     const float* sc = a.scores + (size_t)patch * 64 * 64;
@@ -868,20 +869,54 @@ extern "C" int roitr_patch_gather(const RoitrPatch* a, hipStream_t stream)
     return ROITR_OK;
 }
 
+namespace {
+struct OtStats {
+    unsigned long long* d = nullptr;
+    bool on = false, print = false;
+    OtStats() { if (getenv("ROITR_OT_STATS")) { print = true; enable(true); } }
+    void enable(bool e)
+    {
+        if (e && !d) { if (hipMalloc(&d, 24) != hipSuccess) { d = nullptr; return; } (void)hipMemset(d, 0, 24); }
+        on = e && d;
+    }
+    ~OtStats()
+    {
+        if (d && print) {
+            unsigned long long h[3] = {0, 0, 0};
+            (void)hipMemcpy(h, d, 24, hipMemcpyDeviceToHost);
+            fprintf(stderr, "OTSTATS live_patches %llu skipped_iterations %llu log_domain_patches %llu\n", h[0], h[1], h[2]);
+        }
+    }
+};
+OtStats& ot_stats() { static OtStats st; return st; }   // first use, not library load: the constructor may touch the device
+}  // namespace
+
+/* Counters of the optimal-transport stage since the last reset (synchronous; diagnostics): enable = 1 switches counting on and
+ * zeroes the counters, 0 switches it off.  out[0] live patches, out[1] Sinkhorn iterations skipped by the fixed-point exit,
+ * out[2] patches served by the log-domain kernel. */
+extern "C" int roitr_ot_stats(int enable, unsigned long long* out)
+{
+    if (out) {
+        out[0] = out[1] = out[2] = 0;
+        if (ot_stats().d) { ROITR_HIP(hipDeviceSynchronize()); ROITR_HIP(hipMemcpy(out, ot_stats().d, 24, hipMemcpyDeviceToHost)); }
+    }
+    if (enable >= 0) {
+        ot_stats().enable(enable != 0);
+        if (ot_stats().d && enable) { ROITR_HIP(hipDeviceSynchronize()); ROITR_HIP(hipMemset(ot_stats().d, 0, 24)); }
+    }
+    return ROITR_OK;
+}
+
 extern "C" int roitr_optimal_transport(const RoitrOT* a, hipStream_t stream)
 {
     if (a->pairs <= 0) return ROITR_OK;
     if (a->limit != 64) return ROITR_ERR_UNSUPPORTED;
     roitr_prof_begin(ROITR_PROF_OT, (double)a->pairs * a->num_corr * (64.0 * 64 + 65.0 * 65) * 4.0, stream);
-    // debug (ROITR_OT_STATS=1): live patches and Sinkhorn iterations skipped by the exact fixed-point exit, printed at exit
-    struct Stats {
-        unsigned long long* d = nullptr;
-        Stats() { if (getenv("ROITR_OT_STATS")) { hipMalloc(&d, 16); hipMemset(d, 0, 16); } }
-        ~Stats() { if (d) { unsigned long long h[2]; hipMemcpy(h, d, 16, hipMemcpyDeviceToHost); fprintf(stderr, "OTSTATS live_patches %llu skipped_iterations %llu\n", h[0], h[1]); } }
-    };
-    static Stats stats;
-    ot_kernel<<<a->pairs * a->num_corr, 64, 0, stream>>>(*a, stats.d);
-    ot_log_kernel<<<a->pairs * a->num_corr, 64, 0, stream>>>(*a);   // the patches the exponential form declined; the others leave at once
+    // data-dependent work of this stage (roitr_ot_stats / ROITR_OT_STATS=1): live patches, Sinkhorn iterations skipped by the exact
+    // fixed-point exit, patches the exponential form handed to the log-domain kernel
+    unsigned long long* sd = ot_stats().on ? ot_stats().d : nullptr;
+    ot_kernel<<<a->pairs * a->num_corr, 64, 0, stream>>>(*a, sd);
+    ot_log_kernel<<<a->pairs * a->num_corr, 64, 0, stream>>>(*a, sd);   // the patches the exponential form declined; the others leave at once
     roitr_prof_end(ROITR_PROF_OT, stream);
     ROITR_LAUNCH_CHECK();
     return ROITR_OK;
