@@ -365,7 +365,7 @@ class RIGA_v2(nn.Module):
         inputs_resident (default: self.inputs_resident): the caller states that the tensors of `pairs` are complete -- no copy
         or kernel producing them is still pending on the current stream.  The inputs are then packed on a side stream and the
         engine starts this forward's first sampling level beside the previous forward instead of behind it
-        (RoitrForwardIO::inputs_ready): one pair per call 3.26 -> see DESIGN.md.  Same results."""
+        (RoitrForwardIO::inputs_ready; one pair per call with two calls in flight: 3.23 -> 2.33 ms per pair, DESIGN.md section 4).  Same results."""
         self._ensure_engine()
         if graph:
             return self._launch_graph(pairs, want_gt)
