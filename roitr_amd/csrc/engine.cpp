@@ -132,8 +132,8 @@ struct Engine {
     hipEvent_t pinned_ev[RING] = {nullptr, nullptr, nullptr, nullptr};
     int ring_pos = 0;
     hipStream_t side = nullptr;      // the geometry chain (FPS, grids, kNN + PPF of levels 2-4, 3-NN, embedding E, partition, GT outputs)
-    static constexpr int NEV = 11;   // [8]: the error-path join of roitr_engine_forward; [9]: descriptors copied on the geometry stream; [10]: deferred side units
-    hipEvent_t ev[NEV] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    static constexpr int NEV = 12;   // [8]: the error-path join of roitr_engine_forward; [9]: descriptors copied on the geometry stream; [10]: deferred side units; [11]: level-1 groups (ahead mode)
+    hipEvent_t ev[NEV] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     bool side_forked = false;        // the current forward has issued work on `side` that `st` has not joined yet
     std::string err;
     hipStream_t fin_stream = nullptr;   // stream of the running finalize (weight conversions are queued on it)
@@ -973,10 +973,16 @@ static int forward_body(void* h, const RoitrForwardIO* io, hipStream_t st)
     // at once, beside the previous forward; the rest of the geometry chain writes scratch of the shared arena and waits, as
     // before, for the point of `st` where this forward begins.
     const bool ahead = io->inputs_ready != nullptr && E.capture_pin == nullptr;
+    // ... and so does the level-1 grid + self kNN (+ PPF) the first transformer starts from: in the ahead mode it runs in front of the
+    // sampling level on the geometry stream, its workspace and its group / PPF arrays in the alternating arena too (the previous call's
+    // decoder still reads ITS level-1 groups) -- 3 ms per 512-pair step off the main stream's chain
+    static const bool knn0_ahead_on = !(getenv("ROITR_KNN0_AHEAD") && atoi(getenv("ROITR_KNN0_AHEAD")) == 0);   // experiment switch
+    const bool knn0_ahead = ahead && knn0_ahead_on;
     Arena& G = ahead ? E.garena[E.gpar] : E.arena;
     if (ahead) {
         size_t need = desc_bytes + (size_t)T1 * 4 + (size_t)2 * NC * 4 + 8192;
         for (int l = 1; l < 4; ++l) need += (size_t)V.T[l] * (4 + 12 + 12) + 1024;
+        if (knn0_ahead) need += roitr_knn_workspace_bytes(NC, V.T[0], T1) + (size_t)V.T[0] * E.nsample[0] * (4 + 16) + 4096;
         if (need > G.cap) {
             ROITR_HIP(hipStreamSynchronize(st));
             ROITR_HIP(hipStreamSynchronize(sd));
@@ -1077,15 +1083,15 @@ static int forward_body(void* h, const RoitrForwardIO* io, hipStream_t st)
             CHK(roitr_gather_rows(V.T[l], 3, nrm[l - 1], down[l], 0, (float*)nrm[l], sd));
             return ROITR_OK;
         };
-        if (ahead) CHK(sample_level(1));
         // every buffer the side stream writes is carved here, before the encoder's mark / release scopes
         for (int l = 0; l < 4; ++l) {
             const int K = E.nsample[l];
             const int mcap = l == 0 ? T1 : V.T[l - 1];
-            knn_ws[l] = A.get<char>(roitr_knn_workspace_bytes(NC, V.T[l], mcap));
+            Arena& GA = (l == 0 && knn0_ahead) ? G : A;
+            knn_ws[l] = GA.get<char>(roitr_knn_workspace_bytes(NC, V.T[l], mcap));
             grid[l] = V.T[l] > GRID_MIN_POINTS * NC;
-            g_self[l] = A.get<int>((size_t)V.T[l] * K);
-            ppf_self[l] = A.get<float>((size_t)V.T[l] * K * 4);
+            g_self[l] = GA.get<int>((size_t)V.T[l] * K);
+            ppf_self[l] = GA.get<float>((size_t)V.T[l] * K * 4);
             if (l > 0) {
                 g_td[l] = A.get<int>((size_t)V.T[l] * K);
                 ppf_td[l] = A.get<float>((size_t)V.T[l] * K * 4);
@@ -1097,19 +1103,27 @@ static int forward_body(void* h, const RoitrForwardIO* io, hipStream_t st)
         d_idx = A.get<float>(etot);
         a_idx = A.get<float>((size_t)etot * 3);
         Emb = A.get<float>((size_t)etot * C4);
-        if (A.fail) { roitr_set_error("arena exhausted (geometry)", __FILE__, __LINE__); return ROITR_ERR_ARG; }
+        if (A.fail || G.fail) { roitr_set_error("arena exhausted (geometry)", __FILE__, __LINE__); return ROITR_ERR_ARG; }
 
-        // ---- main stream: level-1 grid + self kNN (+ PPF)
+        // ---- level-1 grid + self kNN (+ PPF): on the main stream (the first transformer needs them at once), or -- ahead mode -- in
+        // front of everything else on the geometry stream, beside the previous call
+        hipStream_t s0 = knn0_ahead ? sd : st;
         if (grid[0]) {
             // 6 points per cell on average: at level 1 (k = 8) the sphere of one cell size then holds ~2.5 (k + 2) points, what
             // the prefilter kNN kernel's radius rule needs
-            CHK(roitr_knn_build_grid_ex(NC, V.T[0], T1, p[0], D.off[0], knn_ws[0], grid_occ(0), st));
+            CHK(roitr_knn_build_grid_ex(NC, V.T[0], T1, p[0], D.off[0], knn_ws[0], grid_occ(0), s0));
             order[0] = roitr_knn_sorted_points(NC, V.T[0], T1, knn_ws[0]);
         }
-        ROITR_HIP(hipEventRecord(E.ev[0], st));  // inputs + descriptors are in place
+        if (!knn0_ahead) ROITR_HIP(hipEventRecord(E.ev[0], st));  // inputs + descriptors are in place
         CHK(roitr_knnquery_ex(NC, V.T[0], V.T[0], E.nsample[0] + 1, p[0], p[0], D.off[0], D.off[0], nullptr, nullptr, g_self[0], ppf_self[0],
-                              nrm[0], nrm[0], grid[0] ? 1 : 0, T1, knn_ws[0], st));
-        ROITR_HIP(hipEventRecord(E.ev[4], st));  // the level-1 workspace (grid + retry list) is free for the TransitionDown query
+                              nrm[0], nrm[0], grid[0] ? 1 : 0, T1, knn_ws[0], s0));
+        if (knn0_ahead) {
+            ROITR_HIP(hipEventRecord(E.ev[11], sd));       // the level-1 groups and PPFs are in place
+            ROITR_HIP(hipStreamWaitEvent(st, E.ev[11], 0));
+            ROITR_HIP(hipEventRecord(E.ev[0], st));        // where this call begins on the main stream: the shared scratch is free from here
+        } else
+            ROITR_HIP(hipEventRecord(E.ev[4], st));  // the level-1 workspace (grid + retry list) is free for the TransitionDown query
+        if (ahead) CHK(sample_level(1));
 
         // ---- side stream
         ROITR_HIP(hipStreamWaitEvent(sd, E.ev[0], 0));
@@ -1124,7 +1138,7 @@ static int forward_body(void* h, const RoitrForwardIO* io, hipStream_t st)
             }
             CHK(roitr_knnquery_ex(NC, V.T[l], V.T[l], K + 1, p[l], p[l], D.off[l], D.off[l], nullptr, nullptr, g_self[l], ppf_self[l], nrm[l],
                                   nrm[l], grid[l] ? 1 : 0, V.T[l - 1], knn_ws[l], sd));
-            if (l == 1) ROITR_HIP(hipStreamWaitEvent(sd, E.ev[4], 0));
+            if (l == 1 && !knn0_ahead) ROITR_HIP(hipStreamWaitEvent(sd, E.ev[4], 0));   // (ahead mode: that query ran on this stream)
             const int mcap_prev = l - 1 == 0 ? T1 : V.T[l - 2];
             CHK(roitr_knnquery_ex(NC, V.T[l - 1], V.T[l], K + 1, p[l - 1], p[l], D.off[l - 1], D.off[l], nullptr, nullptr, g_td[l],
                                   ppf_td[l], nrm[l - 1], nrm[l], grid[l - 1] ? 1 : 0, mcap_prev, knn_ws[l - 1], sd));
