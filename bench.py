@@ -225,6 +225,7 @@ def forward_bench(args, rank, world, distributed):
         pool = [pair_to_device(make_pair(N, config=wl["seed_config"], pair_index=i, normals=normals, cloud=args.cloud)) for i in ids]
         torch.cuda.synchronize()                                   # the pool is resident: nothing pending on any stream
         model.inputs_resident = not args.no_sampling_ahead
+        model.weights_frozen = True                                # an inference loop: the weights were registered by build_model
 
     def batch(step):
         return [pool[(step * B + j) % len(pool)] for j in range(B)]

@@ -211,6 +211,7 @@ class RIGA_v2(nn.Module):
         # launch_batch default: True = the pairs handed to it are complete device tensors with nothing pending on the current
         # stream (a resident pool, a loader that synchronised its copies) -- see launch_batch(inputs_resident=...)
         self.inputs_resident = False
+        self.weights_frozen = False      # True: skip the per-forward "did a weight change" check (see _ensure_engine)
         self._pack_stream = None
         self._engine_sig = None
         self._holders = []
@@ -262,7 +263,9 @@ class RIGA_v2(nn.Module):
         return [(t.data_ptr(), t._version) for m in self._holders for d in (m._parameters, m._buffers) for t in d.values() if t is not None]
 
     def _ensure_engine(self):
-        if self._engine is None or self._weights_signature() != self._engine_sig:
+        # weights_frozen: the caller states that no parameter changes until it says so (an inference loop): the 0.3 ms signature walk in
+        # front of every forward is skipped -- it is a sixth of the host's time in a one-pair call; sync_engine() re-registers explicitly
+        if self._engine is None or (not self.weights_frozen and self._weights_signature() != self._engine_sig):
             self.sync_engine()
 
     def set_tap(self, name, tensor):

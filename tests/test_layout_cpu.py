@@ -66,3 +66,25 @@ def test_weight_signature_sees_every_kind_of_weight_change():
     assert m._weights_signature() != sig2
     m.load_state_dict(m.state_dict())                           # a full reload bumps every version
     assert m._weights_signature() != sig2
+
+
+def test_weights_frozen_skips_only_the_signature_walk():
+    """weights_frozen = True (inference loops, bench.py) must not hide a missing engine: _ensure_engine still synchronises when
+    there is no engine yet, and goes back to checking as soon as the flag is cleared."""
+    from roitr_amd.config import test_config
+    from roitr_amd.riga import create_model
+    m = create_model(test_config("3DMatch"))
+    calls = []
+    m.sync_engine = lambda: calls.append(1) or setattr(m, "_engine", object()) or setattr(m, "_engine_sig", m._weights_signature())
+    m._holders = list(m.modules())
+    m.weights_frozen = True
+    m._ensure_engine()                       # no engine yet: synchronises even when frozen
+    assert len(calls) == 1
+    import torch
+    with torch.no_grad():
+        m.coarse_proj.weight.add_(1.0)       # (an update through `.data` would not bump the version counter: invisible to any such check)
+    m._ensure_engine()                       # frozen: the change is the caller's responsibility
+    assert len(calls) == 1
+    m.weights_frozen = False
+    m._ensure_engine()                       # checking again: the stale registration is noticed
+    assert len(calls) == 2
