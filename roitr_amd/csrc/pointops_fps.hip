@@ -5,11 +5,13 @@
 //   * one workgroup per cloud, but the cloud's xyz AND its running min-distances live in VGPRs for
 //     the whole sampling run (PPT points per lane); HBM is touched once on entry and once on exit
 //     (algorithmic bytes 12n + 4m + 8n for the in/out `tmp`), never inside the m-iteration loop;
-//   * 4 waves per workgroup (one per SIMD) instead of 16: the per-iteration arg-max is a 64-bit
-//     key max -- 6 wave64 butterfly steps + one LDS slot per wave + ONE barrier per iteration
-//     (double-buffered slots), versus the reference's 10-step shared-memory tree with 11 barriers;
-//   * the winner's coordinates ride along with the wave winner through LDS, so the next
-//     iteration never goes back to memory for xyz[old].
+//   * 4 waves per workgroup (one per SIMD; 8 when a call has few clouds) instead of 16; the per-iteration arg-max is two chained
+//     32-bit maxima -- the largest distance, then the largest tie word among the points that attain it -- each a 6-step DPP reduction
+//     of ONE instruction per step, then one 16-byte LDS slot per wave, ONE barrier per iteration (double-buffered slots) and a 2- or 3-step
+//     DPP fold of the slots, versus the reference's 10-step shared-memory tree with 11 barriers;
+//   * two points share a register pair: the distance update is v_pk_add / v_pk_mul / v_pk_fma on both at once (round 4);
+//   * the winner's coordinates come from an LDS copy of the cloud (few clouds per call) or from L2 (large batches: the copy's 76 KB
+//     per cloud would starve the feature path's workgroups), never from a dependent HBM miss.
 //
 // Bit-exactness: the reference's result depends on its launch shape -- thread `tid` of a
 // `bs`-thread block (bs = opt_n_threads(n), cuda_utils.h:11-14) scans k = start+tid, +bs, ...
