@@ -977,7 +977,10 @@ static int forward_body(void* h, const RoitrForwardIO* io, hipStream_t st)
     // sampling level on the geometry stream, its workspace and its group / PPF arrays in the alternating arena too (the previous call's
     // decoder still reads ITS level-1 groups) -- 3 ms per 512-pair step off the main stream's chain
     static const bool knn0_ahead_on = !(getenv("ROITR_KNN0_AHEAD") && atoi(getenv("ROITR_KNN0_AHEAD")) == 0);   // experiment switch
-    const bool knn0_ahead = ahead && knn0_ahead_on;
+    // up to 128 pairs per call: a small batch is bound by the main stream's chain (one pair per call 2.01 -> 1.87 ms, 64 pairs 12.25 -> 12.04 ms);
+    // at 512 pairs the step is bound by the chip's total work and the move only shifts contention onto the GEMMs (5 843 / 5 886 vs 5 906 / 5 862
+    // pairs/s, gemm_kernel 37.7 -> 38.9 ms per step)
+    const bool knn0_ahead = ahead && knn0_ahead_on && B <= 128;
     Arena& G = ahead ? E.garena[E.gpar] : E.arena;
     if (ahead) {
         size_t need = desc_bytes + (size_t)T1 * 4 + (size_t)2 * NC * 4 + 8192;
