@@ -127,6 +127,9 @@ struct Engine {
     // the (stream-ordered, single) scratch arena: two small arenas used alternately
     Arena garena[2];
     int gpar = 0;
+    int cur_par = -1;                // parity arena the running forward uses (-1: none)
+    hipEvent_t gend[2] = {nullptr, nullptr};   // recorded on the main stream where the forward that used the arena ends
+    bool gend_rec[2] = {false, false};
     static constexpr int RING = 4;   // descriptor staging slots: the host may run RING forwards ahead
     char* pinned[RING] = {nullptr, nullptr, nullptr, nullptr}; size_t pinned_cap[RING] = {0, 0, 0, 0};
     hipEvent_t pinned_ev[RING] = {nullptr, nullptr, nullptr, nullptr};
@@ -654,6 +657,7 @@ extern "C" void roitr_engine_destroy(void* h)
     if (E->warena.base) (void)hipFree(E->warena.base);
     if (E->arena.base) (void)hipFree(E->arena.base);
     for (int i = 0; i < 2; ++i) if (E->garena[i].base) (void)hipFree(E->garena[i].base);
+    for (int i = 0; i < 2; ++i) if (E->gend[i]) (void)hipEventDestroy(E->gend[i]);
     for (auto& g : E->graphs) {
         if (g.exec) (void)hipGraphExecDestroy(g.exec);
         if (g.graph) (void)hipGraphDestroy(g.graph);
@@ -897,12 +901,18 @@ extern "C" int roitr_engine_forward(void* h, const RoitrForwardIO* io, hipStream
 {
     Engine& E = *(Engine*)h;
     E.side_forked = false;
+    E.cur_par = -1;
     const int rc = forward_body(h, io, st);
     if (rc != ROITR_OK && E.side_forked && E.side && E.ev[8]) {
         if (hipEventRecord(E.ev[8], E.side) == hipSuccess) (void)hipStreamWaitEvent(st, E.ev[8], 0);
         else (void)hipStreamSynchronize(E.side);
     }
     E.side_forked = false;
+    if (E.cur_par >= 0 && E.gend[E.cur_par]) {   // the alternating arena is free again where this call ends on the main stream
+        if (hipEventRecord(E.gend[E.cur_par], st) == hipSuccess) E.gend_rec[E.cur_par] = true;
+        else { (void)hipStreamSynchronize(st); E.gend_rec[E.cur_par] = false; }
+    }
+    E.cur_par = -1;
     return rc;
 }
 
@@ -981,11 +991,26 @@ static int forward_body(void* h, const RoitrForwardIO* io, hipStream_t st)
     // at 512 pairs the step is bound by the chip's total work and the move only shifts contention onto the GEMMs (5 843 / 5 886 vs 5 906 / 5 862
     // pairs/s, gemm_kernel 37.7 -> 38.9 ms per step)
     const bool knn0_ahead = ahead && knn0_ahead_on && B <= 128;
+    // ... and with it the WHOLE geometry chain (round 4, last step): for calls of up to 128 pairs every buffer the geometry stream writes lives in
+    // the alternating arena, so the chain of call s + 1 needs nothing from the main stream: it runs beside call s from the first kernel to
+    // the last and only waits for the call before that one (same arena) to have ended
+    const bool full_ahead = knn0_ahead;
     Arena& G = ahead ? E.garena[E.gpar] : E.arena;
     if (ahead) {
         size_t need = desc_bytes + (size_t)T1 * 4 + (size_t)2 * NC * 4 + 8192;
         for (int l = 1; l < 4; ++l) need += (size_t)V.T[l] * (4 + 12 + 12) + 1024;
         if (knn0_ahead) need += roitr_knn_workspace_bytes(NC, V.T[0], T1) + (size_t)V.T[0] * E.nsample[0] * (4 + 16) + 4096;
+        if (full_ahead) {   // everything carved from GA below (each allocation rounds up to 256 bytes)
+            for (int l = 1; l < 4; ++l)
+                need += roitr_knn_workspace_bytes(NC, V.T[l], V.T[l - 1]) + (size_t)V.T[l] * E.nsample[l] * (4 + 16) * 2 + 2048;
+            for (int l = 0; l < 3; ++l) need += (size_t)V.T[l] * 3 * 8 + 1024;
+            need += (size_t)etot * (4 + 12 + (size_t)C4 * 4) + 2048;                                   // d_idx, a_idx, E
+            need += (size_t)T4 * (3 * 4 + 4 + (size_t)LIM * 8) + 2048;                                   // node outputs the caller did not ask for
+            const size_t Tp = (size_t)T1 + NC;
+            need += (size_t)V.T[2] * 4 + (size_t)T4 * 4 + (size_t)T1 * 8 + 2048;                         // partition scratch
+            need += Tp * 16 + (size_t)B * 12 + 2 * roitr_knn_workspace_bytes(B, (int)Tp, (int)Tp) + 4096;   // ground-truth clouds + their kNN
+            need += (size_t)B * V.nmax[3] * V.nmax[3] * 4 + (size_t)T4 * 16 + 2048;                      // node correspondences
+        }
         if (need > G.cap) {
             ROITR_HIP(hipStreamSynchronize(st));
             ROITR_HIP(hipStreamSynchronize(sd));
@@ -995,6 +1020,11 @@ static int forward_body(void* h, const RoitrForwardIO* io, hipStream_t st)
             G.cap = need * 2;
         }
         G.off = 0; G.fail = false;
+        E.cur_par = E.gpar;
+        if (!E.gend[E.gpar]) ROITR_HIP(hipEventCreateWithFlags(&E.gend[E.gpar], hipEventDisableTiming));
+        // the call that used this arena before (two calls back) must have left the main stream: implied by `sd` waiting for ev[0] in the
+        // partial mode, the only ordering left in the full one
+        if (E.gend_rec[E.gpar]) ROITR_HIP(hipStreamWaitEvent(sd, E.gend[E.gpar], 0));
         E.gpar ^= 1;
         ROITR_HIP(hipStreamWaitEvent(sd, (hipEvent_t)io->inputs_ready, 0));
         E.side_forked = true;
@@ -1056,10 +1086,11 @@ static int forward_body(void* h, const RoitrForwardIO* io, hipStream_t st)
     static const int geo_after = getenv("ROITR_SIDE_GEO_AFTER") ? atoi(getenv("ROITR_SIDE_GEO_AFTER")) : -1;      // experiment switches
     static const int tail_after = getenv("ROITR_SIDE_TAIL_AFTER") ? atoi(getenv("ROITR_SIDE_TAIL_AFTER")) : -1;
     const float* pts_out = io->points_out ? io->points_out : io->points_geom;
-    float* node_xyz = io->node_xyz ? io->node_xyz : A.get<float>((size_t)T4 * 3);
-    int* node_masks = io->node_masks ? io->node_masks : A.get<int>(T4);
-    int* kidx = io->node_knn_idx ? io->node_knn_idx : A.get<int>((size_t)T4 * LIM);
-    int* kmask = io->node_knn_mask ? io->node_knn_mask : A.get<int>((size_t)T4 * LIM);
+    Arena& GF = full_ahead ? G : A;     // everything else the geometry stream writes
+    float* node_xyz = io->node_xyz ? io->node_xyz : GF.get<float>((size_t)T4 * 3);
+    int* node_masks = io->node_masks ? io->node_masks : GF.get<int>(T4);
+    int* kidx = io->node_knn_idx ? io->node_knn_idx : GF.get<int>((size_t)T4 * LIM);
+    int* kmask = io->node_knn_mask ? io->node_knn_mask : GF.get<int>((size_t)T4 * LIM);
     float* d_idx = nullptr; float* a_idx = nullptr; float* Emb = nullptr;
     // bf16 operand mode: E (an operand of the q~ . E and a' . E contractions of every self layer) is stored bf16 when the
     // attention kernel for this width reads it (C = 256 / 512, 4 heads, <= 512 superpoints)
@@ -1090,22 +1121,22 @@ static int forward_body(void* h, const RoitrForwardIO* io, hipStream_t st)
         for (int l = 0; l < 4; ++l) {
             const int K = E.nsample[l];
             const int mcap = l == 0 ? T1 : V.T[l - 1];
-            Arena& GA = (l == 0 && knn0_ahead) ? G : A;
+            Arena& GA = (l == 0 && knn0_ahead) ? G : GF;
             knn_ws[l] = GA.get<char>(roitr_knn_workspace_bytes(NC, V.T[l], mcap));
             grid[l] = V.T[l] > GRID_MIN_POINTS * NC;
             g_self[l] = GA.get<int>((size_t)V.T[l] * K);
             ppf_self[l] = GA.get<float>((size_t)V.T[l] * K * 4);
             if (l > 0) {
-                g_td[l] = A.get<int>((size_t)V.T[l] * K);
-                ppf_td[l] = A.get<float>((size_t)V.T[l] * K * 4);
+                g_td[l] = GF.get<int>((size_t)V.T[l] * K);
+                ppf_td[l] = GF.get<float>((size_t)V.T[l] * K * 4);
             } else {
                 g_td[0] = g_self[0]; ppf_td[0] = ppf_self[0];  // stride 1: the same kNN (model/model.py:75 vs :31)
             }
-            if (l < 3) { i3[l] = A.get<int>((size_t)V.T[l] * 3); d3[l] = A.get<float>((size_t)V.T[l] * 3); }
+            if (l < 3) { i3[l] = GF.get<int>((size_t)V.T[l] * 3); d3[l] = GF.get<float>((size_t)V.T[l] * 3); }
         }
-        d_idx = A.get<float>(etot);
-        a_idx = A.get<float>((size_t)etot * 3);
-        Emb = A.get<float>((size_t)etot * C4);
+        d_idx = GF.get<float>(etot);
+        a_idx = GF.get<float>((size_t)etot * 3);
+        Emb = GF.get<float>((size_t)etot * C4);
         if (A.fail || G.fail) { roitr_set_error("arena exhausted (geometry)", __FILE__, __LINE__); return ROITR_ERR_ARG; }
 
         // ---- level-1 grid + self kNN (+ PPF): on the main stream (the first transformer needs them at once), or -- ahead mode -- in
@@ -1129,7 +1160,7 @@ static int forward_body(void* h, const RoitrForwardIO* io, hipStream_t st)
         if (ahead) CHK(sample_level(1));
 
         // ---- side stream
-        ROITR_HIP(hipStreamWaitEvent(sd, E.ev[0], 0));
+        if (!full_ahead) ROITR_HIP(hipStreamWaitEvent(sd, E.ev[0], 0));   // (full mode: nothing below touches the shared arena)
         E.side_forked = true;
         for (int l = 1; l < 4; ++l) {
             const int K = E.nsample[l];
@@ -1177,11 +1208,11 @@ static int forward_body(void* h, const RoitrForwardIO* io, hipStream_t st)
             // node coordinates (model/model.py:233-235), point-to-node partition (lib/utils.py:428-471) and the ground-truth side
             // outputs: coordinates, the FPS picks and the given transform only
             {
-                int* c3 = A.get<int>(V.T[2]);
-                int* c4 = A.get<int>(T4);
-                int* p2n = A.get<int>(T1);
-                float* p2nd = A.get<float>(T1);
-                if (A.fail) { roitr_set_error("arena exhausted (partition)", __FILE__, __LINE__); return ROITR_ERR_ARG; }
+                int* c3 = GF.get<int>(V.T[2]);
+                int* c4 = GF.get<int>(T4);
+                int* p2n = GF.get<int>(T1);
+                float* p2nd = GF.get<float>(T1);
+                if (GF.fail) { roitr_set_error("arena exhausted (partition)", __FILE__, __LINE__); return ROITR_ERR_ARG; }
                 CHK(roitr_compose_idx(V.T[2], down[1], down[2], c3, sd));  // level-3 nodes as level-1 rows
                 CHK(roitr_compose_idx(T4, c3, down[3], c4, sd));
                 CHK(roitr_gather_rows(T4, 3, pts_out, c4, 0, node_xyz, sd));
@@ -1193,12 +1224,12 @@ static int forward_body(void* h, const RoitrForwardIO* io, hipStream_t st)
                 const int Tp = T1 + NC;                  // padded rows
                 const int Ts = V.off[0][B - 1];          // source rows
                 const int Tsp = Ts + B, Ttp = Tp - Tsp;  // padded source / target rows
-                float* pad = A.get<float>((size_t)Tp * 3);
-                int* poff = A.get<int>((size_t)3 * B + 4);
-                float* d2p = A.get<float>(Tp);
-                void* ws_s = A.get<char>(roitr_knn_workspace_bytes(B, Tsp, Ttp));
-                void* ws_t = A.get<char>(roitr_knn_workspace_bytes(B, Ttp, Tsp));
-                if (A.fail) { roitr_set_error("arena exhausted (gt)", __FILE__, __LINE__); return ROITR_ERR_ARG; }
+                float* pad = GF.get<float>((size_t)Tp * 3);
+                int* poff = GF.get<int>((size_t)3 * B + 4);
+                float* d2p = GF.get<float>(Tp);
+                void* ws_s = GF.get<char>(roitr_knn_workspace_bytes(B, Tsp, Ttp));
+                void* ws_t = GF.get<char>(roitr_knn_workspace_bytes(B, Ttp, Tsp));
+                if (GF.fail) { roitr_set_error("arena exhausted (gt)", __FILE__, __LINE__); return ROITR_ERR_ARG; }
                 CHK(roitr_build_padded_clouds(B, T1, pts_out, D.off[0], io->rot, io->trans, pad, poff, sd));
                 const float* src_p = pad; const float* tgt_p = pad + (size_t)Tsp * 3;
                 const int* off_s = poff; const int* off_t = poff + 2 * B;
@@ -1215,10 +1246,10 @@ static int forward_body(void* h, const RoitrForwardIO* io, hipStream_t st)
                 }
                 if (io->gt_corr_idx && io->gt_corr_overlaps && io->gt_corr_count) {
                     const long ms = (long)V.nmax[3] * V.nmax[3];
-                    float* om = A.get<float>((size_t)B * ms);
-                    float* nt_ = A.get<float>((size_t)T4 * 3);
-                    float* nr_ = A.get<float>(T4);
-                    if (A.fail) { roitr_set_error("arena exhausted (gt)", __FILE__, __LINE__); return ROITR_ERR_ARG; }
+                    float* om = GF.get<float>((size_t)B * ms);
+                    float* nt_ = GF.get<float>((size_t)T4 * 3);
+                    float* nr_ = GF.get<float>(T4);
+                    if (GF.fail) { roitr_set_error("arena exhausted (gt)", __FILE__, __LINE__); return ROITR_ERR_ARG; }
                     RoitrNodeCorr nc; memset(&nc, 0, sizeof(nc));
                     nc.pairs = B; nc.limit = LIM; nc.max_nodes = V.nmax[3]; nc.pos_radius = E.cfg.matching_radius;
                     nc.nodes = node_xyz; nc.node_offset = D.off[3]; nc.node_masks = node_masks; nc.points = pts_out; nc.pt_offset = D.off[0];
