@@ -388,9 +388,9 @@ typedef struct RoitrForwardIO {
     /* Optional hipEvent_t.  NULL: the inputs above are ordered on `stream` (whatever produced them was queued there before the call).
      * Non-NULL: the inputs are complete once this event has fired and `stream` carries no dependency on them -- the engine then
      * stages the descriptors and runs the first sampling level (the longest serial chain of a small-batch forward) on its geometry
-     * stream as soon as the event fires, BESIDE the previous forward still occupying `stream`, instead of behind it; everything that
-     * touches the engine's shared scratch still starts where this forward begins on `stream`.  Results are identical.  Ignored by
-     * roitr_engine_forward_graph. */
+     * stream as soon as the event fires, BESIDE the previous forward still occupying `stream`, instead of behind it (calls of up to 128
+     * pairs: the whole geometry chain, in scratch the engine alternates between calls); everything that touches the engine's shared
+     * scratch still starts where this forward begins on `stream`.  Results are identical.  Ignored by roitr_engine_forward_graph. */
     void* inputs_ready;
 } RoitrForwardIO;
 
