@@ -46,6 +46,54 @@ __device__ __forceinline__ float sqdist3(float ax, float ay, float az, float bx,
     return __fmaf_rn(dz, dz, __fmaf_rn(dy, dy, __fmul_rn(dx, dx)));
 }
 
+// Point-pair features (lib/utils.py:358-389 calc_ppf_gpu): [ |d|, angle(n1, d), angle(n2, d), angle(n1, n2) ], angles / pi with
+// angle(a, b) = atan2(|a x b|, a . b) in [0, pi].  One definition for every kernel that emits PPFs (the fused kNN kernels, ppf.hip):
+// a pair's features must not depend on which kernel served its query.  Round 5: the three atan2f (OCML: ~60 instructions each plus an
+// IEEE division by pi and correctly rounded square roots -- 248 VALU instructions per feature, the largest single item of the lane
+// kernels) are a first-quadrant reduction t = min / max (v_rcp_f32), a degree-8 polynomial in t^2 (Chebyshev fit of atan(t) / t on
+// [0, 1]: 1.1e-7 rad in fp32 Horner form) and two reflections; v_sqrt_f32 for the norms; 1 / pi as a factor.  Against float64:
+// <= 2.5e-7 on the angles / pi (tests/test_pointops_gpu.py, tolerance of the PPF tests: 2e-6).  atan2(0, +0) = 0 like torch (the dot
+// product starts from +0, so x is never -0); a zero vector gives 0.
+__device__ __forceinline__ float roitr_angle_over_pi(float y, float x)   // y = |a x b| >= 0, x = a . b
+{
+    const float ax = fabsf(x);
+    const float lo = fminf(ax, y), hi = fmaxf(ax, y);
+    float t = lo * __builtin_amdgcn_rcpf(hi);
+    t = lo > 0.f ? fminf(t, 1.0f) : 0.f;          // hi = 0 (both zero) or a flushed denormal: 0 * inf
+    const float s = t * t;
+    float p = 0.0028340641874819994f;
+    p = __fmaf_rn(p, s, -0.016005029901862144f);
+    p = __fmaf_rn(p, s, 0.042587608098983765f);
+    p = __fmaf_rn(p, s, -0.07495445758104324f);
+    p = __fmaf_rn(p, s, 0.10636754333972931f);
+    p = __fmaf_rn(p, s, -0.14202570915222168f);
+    p = __fmaf_rn(p, s, 0.19992484152317047f);
+    p = __fmaf_rn(p, s, -0.3333306610584259f);
+    p = __fmaf_rn(p, s, 1.0f);
+    p *= t;                                        // atan(t), t in [0, 1]
+    p = y > ax ? 1.57079632679489662f - p : p;     // first octant -> first quadrant
+    p = x < 0.f ? 3.14159265358979323846f - p : p; // second quadrant
+    return p * 0.318309886183790672f;
+}
+__device__ __forceinline__ float roitr_angle3(float ax, float ay, float az, float bx, float by, float bz)
+{
+    const float dt = 0.0f + ax * bx + ay * by + az * bz;  // torch.sum starts from +0: keeps atan2(0, +0) = 0
+    const float cx = ay * bz - az * by, cy = az * bx - ax * bz, cz = ax * by - ay * bx;
+    return roitr_angle_over_pi(__builtin_amdgcn_sqrtf(cx * cx + cy * cy + cz * cz), dt);
+}
+// centre c (normal cn) vs neighbour p (normal pn)
+__device__ __forceinline__ float4 roitr_ppf4(float cx, float cy, float cz, float cnx, float cny, float cnz, float px, float py, float pz,
+                                             float pnx, float pny, float pnz)
+{
+    const float dx = px - cx, dy = py - cy, dz = pz - cz;
+    float4 o;
+    o.x = __builtin_amdgcn_sqrtf(dx * dx + dy * dy + dz * dz);
+    o.y = roitr_angle3(cnx, cny, cnz, dx, dy, dz);
+    o.z = roitr_angle3(pnx, pny, pnz, dx, dy, dz);
+    o.w = roitr_angle3(cnx, cny, cnz, pnx, pny, pnz);
+    return o;
+}
+
 // Segment (cloud) of element i under cumulative offsets off[0..n): the first c with i < off[c] + c * stride + bias, clamped to
 // n - 1.  A binary search: the batched engine has up to ~1000 clouds per call, a linear walk per thread shows up in profiles.
 __device__ __forceinline__ int segment_of(int i, const int* __restrict__ off, int n, int stride = 0, int bias = 0)

@@ -6,13 +6,6 @@
 #include "common.h"
 
 namespace {
-__device__ __forceinline__ float ang3(float ax, float ay, float az, float bx, float by, float bz)
-{
-    const float dt = 0.0f + ax * bx + ay * by + az * bz;  // torch.sum starts from +0: keeps atan2(0, +0) = 0
-    const float cx = ay * bz - az * by, cy = az * bx - ax * bz, cz = ax * by - ay * bx;
-    return atan2f(sqrtf(cx * cx + cy * cy + cz * cz), dt) / 3.14159265358979323846f;
-}
-
 __global__ void ppf_kernel(long total, int k, const float* __restrict__ c_xyz, const float* __restrict__ c_n,
                            const float* __restrict__ r_xyz, const float* __restrict__ r_n, const int* __restrict__ grp,
                            float4* __restrict__ out)
@@ -22,13 +15,8 @@ __global__ void ppf_kernel(long total, int k, const float* __restrict__ c_xyz, c
         const long g = grp[t];
         const float cx = c_xyz[m * 3], cy = c_xyz[m * 3 + 1], cz = c_xyz[m * 3 + 2];
         const float nx = c_n[m * 3], ny = c_n[m * 3 + 1], nz = c_n[m * 3 + 2];
-        const float dx = r_xyz[g * 3] - cx, dy = r_xyz[g * 3 + 1] - cy, dz = r_xyz[g * 3 + 2] - cz;
         const float px = r_n[g * 3], py = r_n[g * 3 + 1], pz = r_n[g * 3 + 2];
-        float4 o;
-        o.x = sqrtf(dx * dx + dy * dy + dz * dz);
-        o.y = ang3(nx, ny, nz, dx, dy, dz);
-        o.z = ang3(px, py, pz, dx, dy, dz);
-        o.w = ang3(nx, ny, nz, px, py, pz);
+        const float4 o = roitr_ppf4(cx, cy, cz, nx, ny, nz, r_xyz[g * 3], r_xyz[g * 3 + 1], r_xyz[g * 3 + 2], px, py, pz);
         out[t] = o;
     }
 }

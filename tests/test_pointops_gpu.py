@@ -152,6 +152,116 @@ def test_knn_bit_exact(case, kind, use_grid):
     assert np.array_equal(idx, ridx), f"idx mismatch rows={np.unique(np.nonzero(idx != ridx)[0])[:10]}"
 
 
+@pytest.mark.parametrize("kind", ["uniform", "lattice", "dup", "plane", "surface"])
+@pytest.mark.parametrize("case", [
+    # (clouds, points per cloud, query = self?, nsample): every case has >= 8192 queries on a grid, i.e. the LANE-per-query kernels
+    # of the batched forward (ball filter + key chain for nsample + 1 <= 18, its retry list -> ring kernel -> replay)
+    (4, 5000, True, 9), (4, 5000, True, 17), (8, 1250, True, 17), (3, 5000, False, 17), (9, 1250, False, 17),
+    (4, 5000, False, 3), (4, 5000, False, 1), (2, 9000, True, 5), (1, 70000, True, 9),
+])
+def test_knn_lane_kernels_bit_exact(case, kind):
+    """The kernels the engine's 512-pair calls run (one lane per query) against the C oracle: idx and dist2 bit-equal, clouds of
+    slightly different sizes, queries of non-self calls partly outside the reference cloud's box; the 70000-point cloud is beyond
+    the 16-bit survivor positions of knn_ball_kernel (every query takes the retry path)."""
+    from roitr_amd import pointops as P
+    nc, n, self_q, ns = case
+    if kind != "uniform" and n > 9000:
+        pytest.skip("one large case is enough")
+    rng = np.random.default_rng(77 * len(kind) + 1000 * nc + n + 7 * int(self_q) + 13 * ns)
+    sizes = [n - 3 * (i % 4) for i in range(nc)]
+
+    def make(m):
+        if kind == "surface":   # a noisy two-plane corner: cells mostly empty, the occupied ones dense
+            p = (rng.random((m, 3)) * 2).astype(np.float32)
+            half = m // 2
+            p[:half, 2] = 0.3 + 0.004 * rng.standard_normal(half).astype(np.float32)
+            p[half:, 0] = 0.1 + 0.004 * rng.standard_normal(m - half).astype(np.float32)
+            return p
+        return cloud(rng, m, kind)
+
+    xyz = np.concatenate([make(m) for m in sizes])
+    off = np.cumsum(sizes).astype(np.int32)
+    if self_q:
+        q, qoff = xyz, off
+    else:
+        # FPS-like subsets would be self points: use fresh points, 1/3 of them outside the reference box
+        qs = [max(8192 // nc + 17, m // 2) for m in sizes]
+        q = np.concatenate([make(m) * (1.3 if i % 3 == 0 else 1.0) - (0.3 if i % 3 == 0 else 0.0) for i, m in enumerate(qs)]).astype(np.float32)
+        qoff = np.cumsum(qs).astype(np.int32)
+    assert q.shape[0] >= 8192
+    ridx, rd2 = O.knnquery_raw(ns, xyz, q, off, qoff, threads=8)
+    idx, d2 = P.knnquery_raw(ns, dev(xyz), dev(q), dev(off), dev(qoff), use_grid=True)
+    idx, d2 = idx.cpu().numpy(), d2.cpu().numpy()
+    assert np.array_equal(d2, rd2), f"dist2 mismatch rows={np.unique(np.nonzero(d2 != rd2)[0])[:10]}"
+    assert np.array_equal(idx, ridx), f"idx mismatch rows={np.unique(np.nonzero(idx != ridx)[0])[:10]}"
+
+
+def test_knn_within_matches_oracle_below_the_cap():
+    """roitr_knn_within (the ground-truth occlusion test, lib/utils.py:509-521): nearest squared distance exact wherever it is below the
+    cap, some value >= the cap elsewhere -- lane-per-query path (>= 8192 queries) and wave path."""
+    from roitr_amd import _lib as L
+    rng = np.random.default_rng(9)
+    for nc, n in ((6, 5000), (1, 3000)):
+        sizes = [n - i for i in range(nc)]
+        xyz = np.concatenate([cloud(rng, m) for m in sizes])
+        q = np.concatenate([cloud(rng, m) * 1.1 - 0.05 for m in sizes]).astype(np.float32)
+        off = np.cumsum(sizes).astype(np.int32)
+        _, rd2 = O.knnquery_raw(1, xyz, q, off, off, threads=8)
+        for cap in (0.0375, 0.08, 0.5):
+            cap2 = cap * cap * 1.01
+            lib = L.lib()
+            b, nn, m = len(sizes), xyz.shape[0], q.shape[0]
+            txyz, tq, toff = dev(xyz), dev(q), dev(off)
+            ws = torch.empty(lib.roitr_knn_workspace_bytes(b, nn, m), dtype=torch.uint8, device="cuda")
+            d2 = torch.full((m,), -1.0, dtype=torch.float32, device="cuda")
+            L.check(lib.roitr_knn_build_grid(b, nn, m, L.ptr(txyz), L.ptr(toff), L.ptr(ws), L.stream_ptr()), "grid")
+            import ctypes
+            L.check(lib.roitr_knn_within(b, nn, m, L.ptr(txyz), L.ptr(tq), L.ptr(toff), L.ptr(toff), ctypes.c_float(cap2), L.ptr(d2), 1, m,
+                                         L.ptr(ws), L.stream_ptr()), "within")
+            got = d2.cpu().numpy()
+            below = rd2[:, 0] < cap2
+            assert below.sum() > 10
+            assert np.array_equal(got[below], rd2[below, 0])
+            assert (got[~below] >= cap2).all()
+
+
+def test_ppf_against_float64():
+    """The shared PPF arithmetic (common.h roitr_ppf4: polynomial atan2, v_rcp / v_sqrt) against a float64 evaluation of
+    lib/utils.py:358-389 on random, near-parallel, anti-parallel and zero vectors: 5e-7 on angles / pi, 1e-6 relative on |d|."""
+    from roitr_amd import ops
+    rng = np.random.default_rng(21)
+    m, k = 4096, 16
+    pts = rng.standard_normal((m, 3)).astype(np.float32)
+    nrm = rng.standard_normal((m, 3)).astype(np.float32)
+    nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    patches = (pts[:, None, :] + 0.2 * rng.standard_normal((m, k, 3))).astype(np.float32)
+    pn = rng.standard_normal((m, k, 3)).astype(np.float32)
+    pn /= np.linalg.norm(pn, axis=2, keepdims=True)
+    pn[:, 0] = nrm                                                        # parallel normals
+    pn[:, 1] = -nrm                                                       # anti-parallel
+    patches[:, 2] = pts + nrm * np.float32(0.1)                           # d parallel to n1
+    patches[:, 3] = pts                                                   # d = 0
+    pn[:, 4] = nrm + np.float32(1e-4) * rng.standard_normal((m, 3)).astype(np.float32)   # nearly parallel
+    pn[:, 5] = 0.0                                                        # zero normal
+    grp = torch.arange(m * k, dtype=torch.int32).view(m, k).cuda()
+    out = ops.calc_ppf(dev(pts), dev(nrm), dev(patches.reshape(-1, 3)), dev(pn.reshape(-1, 3)), grp).cpu().numpy()
+    P64, N64, Q64, M64 = pts.astype(np.float64), nrm.astype(np.float64), patches.astype(np.float64), pn.astype(np.float64)
+    d = Q64 - P64[:, None, :]
+
+    def ang(a, b):
+        return np.arctan2(np.linalg.norm(np.cross(a, b), axis=-1), (a * b).sum(-1)) / np.pi
+
+    n1 = np.broadcast_to(N64[:, None, :], d.shape)
+    ref = np.stack([np.linalg.norm(d, axis=-1), ang(n1, d), ang(M64, d), ang(n1, M64)], -1)
+    assert np.abs(out[..., 0] - ref[..., 0]).max() < 1e-6
+    # near-degenerate pairs amplify the fp32 rounding of the cross / dot products themselves (any fp32 implementation does):
+    # compare where the float64 operands are not within 1e-3 rad of (anti-)parallel, and those loosely
+    err = np.abs(out[..., 1:] - ref[..., 1:])
+    generic = (ref[..., 1:] > 1e-3) & (ref[..., 1:] < 1 - 1e-3)
+    assert err[generic].max() < 5e-7, err[generic].max()
+    assert err.max() < 2e-4
+
+
 def test_knn_golden(golden_pair):
     from roitr_amd import pointops as P
     g = golden_pair
