@@ -21,13 +21,10 @@ class Config(dict):
 
 
 def load_config(path):
+    """One flat dict out of the YAML's sections (a key that appears in two sections takes the later one)."""
     with open(path, "r") as f:
-        cfg = yaml.safe_load(f)
-    config = dict()
-    for _, value in cfg.items():
-        for k, v in value.items():
-            config[k] = v
-    return config
+        sections = yaml.safe_load(f)
+    return {key: value for section in sections.values() for key, value in section.items()}
 
 
 def test_config(benchmark="3DMatch"):

@@ -130,6 +130,7 @@ struct Engine {
     int cur_par = -1;                // parity arena the running forward uses (-1: none)
     hipEvent_t gend[2] = {nullptr, nullptr};   // recorded on the main stream where the forward that used the arena ends
     bool gend_rec[2] = {false, false};
+    bool ahead_off = false;          // the alternating arenas could not be allocated: every call is ordered on the main stream
     static constexpr int RING = 4;   // descriptor staging slots: the host may run RING forwards ahead
     char* pinned[RING] = {nullptr, nullptr, nullptr, nullptr}; size_t pinned_cap[RING] = {0, 0, 0, 0};
     hipEvent_t pinned_ev[RING] = {nullptr, nullptr, nullptr, nullptr};
@@ -822,12 +823,19 @@ extern "C" int roitr_engine_finalize(void* h, hipStream_t st)
     E.geo_tab = nullptr;
     {   // GeometricStructureEmbedding as a function table: proj_x(sinusoid(v)) is univariate per channel.  The widest interval
         // whose MEASURED fit error (float64, between the interpolation nodes) is below 2^-25 of the function's amplitude is
-        // taken; distances up to ROITR_GEO_TABLE_RANGE (default 48 = 9.6 m at sigma_d = 0.2) are tabulated, larger ones are
+        // taken; distances up to the table range (default 48 = 9.6 m at sigma_d = 0.2) are tabulated, larger ones are
         // evaluated directly by the kernel.  Angles: atan2 in [0, pi] scaled by 180 / (sigma_a pi).
+        // ROITR_GEO_TABLE (the one switch of this library that selects a code path; tests/test_stages_gpu.py covers each form):
+        // "0" = the GEMM form; otherwise options "range=<units>" (where the distance table ends) and "h=<interval>" (start the
+        // interval search there instead of at 2), comma-separated
         const char* ev = getenv("ROITR_GEO_TABLE");
-        if (!(ev && atoi(ev) == 0) && C4 % 64 == 0) {
-            const char* rv = getenv("ROITR_GEO_TABLE_RANGE");
-            const double d_range = rv && atof(rv) > 0 ? atof(rv) : 48.0, a_range = 180.0 / 15.0;
+        double opt_range = 0.0, opt_h = 0.0;
+        if (ev) {
+            const char* r = strstr(ev, "range="); if (r) opt_range = atof(r + 6);
+            const char* hh = strstr(ev, "h="); if (hh) opt_h = atof(hh + 2);
+        }
+        if (!(ev && ev[0] == '0' && ev[1] == 0) && C4 % 64 == 0) {
+            const double d_range = opt_range > 0 ? opt_range : 48.0, a_range = 180.0 / 15.0;
             std::vector<float> hd((size_t)C4 * C4), ha((size_t)C4 * C4), hbd(C4), hba(C4), hdiv(C4 / 2);
             ROITR_HIP(hipStreamSynchronize(st));
             ROITR_HIP(hipMemcpy(hd.data(), E.proj_d.w, sizeof(float) * hd.size(), hipMemcpyDeviceToHost));
@@ -835,9 +843,7 @@ extern "C" int roitr_engine_finalize(void* h, hipStream_t st)
             ROITR_HIP(hipMemcpy(hbd.data(), E.proj_d.b, sizeof(float) * C4, hipMemcpyDeviceToHost));
             ROITR_HIP(hipMemcpy(hba.data(), E.proj_a.b, sizeof(float) * C4, hipMemcpyDeviceToHost));
             ROITR_HIP(hipMemcpy(hdiv.data(), E.geo_div, sizeof(float) * (C4 / 2), hipMemcpyDeviceToHost));
-            // ROITR_GEO_TABLE_H (diagnostic; tests/test_stages_gpu.py): start the search at this interval instead of 2
-            const char* hv = getenv("ROITR_GEO_TABLE_H");
-            const float h_first = hv && atof(hv) > 0 ? (float)atof(hv) : 2.0f;
+            const float h_first = opt_h > 0 ? (float)opt_h : 2.0f;
             for (float h : {2.0f, 1.0f, 0.5f}) {
                 if (h > h_first) continue;
                 const int nd = (int)ceil(d_range / h), na = (int)floor(a_range / h) + 1;
@@ -878,18 +884,13 @@ extern "C" int roitr_engine_geo_table_info(void* h, double* info)
     return 1;
 }
 
-// mean points per grid cell of level l (experiment switch ROITR_GRID_OCC="a,b,c,d")
-static float grid_occ(int l)
-{
-    static float occ[4] = {6.f, 6.f, 6.f, 6.f};
-    static const bool init = [] {
-        const char* e = getenv("ROITR_GRID_OCC");
-        if (e) sscanf(e, "%f,%f,%f,%f", &occ[0], &occ[1], &occ[2], &occ[3]);
-        return true;
-    }();
-    (void)init;
-    return occ[l];
-}
+// mean points per grid cell (every level): the sphere of one cell size then holds ~2.5 (k + 2) points at level 1 (k = 8), what the
+// prefilter kNN kernel's radius rule needs.  Round 5 re-measured 8 / 9.4 / 11 points per cell at levels 1 - 2 (per-call times of
+// scripts/bench_knn_shapes.py: 5.6 -> 6.0 - 6.6 ms for the calls of a 512-pair forward): 6 stays.
+static constexpr float GRID_OCC = 6.0f;
+
+// calls of up to this many pairs run their whole geometry chain ahead of the previous call (RoitrForwardIO::inputs_ready, forward_body)
+static constexpr int AHEAD_MAX_PAIRS = 128;
 
 static int forward_body(void* h, const RoitrForwardIO* io, hipStream_t st);
 
@@ -968,6 +969,9 @@ static int forward_body(void* h, const RoitrForwardIO* io, hipStream_t st)
     Arena& A = E.arena;
     if (!E.side) {
         // (a lower or higher queue priority for this stream changes nothing measurable: 97.3 / 98.2 / 98.2 ms per 512-pair step)
+        // (round 5: the same stream confined to 32 / 64 / 96 / 128 / 192 CUs by hipExtStreamCreateWithCUMask, spread evenly over the XCDs,
+        // with the main stream off the null stream so that the masked -- "blocking" -- stream does not serialise with it: 3 927 /
+        // 5 768 / 6 004 / 5 969 / 5 949 pairs/s against 5 905 - 6 005 unmasked.  Confinement buys nothing: DESIGN.md section 4.)
         ROITR_HIP(hipStreamCreateWithFlags(&E.side, hipStreamNonBlocking));
         for (int i = 0; i < Engine::NEV; ++i) ROITR_HIP(hipEventCreateWithFlags(&E.ev[i], hipEventDisableTiming));
     }
@@ -982,21 +986,20 @@ static int forward_body(void* h, const RoitrForwardIO* io, hipStream_t st)
     // With the inputs ordered by an event instead of by `st`, the geometry stream copies the descriptors and runs that level
     // at once, beside the previous forward; the rest of the geometry chain writes scratch of the shared arena and waits, as
     // before, for the point of `st` where this forward begins.
-    const bool ahead = io->inputs_ready != nullptr && E.capture_pin == nullptr;
+    bool ahead = io->inputs_ready != nullptr && E.capture_pin == nullptr && !E.ahead_off;
     // ... and so does the level-1 grid + self kNN (+ PPF) the first transformer starts from: in the ahead mode it runs in front of the
     // sampling level on the geometry stream, its workspace and its group / PPF arrays in the alternating arena too (the previous call's
     // decoder still reads ITS level-1 groups) -- 3 ms per 512-pair step off the main stream's chain
-    static const bool knn0_ahead_on = !(getenv("ROITR_KNN0_AHEAD") && atoi(getenv("ROITR_KNN0_AHEAD")) == 0);   // experiment switch
     // up to 128 pairs per call: a small batch is bound by the main stream's chain (one pair per call 2.01 -> 1.87 ms, 64 pairs 12.25 -> 12.04 ms);
     // at 512 pairs the step is bound by the chip's total work and the move only shifts contention onto the GEMMs (5 843 / 5 886 vs 5 906 / 5 862
     // pairs/s, gemm_kernel 37.7 -> 38.9 ms per step)
-    const bool knn0_ahead = ahead && knn0_ahead_on && B <= 128;
+    bool knn0_ahead = ahead && B <= AHEAD_MAX_PAIRS;
     // ... and with it the WHOLE geometry chain (round 4, last step): for calls of up to 128 pairs every buffer the geometry stream writes lives in
     // the alternating arena, so the chain of call s + 1 needs nothing from the main stream: it runs beside call s from the first kernel to
     // the last and only waits for the call before that one (same arena) to have ended
-    const bool full_ahead = knn0_ahead;
-    Arena& G = ahead ? E.garena[E.gpar] : E.arena;
+    bool full_ahead = knn0_ahead;
     if (ahead) {
+        Arena& G = E.garena[E.gpar];
         size_t need = desc_bytes + (size_t)T1 * 4 + (size_t)2 * NC * 4 + 8192;
         for (int l = 1; l < 4; ++l) need += (size_t)V.T[l] * (4 + 12 + 12) + 1024;
         if (knn0_ahead) need += roitr_knn_workspace_bytes(NC, V.T[0], T1) + (size_t)V.T[0] * E.nsample[0] * (4 + 16) + 4096;
@@ -1016,9 +1019,19 @@ static int forward_body(void* h, const RoitrForwardIO* io, hipStream_t st)
             ROITR_HIP(hipStreamSynchronize(sd));
             if (G.base) ROITR_HIP(hipFree(G.base));
             G.base = nullptr; G.cap = 0;
-            ROITR_HIP(hipMalloc((void**)&G.base, need * 2));
-            G.cap = need * 2;
+            const size_t cap = need + need / 8 + ((size_t)1 << 20);   // a margin, not a multiple: 2.4 GB at 128 pairs, twice (two arenas)
+            if (hipMalloc((void**)&G.base, cap) == hipSuccess) G.cap = cap;
+            else {   // no memory for the alternating arenas: this engine orders every call on the main stream from now on
+                (void)hipGetLastError();
+                G.base = nullptr;
+                E.ahead_off = true;
+                ahead = knn0_ahead = full_ahead = false;
+            }
         }
+    }
+    if (io->inputs_ready && !ahead && E.capture_pin == nullptr) ROITR_HIP(hipStreamWaitEvent(st, (hipEvent_t)io->inputs_ready, 0));   // inputs ordered by the event all the same
+    Arena& G = ahead ? E.garena[E.gpar] : E.arena;
+    if (ahead) {
         G.off = 0; G.fail = false;
         E.cur_par = E.gpar;
         if (!E.gend[E.gpar]) ROITR_HIP(hipEventCreateWithFlags(&E.gend[E.gpar], hipEventDisableTiming));
@@ -1083,8 +1096,6 @@ static int forward_body(void* h, const RoitrForwardIO* io, hipStream_t st)
     const void* order[4] = {nullptr, nullptr, nullptr, nullptr};  // cell-order visiting order of each level's points
     float* xe[4];
     std::function<int()> issue_geo, issue_tail;   // see the end of the side-stream section
-    static const int geo_after = getenv("ROITR_SIDE_GEO_AFTER") ? atoi(getenv("ROITR_SIDE_GEO_AFTER")) : -1;      // experiment switches
-    static const int tail_after = getenv("ROITR_SIDE_TAIL_AFTER") ? atoi(getenv("ROITR_SIDE_TAIL_AFTER")) : -1;
     const float* pts_out = io->points_out ? io->points_out : io->points_geom;
     Arena& GF = full_ahead ? G : A;     // everything else the geometry stream writes
     float* node_xyz = io->node_xyz ? io->node_xyz : GF.get<float>((size_t)T4 * 3);
@@ -1145,7 +1156,7 @@ static int forward_body(void* h, const RoitrForwardIO* io, hipStream_t st)
         if (grid[0]) {
             // 6 points per cell on average: at level 1 (k = 8) the sphere of one cell size then holds ~2.5 (k + 2) points, what
             // the prefilter kNN kernel's radius rule needs
-            CHK(roitr_knn_build_grid_ex(NC, V.T[0], T1, p[0], D.off[0], knn_ws[0], grid_occ(0), s0));
+            CHK(roitr_knn_build_grid_ex(NC, V.T[0], T1, p[0], D.off[0], knn_ws[0], GRID_OCC, s0));
             order[0] = roitr_knn_sorted_points(NC, V.T[0], T1, knn_ws[0]);
         }
         if (!knn0_ahead) ROITR_HIP(hipEventRecord(E.ev[0], st));  // inputs + descriptors are in place
@@ -1167,7 +1178,7 @@ static int forward_body(void* h, const RoitrForwardIO* io, hipStream_t st)
             if (!(ahead && l == 1)) CHK(sample_level(l));
             // grid over this level's points (refs for: own self-kNN, next level's TD query, finer level's 3-NN)
             if (grid[l]) {
-                CHK(roitr_knn_build_grid_ex(NC, V.T[l], V.T[l - 1], p[l], D.off[l], knn_ws[l], grid_occ(l), sd));
+                CHK(roitr_knn_build_grid_ex(NC, V.T[l], V.T[l - 1], p[l], D.off[l], knn_ws[l], GRID_OCC, sd));
                 order[l] = roitr_knn_sorted_points(NC, V.T[l], V.T[l - 1], knn_ws[l]);
             }
             CHK(roitr_knnquery_ex(NC, V.T[l], V.T[l], K + 1, p[l], p[l], D.off[l], D.off[l], nullptr, nullptr, g_self[l], ppf_self[l], nrm[l],
@@ -1178,10 +1189,8 @@ static int forward_body(void* h, const RoitrForwardIO* io, hipStream_t st)
                                   ppf_td[l], nrm[l - 1], nrm[l], grid[l - 1] ? 1 : 0, mcap_prev, knn_ws[l - 1], sd));
             ROITR_HIP(hipEventRecord(E.ev[l], sd));
         }
-        // The embedding E and the chain's tail (3-NN, partition, ground-truth outputs) as two units that can be ENQUEUED later than
-        // the rest of the chain (ROITR_SIDE_GEO_AFTER / ROITR_SIDE_TAIL_AFTER = encoder level l: behind that level's feature work;
-        // default: here).  They are needed late (global transformer / decoder / matching), and what they run beside matters:
-        // geo_table_kernel holds 122 KB of LDS per CU, the tail's kernels take registers from the 227-VGPR block transformer of level 2.
+        // The embedding E and the chain's tail (3-NN, partition, ground-truth outputs).  (Round 4 measured both units ENQUEUED behind
+        // encoder level 1, 2 or 3 instead of here: no effect on the step; the switches are gone.)
         issue_geo = [&]() -> int {
             // the embedding of the global transformer (positional_encoding.py:139-154): needs the level-4 coordinates only
             CHK(roitr_geo_indices(T4, p[3], D.off[3], D.cloud_of_node, D.eoff, 0.2f, 15.0f, 3, V.nmax[3], d_idx, a_idx, sd));
@@ -1205,6 +1214,13 @@ static int forward_body(void* h, const RoitrForwardIO* io, hipStream_t st)
                 CHK(roitr_knnquery_ex(NC, V.T[l + 1], V.T[l], 3, p[l + 1], p[l], D.off[l + 1], D.off[l], i3[l], d3[l], nullptr, nullptr, nullptr,
                                       nullptr, grid[l + 1] ? 1 : 0, V.T[l], knn_ws[l + 1], sd));
             ROITR_HIP(hipEventRecord(E.ev[6], sd));
+            // From here on the chain writes the CALLER's output buffers (node_xyz, node_masks, node_knn_*, gt_*).  In the whole-chain-ahead
+            // mode nothing so far has ordered this stream against the previous call on `st` -- but that call's matching phase may still
+            // read ITS outputs through the same pointers (a C caller that reuses one set of buffers; torch's caching allocator handing a
+            // freed block out again): wait for the point where this call begins on `st` (ev[0], recorded behind everything the
+            // previous call queued there).  The kernels below then run beside this call's encoder instead of the previous call's
+            // tail; the matching phase, which needs them, is 1 - 2 ms further down the main stream.
+            if (full_ahead) ROITR_HIP(hipStreamWaitEvent(sd, E.ev[0], 0));
             // node coordinates (model/model.py:233-235), point-to-node partition (lib/utils.py:428-471) and the ground-truth side
             // outputs: coordinates, the FPS picks and the given transform only
             {
@@ -1262,8 +1278,8 @@ static int forward_body(void* h, const RoitrForwardIO* io, hipStream_t st)
             ROITR_HIP(hipEventRecord(E.ev[7], sd));
             return ROITR_OK;
         };
-        if (geo_after < 0) CHK(issue_geo());
-        if (tail_after < 0) CHK(issue_tail());
+        CHK(issue_geo());
+        CHK(issue_tail());
     }
     roitr_prof_begin(ROITR_PROF_PH_ENC, 0.0, st);
     {
@@ -1305,12 +1321,6 @@ static int forward_body(void* h, const RoitrForwardIO* io, hipStream_t st)
                 float* t = cur; cur = nxt; nxt = t;
             }
             xe[l] = cur; xin = cur;
-            if (l == geo_after || l == tail_after) {   // deferred side-stream units: enqueued behind this level's feature work
-                ROITR_HIP(hipEventRecord(E.ev[10], st));
-                ROITR_HIP(hipStreamWaitEvent(sd, E.ev[10], 0));
-                if (l == geo_after) CHK(issue_geo());
-                if (l == tail_after) CHK(issue_tail());
-            }
         }
     }
     if (A.fail) { roitr_set_error("arena exhausted (encoder)", __FILE__, __LINE__); return ROITR_ERR_ARG; }

@@ -15,7 +15,8 @@ void roitr_set_error(const char* msg, const char* file, int line)
 }
 
 extern "C" const char* roitr_last_error(void) { return g_err; }
-extern "C" int roitr_abi_version(void) { return 1; }
+// 2: RoitrForwardIO::inputs_ready and RoitrGemm::a_cat_idx (round 4) -- a client built against version 1 passes shorter structs
+extern "C" int roitr_abi_version(void) { return 2; }
 
 // Dynamic-LDS limit of a kernel, raised once per (kernel, device) and checked: hipFuncSetAttribute applies to the CURRENT device
 // only, so a process that drives several devices needs it on each of them (one process per GPU is the normal case, but nothing

@@ -599,8 +599,7 @@ extern "C" int roitr_gemm(const RoitrGemm* g, hipStream_t stream)
     if (shapes) { hipEventCreate(&e0); hipEventCreate(&e1); hipEventRecord(e0, stream); }
     const bool a2 = g->A2 != nullptr;
     const bool il = T >= GEMM_IL_MIN_TILES;   // staging loads spread over the MFMA stream (see the kernel): large grids only
-    static const int small_max = getenv("ROITR_GEMM_SMALL_MAX") ? atoi(getenv("ROITR_GEMM_SMALL_MAX")) : GEMM_SMALL_MAX_TILES;   // experiment switch
-    if (fast && !g->ln_gamma && T < small_max) {   // a fraction of a tile per SIMD: 32 x 32 tiles with 4x shorter accumulator chains
+    if (fast && !g->ln_gamma && T < GEMM_SMALL_MAX_TILES) {   // a fraction of a tile per SIMD: 32 x 32 tiles with 4x shorter accumulator chains
         const int sx = div_up(g->N, SM), sy = div_up(g->M, SM);
         const int ST = sx * sy * g->batch;
         if (a2) gemm_small_kernel<true><<<xcd_grid(ST), 256, 0, stream>>>(*g, sx, sy, ST);

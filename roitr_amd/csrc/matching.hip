@@ -870,39 +870,45 @@ extern "C" int roitr_patch_gather(const RoitrPatch* a, hipStream_t stream)
 }
 
 namespace {
+// one counter buffer, on the device that was current when counting was switched on; launches on other devices do not count
 struct OtStats {
     unsigned long long* d = nullptr;
-    bool on = false, print = false;
-    OtStats() { if (getenv("ROITR_OT_STATS")) { print = true; enable(true); } }
+    int dev = -1;
+    bool on = false;
     void enable(bool e)
     {
-        if (e && !d) { if (hipMalloc(&d, 24) != hipSuccess) { d = nullptr; return; } (void)hipMemset(d, 0, 24); }
+        if (e && !d) {
+            if (hipGetDevice(&dev) != hipSuccess || hipMalloc(&d, 24) != hipSuccess) { d = nullptr; dev = -1; return; }
+            (void)hipMemset(d, 0, 24);
+        }
         on = e && d;
     }
-    ~OtStats()
+    unsigned long long* for_current_device() const
     {
-        if (d && print) {
-            unsigned long long h[3] = {0, 0, 0};
-            (void)hipMemcpy(h, d, 24, hipMemcpyDeviceToHost);
-            fprintf(stderr, "OTSTATS live_patches %llu skipped_iterations %llu log_domain_patches %llu\n", h[0], h[1], h[2]);
-        }
+        int cur = -1;
+        return on && hipGetDevice(&cur) == hipSuccess && cur == dev ? d : nullptr;
     }
 };
-OtStats& ot_stats() { static OtStats st; return st; }   // first use, not library load: the constructor may touch the device
+OtStats& ot_stats() { static OtStats st; return st; }   // no HIP call at library load or unload
 }  // namespace
 
-/* Counters of the optimal-transport stage since the last reset (synchronous; diagnostics): enable = 1 switches counting on and
- * zeroes the counters, 0 switches it off.  out[0] live patches, out[1] Sinkhorn iterations skipped by the fixed-point exit,
- * out[2] patches served by the log-domain kernel. */
+/* Counters of the optimal-transport stage since the last reset (synchronous; diagnostics; not while a stream of the device is
+ * capturing): enable = 1 switches counting on (on the current device) and zeroes the counters, 0 switches it off, -1 only reads.
+ * out[0] live patches, out[1] Sinkhorn iterations skipped by the fixed-point exit, out[2] patches served by the log-domain kernel. */
 extern "C" int roitr_ot_stats(int enable, unsigned long long* out)
 {
+    OtStats& S = ot_stats();
     if (out) {
         out[0] = out[1] = out[2] = 0;
-        if (ot_stats().d) { ROITR_HIP(hipDeviceSynchronize()); ROITR_HIP(hipMemcpy(out, ot_stats().d, 24, hipMemcpyDeviceToHost)); }
+        if (S.d) {
+            ROITR_HIP(hipSetDevice(S.dev));
+            ROITR_HIP(hipDeviceSynchronize());
+            ROITR_HIP(hipMemcpy(out, S.d, 24, hipMemcpyDeviceToHost));
+        }
     }
     if (enable >= 0) {
-        ot_stats().enable(enable != 0);
-        if (ot_stats().d && enable) { ROITR_HIP(hipDeviceSynchronize()); ROITR_HIP(hipMemset(ot_stats().d, 0, 24)); }
+        S.enable(enable != 0);
+        if (S.d && enable) { ROITR_HIP(hipDeviceSynchronize()); ROITR_HIP(hipMemset(S.d, 0, 24)); }
     }
     return ROITR_OK;
 }
@@ -912,9 +918,9 @@ extern "C" int roitr_optimal_transport(const RoitrOT* a, hipStream_t stream)
     if (a->pairs <= 0) return ROITR_OK;
     if (a->limit != 64) return ROITR_ERR_UNSUPPORTED;
     roitr_prof_begin(ROITR_PROF_OT, (double)a->pairs * a->num_corr * (64.0 * 64 + 65.0 * 65) * 4.0, stream);
-    // data-dependent work of this stage (roitr_ot_stats / ROITR_OT_STATS=1): live patches, Sinkhorn iterations skipped by the exact
-    // fixed-point exit, patches the exponential form handed to the log-domain kernel
-    unsigned long long* sd = ot_stats().on ? ot_stats().d : nullptr;
+    // data-dependent work of this stage (roitr_ot_stats): live patches, Sinkhorn iterations skipped by the exact fixed-point exit,
+    // patches the exponential form handed to the log-domain kernel
+    unsigned long long* sd = ot_stats().for_current_device();
     ot_kernel<<<a->pairs * a->num_corr, 64, 0, stream>>>(*a, sd);
     ot_log_kernel<<<a->pairs * a->num_corr, 64, 0, stream>>>(*a, sd);   // the patches the exponential form declined; the others leave at once
     roitr_prof_end(ROITR_PROF_OT, stream);

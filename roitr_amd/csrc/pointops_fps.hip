@@ -351,17 +351,15 @@ extern "C" int roitr_furthestsampling_ex(int b, int n_max, const float* xyz, con
     while ((1 << bits) <= mask) ++bits;
     // the LDS copy of xyz (winner lookup without a memory round trip) is what a FEW clouds on an empty chip want; in a large batch it
     // only takes LDS away from everybody else: 76 KB per cloud = two clouds per CU and nothing left for the feature path's
-    // workgroups beside them (ROITR_FPS_LDS_MAX_CLOUDS: experiment switch)
-    static const int lds_max_b = getenv("ROITR_FPS_LDS_MAX_CLOUDS") ? atoi(getenv("ROITR_FPS_LDS_MAX_CLOUDS")) : 64;
+    // workgroups beside them
+    constexpr int lds_max_b = 64;
     const int lds_pts = (n_max <= FPS_PTS_CAP && b <= lds_max_b) ? n_max : 0;
     // few clouds (the one-pair-per-call mode): the chain of m dependent arg-max iterations is the critical path of the whole
     // forward and the chip is empty -- 8 waves per cloud halve the per-lane work of an iteration (4.36 vs 4.48 ms per pair;
     // 16 waves: 5.03, the cross-wave stage grows faster than the lane work shrinks).  Same indices for every block size.
-    static const int small_batch_block = getenv("ROITR_FPS_SMALL_BATCH_BLOCK") ? atoi(getenv("ROITR_FPS_SMALL_BATCH_BLOCK")) : 512;   // experiment switch
-    static const int big_batch_block = getenv("ROITR_FPS_BLOCK") ? atoi(getenv("ROITR_FPS_BLOCK")) : 0;                               // experiment switch
-    static const int grid_cap = getenv("ROITR_FPS_GRID") ? atoi(getenv("ROITR_FPS_GRID")) : 0;                                        // experiment switch
-    const int forced = n_max <= 512 * 16 && ((b <= 16 && small_batch_block == 512) || (b > 16 && big_batch_block == 512)) ? 512 : 0;
-    const int nblk = grid_cap > 0 && b > grid_cap ? grid_cap : b;
+    // (Round 4 measured 8-wave workgroups for large batches and a cap on the resident clouds per CU as well: no effect, removed.)
+    const int forced = n_max <= 512 * 16 && b <= 16 ? 512 : 0;
+    const int nblk = b;
 #define FPS_CASE(BLK, P)                                                                              \
     if (n_max <= (BLK) * (P) && (forced == 0 || forced == (BLK))) {                                   \
         ROITR_GRANT_LDS((fps_kernel<BLK, P>), fps_lds_bytes(BLK, FPS_PTS_CAP));                       \

@@ -1183,191 +1183,12 @@ __global__ __launch_bounds__(256) void knn_prefilter_kernel(int m, int nsample, 
     lane_emit<L>(o, q, nsample, d, id, tie, xyz, qx, qy, qz);
 }
 
-// ---------------------------------------------------------------- small k, one LANE per query: ball filter + key chain (round 5)
-// What the prefilter above still pays: (1) its radius is cut at the guarantee radius of the fixed 3 x 3 x 3 box (h .. 1.5 h), so at
-// nsample + 1 = 18 on 6-point cells most lanes find too few survivors; (2) the insertion chain carries (distance, index) pairs --
-// a v_med3 + 2 v_cndmask + a compare per list slot and candidate; (3) every survivor is re-fetched by a dependent load.
-// Here:
-//   * the box FOLLOWS the radius: the cells that overlap the axis-aligned bounding box of the ball of radius r around the query
-//     (r = the radius expected to hold `want` points at the density of the query's 27-cell neighbourhood, spherical caps cut off by
-//     the cloud's bounding box added back) -- every point closer than r lies in one of them whatever the cell size, so with at
-//     least nsample + 1 survivors (d2 < r^2) the nsample + 1 nearest points of the cloud are among the survivors;
-//   * a survivor is a 16-bit position in its cloud's sorted array, stored in the lane's LDS column (branch-free: rejected
-//     candidates are written to a trash row);
-//   * the list is a chain of 32-bit KEYS: the distance's bit pattern (non-negative floats order like unsigned integers) with its 6
-//     low mantissa bits replaced by the survivor's slot number -- ONE v_med3_u32 per list slot and survivor, no index registers.
-//     Two keys that agree in the upper 26 bits are not ordered by distance (and an exact tie always looks like that): the query
-//     then goes through the retry list to the ring-expanding kernel, which keeps exact (distance, index) lists and hands real
-//     ties to the replay (0.1 - 0.2 % of the queries of a generic cloud; all of them on lattice / duplicate clouds).  The chain
-//     keeps nsample + 2 keys so that the pair (nsample, nsample + 1) is checked too: the best nsample + 1 are then exactly the
-//     chain's first nsample + 1, strictly ordered;
-//   * the winners' slots give their positions back (LDS), one load each gives coordinates + index (the same sqdist3 -> the same
-//     bits as every other kernel), the PPF takes the neighbour's coordinates from that load.
-// Queries this kernel cannot decide (fewer than nsample + 1 or more than CAP survivors, a cloud beyond 65535 points, a box of more
-// than 5 cells along an axis, ambiguous keys) are appended to the retry list; results of the others are bit-identical to the ring kernel's.
-__device__ __forceinline__ unsigned umed3(unsigned a, unsigned b, unsigned c) { return max(min(a, b), min(max(a, b), c)); }   // -> v_med3_u32
-
-// radius expected to hold `want` points around (qx, qy, qz) at the density nbox / vbox of the (clipped) 3 x 3 x 3 cell box around
-// the query's cell, grown by the spherical caps the faces of the cloud's bounding box cut off (two fixed-point steps; overlapping
-// caps at edges / corners are subtracted twice -> a larger radius, never a wrong result)
-__device__ __forceinline__ float capped_density_radius(const RoitrGrid& g, float qx, float qy, float qz, float want, float vbox, int nbox)
-{
-    const float r0 = cbrtf(want * vbox * 0.2387324f / (float)max(nbox, 1));   // 3 / (4 pi)
-    const float fd[6] = {qx - g.ox, g.ox + (float)g.nx * g.h - qx, qy - g.oy, g.oy + (float)g.ny * g.h - qy, qz - g.oz, g.oz + (float)g.nz * g.h - qz};
-    float r_est = r0;
-#pragma unroll
-    for (int itr = 0; itr < 2; ++itr) {
-        float inside = 1.0f;
-#pragma unroll
-        for (int f = 0; f < 6; ++f) {
-            const float hc = r_est - fmaxf(fd[f], 0.f);
-            if (hc > 0.f) inside -= hc * hc * (3.0f * r_est - hc) / (4.0f * r_est * r_est * r_est);
-        }
-        r_est = r0 * rcbrtf(fmaxf(inside, 0.125f));
-    }
-    return r_est;
-}
-__device__ __forceinline__ float density_radius(const RoitrGrid& g, const int* __restrict__ cs, float qx, float qy, float qz, const int (&c0)[3],
-                                                float want)
-{
-    const int x0 = max(c0[0] - 1, 0), x1 = min(c0[0] + 1, g.nx - 1);
-    const int y0 = max(c0[1] - 1, 0), y1 = min(c0[1] + 1, g.ny - 1);
-    const int z0 = max(c0[2] - 1, 0), z1 = min(c0[2] + 1, g.nz - 1);
-    int nbox = 0;
-    for (int cz = z0; cz <= z1; ++cz)
-        for (int cy = y0; cy <= y1; ++cy) {
-            const int rowbase = (cz * g.ny + cy) * g.nx;
-            nbox += cs[rowbase + x1 + 1] - cs[rowbase + x0];
-        }
-    const float vbox = (float)((x1 - x0 + 1) * (y1 - y0 + 1) * (z1 - z0 + 1)) * g.h * g.h * g.h;
-    return capped_density_radius(g, qx, qy, qz, want, vbox, nbox);
-}
-
+// ---------------------------------------------------------------- radius test, one LANE per query (round 5)
 // cells [lo, hi] along one axis that the interval [q - rb, q + rb] overlaps (clamped in float first: no int overflow far outside)
 __device__ __forceinline__ void ball_cells(float q, float rb, float o, float inv_h, int dim, int& lo, int& hi)
 {
     lo = (int)fminf(fmaxf((q - rb - o) * inv_h, 0.f), (float)(dim - 1));
     hi = (int)fminf(fmaxf((q + rb - o) * inv_h, 0.f), (float)(dim - 1));
-}
-
-template <int LC, int CAP>
-__global__ __launch_bounds__(256) void knn_ball_kernel(int m, int nsample, int b, const float* __restrict__ xyz,
-                                                       const float* __restrict__ new_xyz, const int* __restrict__ offset,
-                                                       const int* __restrict__ new_offset, const RoitrGrid* __restrict__ grids,
-                                                       const int* __restrict__ cell_start, const float4* __restrict__ sorted, KnnOut o,
-                                                       int self_sorted, const int* __restrict__ qorder, float want,
-                                                       int* __restrict__ retry_count, int* __restrict__ retry_list)
-{
-    static_assert(CAP <= 64, "a survivor's slot number lives in the 6 low bits of its key");
-    constexpr int NF = 8;                            // candidate loads in flight per lane
-    __shared__ unsigned short surv[CAP + NF][256];   // [slot][thread]: conflict-free; the count is clamped to CAP once per NF candidates
-    const int nblk = (m + 255) >> 8;
-    const int blk = xcd_block_id(nblk);
-    if (blk >= nblk) return;
-    const int tid = threadIdx.x;
-    const int t = blk * 256 + tid;
-    if (t >= m) return;
-    const int q = self_sorted ? __float_as_int(sorted[t].w) : (qorder ? qorder[t] : t);
-    const int seg = segment_of(q, new_offset, b);
-    const int start = seg == 0 ? 0 : offset[seg - 1];
-    const int n_cloud = offset[seg] - start;
-    const RoitrGrid g = grids[seg];
-    const int* cs = cell_start + (size_t)seg * (GRID_MAX_CELLS + 1);
-    const float qx = new_xyz[(size_t)q * 3], qy = new_xyz[(size_t)q * 3 + 1], qz = new_xyz[(size_t)q * 3 + 2];
-    int c0[3];
-    {
-        const float tq[3] = {(qx - g.ox) * g.inv_h, (qy - g.oy) * g.inv_h, (qz - g.oz) * g.inv_h};
-        const int dim[3] = {g.nx, g.ny, g.nz};
-#pragma unroll
-        for (int a = 0; a < 3; ++a) c0[a] = (int)fminf(fmaxf(tq[a], 0.f), (float)(dim[a] - 1));
-    }
-    const float r = density_radius(g, cs, qx, qy, qz, c0, want);
-    const float r2 = r * r;
-    const float margin = 2e-4f * g.h;
-    int bx0, bx1, by0, by1, bz0, bz1;
-    ball_cells(qx, r + margin, g.ox, g.inv_h, g.nx, bx0, bx1);
-    ball_cells(qy, r + margin, g.oy, g.inv_h, g.ny, by0, by1);
-    ball_cells(qz, r + margin, g.oz, g.inv_h, g.nz, bz0, bz1);
-    const int need = nsample + 1;
-    bool fail = !(r2 > 0.f) || n_cloud > 65535 || n_cloud < 1 || bx1 - bx0 > 4 || by1 - by0 > 4 || bz1 - bz0 > 4;
-    // the sorted array through 32-bit byte offsets (scalar base + vector offset addressing; < 2^28 points per call)
-    const char* sbase = reinterpret_cast<const char*>(sorted);
-    auto point_at = [&](int i) { return *reinterpret_cast<const float4*>(sbase + ((unsigned)i << 4)); };
-    int cnt = 0;
-    if (!fail)
-    for (int cz = bz0; cz <= bz1; ++cz)
-        for (int cy = by0; cy <= by1; ++cy) {
-            // a row of cells whose (y, z) slab lies beyond the ball holds no survivor (the ring kernel's pruning rule, same margin)
-            const float ylo = __fmaf_rn((float)cy, g.h, g.oy), zlo = __fmaf_rn((float)cz, g.h, g.oz);
-            const float dy = fmaxf(fmaxf(ylo - qy, qy - (ylo + g.h)), 0.f), dz = fmaxf(fmaxf(zlo - qz, qz - (zlo + g.h)), 0.f);
-            const float lb = fmaxf(sqrtf(dy * dy + dz * dz) - margin, 0.f);
-            if (lb * lb > r2) continue;
-            const int rowbase = (cz * g.ny + cy) * g.nx;
-            const int s = cs[rowbase + bx0], e = cs[rowbase + bx1 + 1];
-            for (int p = s; p < e; p += NF) {
-                float4 c[NF];
-#pragma unroll
-                for (int u = 0; u < NF; ++u) c[u] = point_at(min(p + u, e - 1));
-#pragma unroll
-                for (int u = 0; u < NF; ++u) {
-                    const float dd = sqdist3(qx, qy, qz, c[u].x, c[u].y, c[u].z);
-                    if (p + u < e && dd < r2) { surv[cnt][tid] = (unsigned short)(p + u - start); ++cnt; }
-                }
-                fail = fail || cnt > CAP;
-                cnt = min(cnt, CAP);
-            }
-        }
-    fail = fail || cnt < need;
-    const int my = fail ? 0 : cnt;
-    unsigned key[LC];
-#pragma unroll
-    for (int j = 0; j < LC; ++j) key[j] = 0xFFFFFFFFu;
-    // the chain: survivors are fetched NS at a time (L1 / L2-resident: just scanned), loads unconditional (a lane past its own
-    // count reads its cloud's first point and feeds the fill key)
-    constexpr int NS = 8;
-    for (int j0 = 0; __any(j0 < my); j0 += NS) {
-        int pos[NS];
-#pragma unroll
-        for (int u = 0; u < NS; ++u) pos[u] = surv[min(j0 + u, CAP + NF - 1)][tid];
-        float4 c[NS];
-#pragma unroll
-        for (int u = 0; u < NS; ++u) c[u] = point_at(start + (j0 + u < my ? pos[u] : 0));
-#pragma unroll
-        for (int u = 0; u < NS; ++u) {
-            unsigned k = (__float_as_uint(sqdist3(qx, qy, qz, c[u].x, c[u].y, c[u].z)) & ~63u) | (unsigned)(j0 + u);
-            k = j0 + u < my ? k : 0xFFFFFFFFu;
-#pragma unroll
-            for (int v = LC - 1; v > 0; --v) key[v] = umed3(k, key[v - 1], key[v]);   // ascending list: the median IS the shifted / inserted / kept value
-            key[0] = min(key[0], k);
-        }
-    }
-    // two neighbouring keys with the same upper 26 bits: their order (and an exact tie) is not decided here
-#pragma unroll
-    for (int j = 0; j + 1 < LC; ++j) fail = fail || (j <= nsample && ((key[j] ^ key[j + 1]) < 64u));
-    if (fail) {
-        const int slot = atomicAdd(retry_count, 1);
-        retry_list[slot] = q;
-        return;
-    }
-    float qnx = 0.f, qny = 0.f, qnz = 0.f;
-    if (o.ppf) { const float* qn = o.query_normals + (size_t)q * 3; qnx = qn[0]; qny = qn[1]; qnz = qn[2]; }
-#pragma unroll
-    for (int j = 0; j < LC; ++j) {
-        if (j < nsample) {
-            const float4 c = point_at(start + surv[key[j] & 63u][tid]);
-            const int ci = __float_as_int(c.w);
-            if (o.idx) o.idx[(size_t)q * nsample + j] = ci;
-            if (o.dist2) o.dist2[(size_t)q * nsample + j] = sqdist3(qx, qy, qz, c.x, c.y, c.z);
-            if (j >= 1) {
-                if (o.group_idx) o.group_idx[(size_t)q * (nsample - 1) + j - 1] = ci;
-                if (o.ppf) {
-                    const float* pn = o.ref_normals + (size_t)ci * 3;
-                    reinterpret_cast<float4*>(o.ppf)[(size_t)q * (nsample - 1) + j - 1] =
-                        ppf4(qx, qy, qz, qnx, qny, qnz, c.x, c.y, c.z, pn[0], pn[1], pn[2]);
-                }
-            }
-        }
-    }
 }
 
 // Nearest-neighbour distance for a radius test (roitr_knn_within: lib/utils.py:509-521 only evaluates `nearest distance < radius`): the
@@ -1414,237 +1235,6 @@ __global__ __launch_bounds__(256) void knn_within_kernel(int m, int b, const flo
             }
         }
     dist2[q] = best;
-}
-
-// ---------------------------------------------------------------- small k: LDS-staged cell neighbourhood, lane per query, key chain (round 5)
-// The ball kernel above halves the VALU work of the ring kernel and runs no faster: its candidate loads are 64 independent gathers
-// per instruction (25 cache lines per wave-load, SQ / TCP counters of round 5: wave cycles 57 % parked on s_waitcnt, ~75 dependent
-// round trips per wave).  Here ONE WAVE = 64 consecutive queries of the cell order (a workgroup is one wave), and
-//   1. the wave's cell neighbourhood -- the bounding box of its lanes' 3 x 3 x 3 cell boxes: (y, z) rows of cells, each one
-//      contiguous run of the counting-sorted array -- is staged ONCE into LDS by coalesced loads, all of them in flight together
-//      (16 float4 per lane at most), next to the cell_start entries of those rows;
-//   2. every lane filters ITS 27 cells out of LDS (ds_read_b128, lanes of a cell read the same address) against
-//      tau = min(guarantee radius of its box, radius expected to hold `want` points at the box's density): everything closer
-//      than tau lies in the box, so with >= nsample + 1 survivors the nsample + 1 nearest points are among them;
-//   3. survivors (16-bit LDS slots in the lane's column) go through the chain of 32-bit keys (distance bits | slot number: one
-//      v_med3_u32 per list position), winners come back out of LDS with their coordinates and indices; the fused PPF needs one
-//      gather per neighbour (its normal).
-// No global gather is left in the selection.  Lanes whose box would not fit (a wave that straddles clouds, or a z-plane of a
-// large grid: bounding box > 32 rows / 16 cells / 1024 points) are taken in groups -- same cloud first, then same row of cells --
-// inside the kernel; queries that still cannot be decided (too few / too many survivors, ambiguous keys = possible ties) go to
-// the ring-expanding kernel through the retry list, exactly like the prefilter kernel's.  Results are bit-identical to it.
-constexpr int TILE_STAGE = 1024;   // staged points per wave (16 KB)
-constexpr int TILE_ROWS = 32;      // (y, z) rows of cells per staged box
-constexpr int TILE_W = 16;         // cells per staged row
-
-__device__ __forceinline__ int wave_min_i(int v) { return -(int)wave_max(-(float)v); }   // |v| < 2^24: exact in fp32
-__device__ __forceinline__ int wave_max_i(int v) { return (int)wave_max((float)v); }
-
-template <int LC, int CAP>
-__global__ __launch_bounds__(64) void knn_tile_kernel(int m, int nsample, int b, const float* __restrict__ new_xyz,
-                                                      const int* __restrict__ offset, const int* __restrict__ new_offset,
-                                                      const RoitrGrid* __restrict__ grids, const int* __restrict__ cell_start,
-                                                      const float4* __restrict__ sorted, KnnOut o, int self_sorted,
-                                                      const int* __restrict__ qorder, float want, int* __restrict__ retry_count,
-                                                      int* __restrict__ retry_list)
-{
-    static_assert(CAP <= 64, "a survivor's slot number lives in the 6 low bits of its key");
-    constexpr int NF = 4;
-    __shared__ float4 stage[TILE_STAGE];
-    __shared__ int cstab[TILE_ROWS][TILE_W + 1];       // cell_start entries ux0 .. ux1 + 1 of every staged row
-    __shared__ int roffs[TILE_ROWS + 1];               // LDS offset of every staged row; sentinel behind the last
-    __shared__ int rstab[TILE_ROWS];                   // position of every staged row's first point in the sorted array
-    __shared__ unsigned short surv[CAP + NF][64];      // [slot][lane]: survivors' LDS slots
-    const int nblk = (m + 63) >> 6;
-    const int blk = xcd_block_id(nblk);
-    if (blk >= nblk) return;
-    const int lane = threadIdx.x;
-    const int t = blk * 64 + lane;
-    const bool valid = t < m;
-    const int tt = valid ? t : m - 1;
-    float qx, qy, qz; int q;
-    if (self_sorted) { const float4 sp = sorted[tt]; q = __float_as_int(sp.w); qx = sp.x; qy = sp.y; qz = sp.z; }   // the query IS that point
-    else { q = qorder ? qorder[tt] : tt; qx = new_xyz[(size_t)q * 3]; qy = new_xyz[(size_t)q * 3 + 1]; qz = new_xyz[(size_t)q * 3 + 2]; }
-    // cloud: the wave's first query's by a scalar search, the (rare) lanes of another cloud search for themselves
-    int seg = segment_of(__builtin_amdgcn_readfirstlane(q), new_offset, b);
-    {
-        const int lo = seg == 0 ? 0 : new_offset[seg - 1];
-        if (q < lo || q >= new_offset[seg]) seg = segment_of(q, new_offset, b);
-    }
-    const int start = seg == 0 ? 0 : offset[seg - 1];
-    const RoitrGrid g = grids[seg];
-    const int* cs = cell_start + (size_t)seg * (GRID_MAX_CELLS + 1);
-    int c0[3];
-    {
-        const float tq[3] = {(qx - g.ox) * g.inv_h, (qy - g.oy) * g.inv_h, (qz - g.oz) * g.inv_h};
-        const int dim[3] = {g.nx, g.ny, g.nz};
-#pragma unroll
-        for (int a = 0; a < 3; ++a) c0[a] = (int)fminf(fmaxf(tq[a], 0.f), (float)(dim[a] - 1));
-    }
-    const int x0 = max(c0[0] - 1, 0), x1 = min(c0[0] + 1, g.nx - 1);
-    const int y0 = max(c0[1] - 1, 0), y1 = min(c0[1] + 1, g.ny - 1);
-    const int z0 = max(c0[2] - 1, 0), z1 = min(c0[2] + 1, g.nz - 1);
-    const int need = nsample + 1;
-    bool fail = false;            // -> retry list
-    bool done = !valid;           // result rows written (or lane idle)
-    unsigned long long todo = __ballot(valid);
-    while (todo) {
-        const int first = __ffsll((long long)todo) - 1;
-        const int seg_f = rl_i(seg, first), cy_f = rl_i(c0[1], first), cz_f = rl_i(c0[2], first);
-        unsigned long long grp = 0ull;
-        bool fits = false;
-        int ux0 = 0, uy0 = 0, uz0 = 0, unx = 1, uny = 1, nrow = 0, total = 0;
-        bool in = false;
-#pragma unroll 1
-        for (int attempt = 0; attempt < 2 && !fits; ++attempt) {
-            const bool mine = ((todo >> lane) & 1ull) && seg == seg_f && (attempt == 0 || (c0[1] == cy_f && c0[2] == cz_f));
-            grp = __ballot(mine);
-            in = mine;
-            ux0 = wave_min_i(mine ? x0 : 1 << 20); const int ux1 = wave_max_i(mine ? x1 : -1);
-            uy0 = wave_min_i(mine ? y0 : 1 << 20); const int uy1 = wave_max_i(mine ? y1 : -1);
-            uz0 = wave_min_i(mine ? z0 : 1 << 20); const int uz1 = wave_max_i(mine ? z1 : -1);
-            unx = ux1 - ux0 + 1; uny = uy1 - uy0 + 1;
-            nrow = uny * (uz1 - uz0 + 1);
-            fits = nrow <= TILE_ROWS && unx <= TILE_W;
-            if (!fits) continue;
-            // grid of the group (wave-uniform copies), row extents: lane i < nrow owns row i
-            const int gny = rl_i(g.ny, first), gnx = rl_i(g.nx, first);
-            const int* csf = cell_start + (size_t)seg_f * (GRID_MAX_CELLS + 1);
-            int rs = 0, len = 0;
-            if (lane < nrow) {
-                const int rb = ((uz0 + lane / uny) * gny + (uy0 + lane % uny)) * gnx;
-                rs = csf[rb + ux0]; len = csf[rb + ux1 + 1] - rs;
-            }
-            const int incl = wave_incl_scan(len, lane);
-            total = rl_i(incl, 63);
-            fits = total <= TILE_STAGE;
-            if (!fits) continue;
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the previous group's lanes are done with the tables (one wave: LDS in order)
-            if (lane < nrow) { roffs[lane] = incl - len; rstab[lane] = rs; }
-            if (lane == nrow) roffs[lane] = 0x7fffffff;
-            // cell_start entries of the staged rows
-            const int w1 = unx + 1;
-            for (int e = lane; e < nrow * w1; e += 64) {
-                const int ri = e / w1, k = e - ri * w1;
-                const int rb = ((uz0 + ri / uny) * gny + (uy0 + ri % uny)) * gnx;
-                cstab[ri][k] = csf[rb + ux0 + k];
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            // the points: slot e <- row(e), all loads of a lane in flight together
-            int src[TILE_STAGE / 64];
-            {
-                int row = 0;
-#pragma unroll
-                for (int u = 0; u < TILE_STAGE / 64; ++u) {
-                    const int e = lane + 64 * u;
-                    while (e >= roffs[row + 1]) ++row;          // rows in ascending slot order; the sentinel ends the walk
-                    src[u] = e < total ? rstab[row] + (e - roffs[row]) : rstab[0];   // slots >= total: never read, filled with a valid point
-                }
-            }
-            float4 pv[TILE_STAGE / 64];
-#pragma unroll
-            for (int u = 0; u < TILE_STAGE / 64; ++u) pv[u] = sorted[src[u]];   // unconditional: a predicated load is waited for at once
-#pragma unroll
-            for (int u = 0; u < TILE_STAGE / 64; ++u) stage[lane + 64 * u] = pv[u];
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        }
-        todo &= ~grp;
-        if (!fits) { fail = fail || in; continue; }   // (cannot happen for a single row of cells unless it holds > 1024 points)
-        if (in) {
-            // ---- radius: guarantee radius of the lane's own 3 x 3 x 3 box, capped by the density radius
-            float dmin = INFINITY;
-            if (x0 > 0) dmin = fminf(dmin, qx - __fmaf_rn((float)x0, g.h, g.ox));
-            if (x1 < g.nx - 1) dmin = fminf(dmin, __fmaf_rn((float)(x1 + 1), g.h, g.ox) - qx);
-            if (y0 > 0) dmin = fminf(dmin, qy - __fmaf_rn((float)y0, g.h, g.oy));
-            if (y1 < g.ny - 1) dmin = fminf(dmin, __fmaf_rn((float)(y1 + 1), g.h, g.oy) - qy);
-            if (z0 > 0) dmin = fminf(dmin, qz - __fmaf_rn((float)z0, g.h, g.oz));
-            if (z1 < g.nz - 1) dmin = fminf(dmin, __fmaf_rn((float)(z1 + 1), g.h, g.oz) - qz);
-            const float dm = dmin - 2e-4f * g.h;
-            int nbox = 0;
-            for (int cz = z0; cz <= z1; ++cz)
-                for (int cy = y0; cy <= y1; ++cy) {
-                    const int ri = (cz - uz0) * uny + (cy - uy0);
-                    nbox += cstab[ri][x1 + 1 - ux0] - cstab[ri][x0 - ux0];
-                }
-            const float vbox = (float)((x1 - x0 + 1) * (y1 - y0 + 1) * (z1 - z0 + 1)) * g.h * g.h * g.h;
-            const float r_est = capped_density_radius(g, qx, qy, qz, want, vbox, nbox);
-            const float tau = dm > 0.f ? fminf(dm, r_est) : 0.f;
-            const float tau2 = tau * tau;
-            // ---- filter the 27 cells out of LDS
-            int cnt = 0;
-            bool over = false;
-            for (int cz = z0; cz <= z1; ++cz)
-                for (int cy = y0; cy <= y1; ++cy) {
-                    const int ri = (cz - uz0) * uny + (cy - uy0);
-                    const int s = cstab[ri][x0 - ux0], e = cstab[ri][x1 + 1 - ux0];
-                    const int base = roffs[ri] - cstab[ri][0];    // sorted position p of this row -> LDS slot base + p
-                    for (int p = s; p < e; p += NF) {
-                        float4 c[NF];
-#pragma unroll
-                        for (int u = 0; u < NF; ++u) c[u] = stage[base + min(p + u, e - 1)];
-#pragma unroll
-                        for (int u = 0; u < NF; ++u) {
-                            const float dd = sqdist3(qx, qy, qz, c[u].x, c[u].y, c[u].z);
-                            if (p + u < e && dd < tau2) { surv[cnt][lane] = (unsigned short)(base + p + u); ++cnt; }
-                        }
-                        over = over || cnt > CAP;
-                        cnt = min(cnt, CAP);
-                    }
-                }
-            bool bad = over || cnt < need;
-            const int my = bad ? 0 : cnt;
-            unsigned key[LC];
-#pragma unroll
-            for (int j = 0; j < LC; ++j) key[j] = 0xFFFFFFFFu;
-            constexpr int NS = 4;
-            for (int j0 = 0; __any(j0 < my); j0 += NS) {
-                int slot[NS];
-#pragma unroll
-                for (int u = 0; u < NS; ++u) slot[u] = surv[min(j0 + u, CAP + NF - 1)][lane];
-                float4 c[NS];
-#pragma unroll
-                for (int u = 0; u < NS; ++u) c[u] = stage[j0 + u < my ? slot[u] : 0];
-#pragma unroll
-                for (int u = 0; u < NS; ++u) {
-                    unsigned k = (__float_as_uint(sqdist3(qx, qy, qz, c[u].x, c[u].y, c[u].z)) & ~63u) | (unsigned)(j0 + u);
-                    k = j0 + u < my ? k : 0xFFFFFFFFu;
-#pragma unroll
-                    for (int v = LC - 1; v > 0; --v) key[v] = umed3(k, key[v - 1], key[v]);   // ascending list: the median IS the shifted / inserted / kept value
-                    key[0] = min(key[0], k);
-                }
-            }
-            // two neighbouring keys with the same upper 26 bits: their order (and an exact tie) is not decided here
-#pragma unroll
-            for (int j = 0; j + 1 < LC; ++j) bad = bad || (j <= nsample && ((key[j] ^ key[j + 1]) < 64u));
-            fail = fail || bad;
-            if (!bad) {
-                float qnx = 0.f, qny = 0.f, qnz = 0.f;
-                if (o.ppf) { const float* qn = o.query_normals + (size_t)q * 3; qnx = qn[0]; qny = qn[1]; qnz = qn[2]; }
-#pragma unroll
-                for (int j = 0; j < LC; ++j) {
-                    if (j < nsample) {
-                        const float4 c = stage[surv[key[j] & 63u][lane]];
-                        const int ci = __float_as_int(c.w);
-                        if (o.idx) o.idx[(size_t)q * nsample + j] = ci;
-                        if (o.dist2) o.dist2[(size_t)q * nsample + j] = sqdist3(qx, qy, qz, c.x, c.y, c.z);
-                        if (j >= 1) {
-                            if (o.group_idx) o.group_idx[(size_t)q * (nsample - 1) + j - 1] = ci;
-                            if (o.ppf) {
-                                const float* pn = o.ref_normals + (size_t)ci * 3;
-                                reinterpret_cast<float4*>(o.ppf)[(size_t)q * (nsample - 1) + j - 1] =
-                                    ppf4(qx, qy, qz, qnx, qny, qnz, c.x, c.y, c.z, pn[0], pn[1], pn[2]);
-                            }
-                        }
-                    }
-                }
-                done = true;
-            }
-        }
-    }
-    if (valid && fail && !done) {
-        const int slot = atomicAdd(retry_count, 1);
-        retry_list[slot] = q;
-    }
 }
 
 // ---------------------------------------------------------------- grid query, one LANE per query
@@ -2055,23 +1645,6 @@ int knnquery_impl(int b, int n, int m, int nsample, const float* xyz, const floa
         knn_lane_kernel<LC><<<min(div_up(m, 256), 1024), 256, 0, stream>>>(m, nsample, b, xyz, new_xyz, offset, new_offset, v.grids, v.cell_start, \
                                                                            v.sorted, o, self_sorted, qorder, cap2, v.retry, retry_count);   \
     } while (0)
-    // ball filter + key chain (knn_ball_kernel<LC, CAP>), then the ring-expanding kernel <LR> in list mode for what it hands over
-#define BALL_CASE(LR, LC, CAPC, WANT)                                                                                        \
-    do {                                                                                                                     \
-        int* retry_count = v.tie_count + 1;                                                                                  \
-        knn_ball_kernel<LC, CAPC><<<xcd_grid(div_up(m, 256)), 256, 0, stream>>>(m, nsample, b, xyz, new_xyz, offset, new_offset, v.grids, \
-                                                                               v.cell_start, v.sorted, o, self_sorted, qorder, WANT, retry_count, v.retry); \
-        knn_lane_kernel<LR><<<min(div_up(m, 256), 1024), 256, 0, stream>>>(m, nsample, b, xyz, new_xyz, offset, new_offset, v.grids, v.cell_start, \
-                                                                           v.sorted, o, self_sorted, qorder, cap2, v.retry, retry_count);   \
-    } while (0)
-#define TILE_CASE(LR, LC, CAPC, WANT)                                                                                        \
-    do {                                                                                                                     \
-        int* retry_count = v.tie_count + 1;                                                                                  \
-        knn_tile_kernel<LC, CAPC><<<xcd_grid(div_up(m, 64)), 64, 0, stream>>>(m, nsample, b, new_xyz, offset, new_offset, v.grids, v.cell_start, \
-                                                                             v.sorted, o, self_sorted, qorder, WANT, retry_count, v.retry); \
-        knn_lane_kernel<LR><<<min(div_up(m, 256), 1024), 256, 0, stream>>>(m, nsample, b, xyz, new_xyz, offset, new_offset, v.grids, v.cell_start, \
-                                                                           v.sorted, o, self_sorted, qorder, cap2, v.retry, retry_count);   \
-    } while (0)
     if (lane_ok && nsample + 1 <= 34) {   // from nsample + 1 = 35 the selection kernels take over
         const int need = nsample + 1;
         const bool exact_k = cap2 == INFINITY && v.retry != nullptr;   // roitr_knn_within (cap2 < inf) stops on the radius: ring kernel
@@ -2083,17 +1656,13 @@ int knnquery_impl(int b, int n, int m, int nsample, const float* xyz, const floa
         // target counts of 1.4 - 2.0 (nsample + 1): 8 - 15 % of the need-18 queries still go to the ring kernel -- the clouds are
         // surface-like, the count inside a radius does not follow the box's volume density -- kNN 12.7 -> 17.4 - 19.9 ms per step).
         // So: need 5..10 only.
-        static const int xsw = getenv("ROITR_KNN_X") ? atoi(getenv("ROITR_KNN_X")) : 56;   // TEMPORARY experiment switch (round 5)
-        static const float xw18 = getenv("ROITR_KNN_W18") ? (float)atof(getenv("ROITR_KNN_W18")) : 32.f;
-        static const float xw10 = getenv("ROITR_KNN_W10") ? (float)atof(getenv("ROITR_KNN_W10")) : 20.f;
-        static const float xw4 = getenv("ROITR_KNN_W4") ? (float)atof(getenv("ROITR_KNN_W4")) : 12.f;
-        if (cap2 < INFINITY && nsample == 1 && dist2 && !idx && !group_idx && (xsw & 8))
+        if (cap2 < INFINITY && nsample == 1 && dist2 && !idx && !group_idx)   // roitr_knn_within: one pass over the ball's cells
             knn_within_kernel<<<xcd_grid(div_up(m, 256)), 256, 0, stream>>>(m, b, new_xyz, new_offset, v.grids, v.cell_start, v.sorted,
                                                                            self_sorted ? nullptr : qorder, cap2, dist2);
         else if (need <= 2) LANE_CASE(2);
-        else if (need <= 4) { if (exact_k && (xsw & 64)) TILE_CASE(4, 5, 24, xw4); else if (exact_k && (xsw & 4)) BALL_CASE(4, 5, 24, xw4); else LANE_CASE(4); }
-        else if (need <= 10) { if (exact_k && (xsw & 16)) TILE_CASE(10, 11, 40, xw10); else if (exact_k && (xsw & 1)) BALL_CASE(10, 11, 40, xw10); else if (exact_k) PREF_CASE(10, 40); else LANE_CASE(10); }
-        else if (need <= 18) { if (exact_k && (xsw & 32)) TILE_CASE(18, 19, 56, xw18); else if (exact_k && (xsw & 2)) BALL_CASE(18, 19, 56, xw18); else LANE_CASE(18); }
+        else if (need <= 4) LANE_CASE(4);
+        else if (need <= 10) { if (exact_k) PREF_CASE(10, 40); else LANE_CASE(10); }
+        else if (need <= 18) LANE_CASE(18);
         else LANE_CASE(34);
     } else if (use_grid && self_sorted && b > 0 && v.qorder && nsample - 1 <= 64) {
         // large k, self queries: workgroup per cell over the LDS-staged neighbourhood; what it cannot decide goes through the
@@ -2110,8 +1679,6 @@ int knnquery_impl(int b, int n, int m, int nsample, const float* xyz, const floa
     } else
 #undef LANE_CASE
 #undef PREF_CASE
-#undef BALL_CASE
-#undef TILE_CASE
     if (!use_grid && nsample + 1 <= 34 && (!ppf || group_idx) && m >= lane_brute_min) {
         // staging chunk: the mean cloud rounded up to 64 points, 64 .. 1024 (a larger cloud takes several chunks)
         int ch = b > 0 ? (int)(((long)n / b + 63) / 64 * 64) : 1024;

@@ -401,6 +401,12 @@ class RIGA_v2(nn.Module):
                 geom, pout, nrm, feats, rot, trans = pack_inputs()
                 ready = torch.cuda.Event()
                 ready.record()
+            # allocated under the pack stream, read by the forward on the current stream (and the engine's geometry stream, which is
+            # joined into it): tell the caching allocator, so that a handle dropped before finish_batch cannot hand these blocks to the
+            # next pack while the forward still reads them
+            for t_ in (geom, pout, nrm, feats, rot, trans):
+                if t_ is not None:
+                    t_.record_stream(torch.cuda.current_stream())
         else:
             geom, pout, nrm, feats, rot, trans = pack_inputs()
         n4 = [self.level_sizes(n)[3] for n in n_all]

@@ -119,3 +119,69 @@ def test_sampling_ahead_of_the_previous_forward_changes_nothing():
         model.inputs_resident = True
         h0, h1 = model.launch_batch(one), model.launch_batch(one)
         _same(model.finish_batch(h0)[0], ref_one[0]); _same(model.finish_batch(h1)[0], ref_one[0])
+
+
+def test_ahead_mode_switch_between_batch_sizes():
+    """Calls of up to 128 pairs run their WHOLE geometry chain ahead of the previous call out of the alternating arenas, larger calls
+    only their first sampling level (engine.cpp AHEAD_MAX_PAIRS): a different arena discipline on either side of the switch.  Calls of
+    130 and 8 pairs mixed, four to six in flight, inputs ordered by event or by stream; 128 and 129 pairs back to back; a big call
+    between two small ones that share an arena.  Every output bit-identical to the same call run alone."""
+    from roitr_amd.synthetic import make_pair
+    from tests.gpu_util import build_model, pair_to_device
+    model = build_model("3DMatch", weights="selective")
+    base = [pair_to_device(make_pair(1024 + 64 * (i % 3), config=2, pair_index=i, normals="field")) for i in range(13)]
+    torch.cuda.synchronize()
+    b8, b130 = base[:8], [base[i % 13] for i in range(130)]
+    b128, b129 = b130[:128], b130[:129]
+    with torch.no_grad():
+        refs = {}
+        for name, b in (("b8", b8), ("b130", b130), ("b128", b128), ("b129", b129)):
+            refs[name] = model.forward_batch(b)
+            torch.cuda.synchronize()
+        plans = [
+            [("b130", True), ("b8", True), ("b130", True), ("b8", True), ("b8", True), ("b130", False)],
+            [("b8", True), ("b130", True), ("b8", True), ("b8", False), ("b130", True), ("b8", True)],
+            [("b128", True), ("b129", True), ("b128", True), ("b129", True)],
+            [("b129", True), ("b128", True), ("b8", True), ("b129", False), ("b128", True)],
+        ]
+        for plan in plans:
+            hs = [(name, model.launch_batch({"b8": b8, "b130": b130, "b128": b128, "b129": b129}[name], inputs_resident=res)) for name, res in plan]
+            for name, h in hs:
+                got = model.finish_batch(h)
+                assert len(got) == len(refs[name])
+                for x, y in zip(got, refs[name]):
+                    _same(x, y)
+
+
+def test_stress_of_calls_in_flight():
+    """scripts/stress_inflight.py as a test: 30 rounds of 8 calls in flight, batch sizes 1 - 12 of clouds of 1024 - 5000 points drawn at
+    random, ground-truth outputs on / off, inputs by event / by stream -- a race between the two streams or a stale arena shows as a
+    bitwise mismatch against the same batch run alone."""
+    import random
+    from roitr_amd.synthetic import make_pair
+    from tests.gpu_util import build_model, pair_to_device
+    keys = KEYS + ("src_node_corr_indices",)
+    rng = random.Random(7)
+    model = build_model("3DMatch", weights="selective")
+    sizes = (1024, 1500, 2048, 3000, 4000, 5000)
+    pool = [pair_to_device(make_pair(sizes[i % len(sizes)], config=2, pair_index=i, normals="field")) for i in range(24)]
+    torch.cuda.synchronize()
+    batches = [[pool[j] for j in rng.sample(range(24), rng.choice((1, 1, 2, 3, 6, 12)))] for _ in range(16)]
+    with torch.no_grad():
+        refs = []
+        for b in batches:
+            refs.append(model.forward_batch(b))
+            torch.cuda.synchronize()
+        bad = []
+        for r in range(30):
+            order = [rng.randrange(len(batches)) for _ in range(8)]
+            hs = [(i, model.launch_batch(batches[i], want_gt=rng.random() < 0.8, inputs_resident=rng.random() < 0.7)) for i in order]
+            for i, h in hs:
+                got = model.finish_batch(h)
+                for x, y in zip(got, refs[i]):
+                    for k in keys:
+                        if k.startswith("gt_") and not h["have_gt"]:
+                            continue
+                        if not torch.equal(x[k], y[k]):
+                            bad.append((r, i, k))
+    assert not bad, bad[:10]

@@ -155,14 +155,14 @@ def test_knn_bit_exact(case, kind, use_grid):
 @pytest.mark.parametrize("kind", ["uniform", "lattice", "dup", "plane", "surface"])
 @pytest.mark.parametrize("case", [
     # (clouds, points per cloud, query = self?, nsample): every case has >= 8192 queries on a grid, i.e. the LANE-per-query kernels
-    # of the batched forward (ball filter + key chain for nsample + 1 <= 18, its retry list -> ring kernel -> replay)
+    # of the batched forward (prefilter for nsample + 1 <= 10, its retry list -> ring kernel, ring kernel alone above, -> replay)
     (4, 5000, True, 9), (4, 5000, True, 17), (8, 1250, True, 17), (3, 5000, False, 17), (9, 1250, False, 17),
     (4, 5000, False, 3), (4, 5000, False, 1), (2, 9000, True, 5), (1, 70000, True, 9),
 ])
 def test_knn_lane_kernels_bit_exact(case, kind):
     """The kernels the engine's 512-pair calls run (one lane per query) against the C oracle: idx and dist2 bit-equal, clouds of
-    slightly different sizes, queries of non-self calls partly outside the reference cloud's box; the 70000-point cloud is beyond
-    the 16-bit survivor positions of knn_ball_kernel (every query takes the retry path)."""
+    slightly different sizes, queries of non-self calls partly outside the reference cloud's box; one 70000-point cloud (more
+    points than a 16-bit position holds, the largest grid)."""
     from roitr_amd import pointops as P
     nc, n, self_q, ns = case
     if kind != "uniform" and n > 9000:

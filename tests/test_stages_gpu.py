@@ -369,9 +369,9 @@ def test_engine_uses_the_table_and_agrees_with_the_gemm_form():
     for k in ("src_node_feats", "tgt_node_feats", "src_point_feats", "tgt_point_feats"):
         assert (out[k] - ref[k]).abs().max().item() < 2e-5, k
     assert torch.equal(out["src_nodes"], ref["src_nodes"])
-    # ROITR_GEO_TABLE_RANGE: a table that ends at 2 units (0.4 m) -- most superpoint distances of the pair then take the direct
+    # ROITR_GEO_TABLE="range=2": a table that ends at 2 units (0.4 m) -- most superpoint distances of the pair then take the direct
     # sin / cos evaluation inside the kernel; the result must not depend on where the table ends
-    os.environ["ROITR_GEO_TABLE_RANGE"] = "2"
+    os.environ["ROITR_GEO_TABLE"] = "range=2"
     try:
         short = build_model("3DMatch")
         si = short.geo_table_info()
@@ -379,7 +379,7 @@ def test_engine_uses_the_table_and_agrees_with_the_gemm_form():
         with torch.no_grad():
             got = short.forward(**pair)
     finally:
-        del os.environ["ROITR_GEO_TABLE_RANGE"]
+        del os.environ["ROITR_GEO_TABLE"]
     for k in ("src_node_feats", "tgt_node_feats", "src_point_feats", "tgt_point_feats"):
         assert (out[k] - got[k]).abs().max().item() < 2e-5, k
 
@@ -398,7 +398,7 @@ def _top_frequency_embedding(sd_np):
     return sd_np
 
 
-@pytest.mark.parametrize("env,expect_h", [({}, 1.0), ({"ROITR_GEO_TABLE_H": "0.5", "ROITR_GEO_TABLE_RANGE": "24"}, 0.5), ({"ROITR_GEO_TABLE": "0"}, None)])
+@pytest.mark.parametrize("env,expect_h", [({}, 1.0), ({"ROITR_GEO_TABLE": "h=0.5,range=24"}, 0.5), ({"ROITR_GEO_TABLE": "0"}, None)])
 def test_function_table_with_top_frequency_weights_against_the_oracle(env, expect_h):
     """the table's acceptance depends on the weights.  With embedding projections that load only the top
     frequency the engine must REJECT the interval of 2 (dense per-channel probe) and take 1; the interval of 0.5 (diagnostic switch)
@@ -435,9 +435,8 @@ def test_function_table_with_top_frequency_weights_against_the_oracle(env, expec
     for k in ("src_nodes", "tgt_nodes"):
         assert np.array_equal(out[k].cpu().numpy(), ref[k])
     for k in ("src_node_feats", "tgt_node_feats", "src_point_feats", "tgt_point_feats"):
-        got = out[k].cpu().numpy()
-        err = float((np.abs(got - ref[k]) / np.maximum(1.0, np.abs(ref[k]))).max())
-        assert err < 1e-4, (k, err)
+        from corr_util import assert_descriptors_close
+        assert_descriptors_close(out[k].cpu().numpy(), ref[k], k)
 
 
 def test_gemm_rows_do_not_depend_on_the_row_count():
