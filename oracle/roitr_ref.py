@@ -435,34 +435,68 @@ def closed_form_state(factor=1, variant="plain"):
 FDMATCH_CFG = {"adaptive": True, "num_est_coarse_corr": 128, "fine_matching_topk": 2}   # configs/test/fdmatch.yaml
 
 
-def timed_baseline(n_points, budget_s=20.0, max_pairs=16, benchmark="3DMatch", seed_config=2, weights="plain", normals="random",
-                   cloud="uniform"):
-    """bench.py cpu_baseline ('port'): full forwards of pairs of the bench workload on this host's cores.
-
-    FPS/kNN run in the C restatement (kNN split over all cores with threads; FPS is inherently serial per
-    cloud), the dense stages in numpy (BLAS threads as configured).  The bounded sample: distinct pairs are run
-    one after the other until `budget_s` seconds of wall time are used (at least one pair, at most `max_pairs`).
-    `stage_ms_per_pair`: wall ms per stage (fps, knn_ppf, encoder, global, decoder, matching), mean over the sample."""
+def _baseline_worker(job):
+    """One worker process of timed_baseline: forwards of its own pairs (index wid, wid + W, ...) back to back for `budget_s` seconds
+    on `threads` cores (C kNN threads; BLAS threads through OMP_NUM_THREADS of the process).  Returns
+    (pairs, correspondences, stage seconds, wall-clock start, wall-clock end)."""
+    wid, workers, threads, n_points, budget_s, max_pairs, benchmark, seed_config, weights, normals, cloud = job
     from roitr_amd.synthetic import make_pair
-    cores = len(os.sched_getaffinity(0))
     fd = benchmark in ("4DMatch", "4DLoMatch")
     sd = closed_form_state(2 if fd else 1, weights)
     cfg = dict(FDMATCH_CFG) if fd else None
-    pairs = 0
-    ncorr = 0
-    dt = 0.0
-    stages = {}
-    while pairs < max_pairs and (pairs == 0 or dt < budget_s):
-        pair = make_pair(n_points, config=seed_config, pair_index=pairs, normals=normals, cloud=cloud)
-        t0 = time.perf_counter()
-        out = forward(sd, pair, cfg=cfg, threads=cores, timings=stages)
-        dt += time.perf_counter() - t0
+    pairs, ncorr, stages = 0, 0, {}
+    t_start = time.time()
+    while pairs < max_pairs and (pairs == 0 or time.time() - t_start < budget_s):
+        pair = make_pair(n_points, config=seed_config, pair_index=wid + workers * pairs, normals=normals, cloud=cloud)
+        out = forward(sd, pair, cfg=cfg, threads=threads, timings=stages)
         ncorr += int(out["corr_scores"].shape[0])
         pairs += 1
-    return {"value": round(pairs / dt, 5), "unit": "pairs/s", "cores": cores, "kind": "port",
+    return pairs, ncorr, stages, t_start, time.time()
+
+
+def timed_baseline(n_points, budget_s=20.0, max_pairs=16, benchmark="3DMatch", seed_config=2, weights="plain", normals="random",
+                   cloud="uniform", workers=None):
+    """bench.py cpu_baseline ('port'): full forwards of pairs of the bench workload on this host's cores, PAIRS IN PARALLEL (round 5;
+    before: one pair at a time with every stage spread over all cores -- 0.32 pairs/s on 256 cores, the serial FPS chain and the
+    numpy stages idling most of them).  `workers` processes (default: cores // 8; own interpreters started with subprocess -- the
+    caller holds a HIP context, which must not be forked) run distinct pairs back to back for `budget_s` seconds, each on 8 cores
+    (C kNN threads, OMP_NUM_THREADS for BLAS): value = pairs of all workers / (last finish - first start of a worker's loop).
+    FPS / kNN in the C restatement, the dense stages in numpy.  `stage_ms_per_pair`: wall ms per stage inside a worker (fps,
+    knn_ppf, encoder, global, decoder, matching), mean over the sample."""
+    import json
+    import subprocess
+    import sys
+    cores = len(os.sched_getaffinity(0))
+    workers = workers or max(1, cores // 8)
+    threads = max(1, cores // workers)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import json, sys; from oracle import roitr_ref as R; "
+            "print('RESULT ' + json.dumps(R._baseline_worker(tuple(json.loads(sys.argv[1])))))")
+    env = dict(os.environ, OMP_NUM_THREADS=str(threads), OPENBLAS_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads))
+    procs = []
+    for w in range(workers):
+        job = [w, workers, threads, n_points, budget_s, max_pairs, benchmark, seed_config, weights, normals, cloud]
+        procs.append(subprocess.Popen([sys.executable, "-c", code, json.dumps(job)], cwd=root, env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.DEVNULL, text=True))
+    res = []
+    for p in procs:
+        out, _ = p.communicate()
+        lines = [ln for ln in out.splitlines() if ln.startswith("RESULT ")]
+        if p.returncode == 0 and lines:
+            res.append(json.loads(lines[-1][7:]))
+    if not res:
+        return {"value": None, "unit": "pairs/s", "cores": cores, "kind": "port", "sample": "unavailable: no baseline worker finished"}
+    wall = max(r[4] for r in res) - min(r[3] for r in res)
+    pairs = sum(r[0] for r in res)
+    ncorr = sum(r[1] for r in res)
+    stages = {}
+    for r in res:
+        for k, v in r[2].items():
+            stages[k] = stages.get(k, 0.0) + v
+    return {"value": round(pairs / wall, 5), "unit": "pairs/s", "cores": cores, "kind": "port", "workers": len(res), "threads_per_worker": threads,
             "stage_ms_per_pair": {k: round(1e3 * v / pairs, 1) for k, v in stages.items()},
-            "sample": f"{pairs} pair(s), N={n_points} pts/cloud, {benchmark} settings, full fp32 forward each, oracle/roitr_ref.py "
-                      f"(numpy fp32 + C FPS/kNN), {dt:.2f} s wall, {ncorr} correspondences"}
+            "sample": f"{pairs} distinct pair(s) on {len(res)} worker process(es) x {threads} cores in parallel, N={n_points} pts/cloud, {benchmark} "
+                      f"settings, full fp32 forward each, oracle/roitr_ref.py (numpy fp32 + C FPS/kNN), {wall:.2f} s wall, {ncorr} correspondences"}
 
 
 def timed_knn_baseline(n_points, k, budget_s=20.0, max_clouds=8):

@@ -62,5 +62,21 @@ def build(force=False, verbose=False):
     return LIB
 
 
+def source_hash():
+    """sha256 (first 16 hex digits) over the kernel and ABI sources (csrc/*, include/*.h, in name order): what profiles/*.json are
+    stamped with when they are collected, and what bench.py checks before it attaches counters from them to a fresh timing."""
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(CSRC, "*")) + glob.glob(os.path.join(os.path.dirname(HERE), "include", "*.h")))
+    for f in files:
+        if os.path.isfile(f):
+            h.update(os.path.basename(f).encode())
+            h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 if __name__ == "__main__":
+    if "--source-hash" in sys.argv:
+        print(source_hash())
+        sys.exit(0)
     print(build(force="--force" in sys.argv, verbose=True))

@@ -566,7 +566,8 @@ extern "C" int roitr_gemm(const RoitrGemm* g, hipStream_t stream)
     if (Tl > 0x7ffffff0L) return ROITR_ERR_UNSUPPORTED;
     const int T = (int)Tl;
     const unsigned grid = (unsigned)xcd_grid(T);
-    roitr_prof_begin2(ROITR_PROF_GEMM, 2.0 * g->M * g->N * (double)g->K * g->batch, roitr_gemm_algorithmic_bytes(g), stream);
+    const int prof_cls = roitr_prof_is_enabled() ? roitr_gemm_prof_class(g) : ROITR_PROF_GEMM;
+    roitr_prof_begin2(prof_cls, 2.0 * g->M * g->N * (double)g->K * g->batch, roitr_gemm_algorithmic_bytes(g), stream);
     // Measured and dropped (A/B on the forward bench): 64x128 / 128x128 multi-accumulator tiles (19.7 / 22.0 vs 16.9 ms of
     // GEMM per 128-pair forward), two K-slabs per barrier pair (7.9 vs 7.5 ms at 32 pairs), and a persistent-block
     // variant that opens the next tile (row pointers + first slab in flight) before the store epilogue (18.3-19.8 vs
@@ -625,7 +626,7 @@ extern "C" int roitr_gemm(const RoitrGemm* g, hipStream_t stream)
         float ms = 0; hipEventElapsedTime(&ms, e0, e1); hipEventDestroy(e0); hipEventDestroy(e1);
         shape_log(g, fast, ms);
     }
-    roitr_prof_end(ROITR_PROF_GEMM, stream);
+    roitr_prof_end(prof_cls, stream);
     ROITR_LAUNCH_CHECK();
     return ROITR_OK;
 }

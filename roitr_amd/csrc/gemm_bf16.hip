@@ -317,7 +317,8 @@ int roitr_gemm_bf16_launch(const RoitrGemm* g, hipStream_t stream)
     const int T = (int)Tl;
     const unsigned grid = (unsigned)xcd_grid(T);
     const bool a_h = (g->bf16 & ROITR_BF16_A) != 0;
-    roitr_prof_begin2(ROITR_PROF_GEMM, 2.0 * g->M * g->N * (double)g->K * g->batch, roitr_gemm_algorithmic_bytes(g), stream);
+    const int prof_cls = roitr_prof_is_enabled() ? roitr_gemm_prof_class(g) : ROITR_PROF_GEMM;
+    roitr_prof_begin2(prof_cls, 2.0 * g->M * g->N * (double)g->K * g->batch, roitr_gemm_algorithmic_bytes(g), stream);
     if (g->ln_gamma) {
         if (a_h) {
             if (tn == 1) gemm_bf16_kernel<false, 1, true><<<grid, 256, 0, stream>>>(*g, nx, ny, T);
@@ -330,7 +331,7 @@ int roitr_gemm_bf16_launch(const RoitrGemm* g, hipStream_t stream)
         }
     } else if (a_h) gemm_bf16_kernel<false, 1, false><<<grid, 256, 0, stream>>>(*g, nx, ny, T);
     else gemm_bf16_kernel<true, 1, false><<<grid, 256, 0, stream>>>(*g, nx, ny, T);
-    roitr_prof_end(ROITR_PROF_GEMM, stream);
+    roitr_prof_end(prof_cls, stream);
     ROITR_LAUNCH_CHECK();
     return ROITR_OK;
 }

@@ -118,7 +118,7 @@ void roitr_prof_begin2(int cls, double bytes, double aux, hipStream_t st)
     // Work issued inside an open engine phase is also booked on the phase: the "bytes" of a phase class are the FLOPs of its
     // GEMM / geo_embed launches (bench.py prices the global-transformer phase against the MFMA peak with them), its "aux" the
     // algorithmic HBM bytes of every instrumented launch inside it (MFMA classes carry them in aux, the others in bytes)
-    const bool mfma = cls == ROITR_PROF_GEMM || cls == ROITR_PROF_GEO_EMBED;
+    const bool mfma = cls == ROITR_PROF_GEMM || cls == ROITR_PROF_GEMM_HBM || cls == ROITR_PROF_GEO_EMBED;
     const bool phase = cls >= ROITR_PROF_PH_GEOM && cls <= ROITR_PROF_PH_FORWARD;
     if (!phase && cls != ROITR_PROF_GEO_ALGO)
         for (auto& o : g_open)
@@ -161,4 +161,11 @@ double roitr_gemm_algorithmic_bytes(const RoitrGemm* g)
     if (g->ln_res) per += M * N * 4.0;
     if (g->ln_post) per += M * N * 4.0;
     return per * g->batch;
+}
+
+int roitr_gemm_prof_class(const RoitrGemm* g)
+{
+    const double flops = 2.0 * g->M * g->N * (double)g->K * g->batch;
+    const double balance = (g->bf16 & ROITR_BF16_W) ? 2500.0 / 8.0 : 157.3 / 8.0;   // peak FLOP/s over peak HBM bytes/s (MI355X_MICROARCH.md)
+    return flops < balance * roitr_gemm_algorithmic_bytes(g) ? ROITR_PROF_GEMM_HBM : ROITR_PROF_GEMM;
 }

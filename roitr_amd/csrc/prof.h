@@ -3,7 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
-#define ROITR_PROF_CLASSES 18
+#define ROITR_PROF_CLASSES 19
 enum {
     ROITR_PROF_FPS = 0,        // fps_kernel, one launch
     ROITR_PROF_KNN = 1,        // knn_grid_kernel / knn_brute_kernel (the query kernel incl. fused PPF), one launch
@@ -22,7 +22,9 @@ enum {
     ROITR_PROF_GEO_EMBED = 14, // geo_embed_kernel (GEMM form): "bytes" carries FLOPs
     ROITR_PROF_GEO_TABLE = 15, // geo_table_kernel: HBM bytes
     ROITR_PROF_GEO_ALGO = 16,  // no time: the FLOPs the GEMM form of the embedding would have spent on the rows geo_table_kernel served
-    ROITR_PROF_LOCAL_BLOCK = 17 // local_block_kernel: "bytes" = HBM bytes, aux = the FLOPs of its three on-chip GEMMs
+    ROITR_PROF_LOCAL_BLOCK = 17,// local_block_kernel: "bytes" = HBM bytes, aux = the FLOPs of its three on-chip GEMMs
+    ROITR_PROF_GEMM_HBM = 18   // gemm_kernel launches whose roof is HBM: algorithmic FLOPs per algorithmic byte below the machine balance
+                               // (roitr_gemm_prof_class); same fields as ROITR_PROF_GEMM, which keeps the MFMA-roofed launches
 };
 
 void roitr_prof_begin(int cls, double bytes, hipStream_t st);
@@ -40,3 +42,6 @@ extern "C" int roitr_prof_read_aux(int cls, double* aux);
 // larger tensor count as read once each, a ragged batch is priced at its bounding M x N).  bench.py `roofline` of gemm_kernel.
 struct RoitrGemm;
 double roitr_gemm_algorithmic_bytes(const RoitrGemm* g);
+// ROITR_PROF_GEMM (MFMA-roofed) or ROITR_PROF_GEMM_HBM: 2 M N K over the algorithmic bytes against peak FLOP/s over peak HBM bytes/s of
+// the operand dtype (fp32: 157.3 T / 8 T = 19.7 FLOP per byte; bf16 operands: 2500 / 8 = 312)
+int roitr_gemm_prof_class(const RoitrGemm* g);

@@ -10,7 +10,9 @@ P="python bench.py --config 5 --steps 3 --warmup 1 --no-cpu-baseline"
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVES \
     --output-format csv -d $out/a -o s -- $P > $out/a.log 2>&1
 python - $out <<'PY'
-import csv, collections, glob, json, re, sys
+import csv, collections, glob, json, os, re, sys
+sys.path.insert(0, os.getcwd())
+from roitr_amd.build import source_hash
 out = sys.argv[1]
 t = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.defaultdict(int); dur = collections.defaultdict(float)
 for f in glob.glob(out + "/a/**/*counter_collection.csv", recursive=True):
@@ -21,7 +23,7 @@ for f in glob.glob(out + "/a/**/*counter_collection.csv", recursive=True):
             n[k] += 1
             dur[k] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-9
 clouds, npts = 32, 30000
-res = {"clouds": clouds, "n_points": npts, "k": 64, "source": "rocprofv3 --kernel-trace --pmc SQ_* (scripts/knn_config5_sq.sh), per launch averages",
+res = {"clouds": clouds, "n_points": npts, "k": 64, "kernel_source_sha16": source_hash(), "source": "rocprofv3 --kernel-trace --pmc SQ_* (scripts/knn_config5_sq.sh), per launch averages",
        "definition": "valu_issue_frac = SQ_INSTS_VALU * 2 cycles / (launch duration * 2.4 GHz * 1024 SIMDs)", "kernels": {}}
 for k, v in t.items():
     if not (k.startswith("knn_") or k.startswith("grid_build")) or not n[k]:

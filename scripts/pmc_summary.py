@@ -7,7 +7,9 @@
 Units / corrections follow /opt/skills/guides/MI355X_MICROARCH.md "HBM [CDNA4]": FETCH_SIZE and WRITE_SIZE are
 reported in KiB-ish units of 1024 B; on gfx950 FETCH_SIZE tallies 128-B requests at 64 B, so it is DOUBLED for wide
 coalesced reads (all our streaming kernels use 16 B/lane loads).  WRITE_SIZE is taken as reported (uncalibrated)."""
-import collections, csv, json, re, sys
+import collections, csv, json, os, re, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from roitr_amd.build import source_hash
 
 def load(path, counter):
     tot = collections.defaultdict(float); n = collections.defaultdict(int)
@@ -24,7 +26,7 @@ f, fn = load(sys.argv[1], "FETCH_SIZE")
 w, wn = load(sys.argv[2], "WRITE_SIZE")
 steps = int(sys.argv[5]) if len(sys.argv) > 5 else None
 out = {"pairs_per_step": int(sys.argv[4]) if len(sys.argv) > 4 else None, "baseline_config": int(sys.argv[6]) if len(sys.argv) > 6 else 2,
-       "forwards_profiled": steps,
+       "forwards_profiled": steps, "kernel_source_sha16": source_hash(),
        "note": "bytes per launch; fetch = FETCH_SIZE*1024*2 (gfx950 half-count correction), write = WRITE_SIZE*1024", "kernels": {}}
 for k in sorted(f, key=lambda k: -f[k]):
     if k.startswith("__amd") or "at::" in k:

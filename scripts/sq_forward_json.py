@@ -8,7 +8,11 @@ import csv
 import glob
 import json
 import re
+import os
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from roitr_amd.build import source_hash
 
 
 def main(src, dst):
@@ -23,7 +27,7 @@ def main(src, dst):
             if r["Counter_Name"] == "SQ_WAVES":
                 n[k] += 1
                 dur[k] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-9
-    res = {"source": "rocprofv3 --kernel-trace --pmc SQ_* (scripts/sq_pass.sh pass a; kernels serialised by the counter collection)",
+    res = {"kernel_source_sha16": source_hash(), "source": "rocprofv3 --kernel-trace --pmc SQ_* (scripts/sq_pass.sh pass a; kernels serialised by the counter collection)",
            "definition": "valu_issue_frac = SQ_INSTS_VALU * 2 cycles / (kernel time * 2.4 GHz * 1024 SIMDs)", "kernels": {}}
     for k, v in sorted(t.items(), key=lambda kv: -dur[kv[0]]):
         if not n[k] or dur[k] <= 0 or "rocclr" in k or "at::native" in k:

@@ -66,9 +66,17 @@ def test_whole_forward_entry():
     assert b.whole_forward(_prof(), 1, "f32", 111.7, None)["executed_flops_per_step"] == int(4.51e12)
 
 
-def test_traffic_is_attached_from_the_committed_pmc_summary():
+def test_traffic_is_attached_from_the_committed_pmc_summary(monkeypatch):
     b = _bench()
+    from roitr_amd import build
     pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+    # counters ride on a timing only when they were collected from the SAME kernel sources (stamp of scripts/pmc_summary.py):
+    # another build's counters leave `traffic` null and say why
+    stale = b.rooflines(_prof(), 1, "f32")
+    monkeypatch.setattr(build, "source_hash", lambda: "0123456789abcdef")
+    assert b.attach_traffic(stale, pmc["pairs_per_step"], pmc.get("baseline_config", 2)) is None
+    assert stale[0]["traffic"] is None and "re-collect" in stale[0]["traffic_note"]
+    monkeypatch.setattr(build, "source_hash", lambda: pmc.get("kernel_source_sha16"))
     roofs = b.rooflines(_prof(), 1, "f32")
     b.attach_traffic(roofs, pmc["pairs_per_step"], pmc.get("baseline_config", 2))
     # the instrumented class spans both kernels of csrc/gemm.hip: launch-weighted mean, the same launch set as `achieved`
