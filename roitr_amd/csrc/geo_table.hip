@@ -16,11 +16,12 @@
 // amplitude: no 256-term accumulation).  A value outside the tabulated range (a superpoint pair further apart than
 // n_int_d * h * sigma_d) takes a direct sin / cos evaluation in the kernel, so the result is defined for any input.
 //
-// Layout: table[slice = C/64][interval (n_int_d distance intervals, then n_int_a angle intervals)][coef 0..7][64 channels].
-// A workgroup owns one 64-channel slice (its table slice stays in LDS: 2 KB per interval) and walks 64-row chunks; inside a
-// chunk lane = channel, so the interval index / local coordinate of a row are wave-uniform (v_readlane), the 8 coefficient
-// reads of an evaluation are conflict-free stride-1 LDS reads (ds_read2st64_b32) and the store of a row slice is one
-// contiguous 256-byte line.  Bound: LDS bytes (4 evaluations x 8 coefficients per output) and the HBM write of E.
+// Layout: table[slice = C/64][interval (n_int_d distance intervals, then n_int_a angle intervals)][half: coefs 0..3 | 4..7][64
+// channels][4 coefs].  A workgroup owns one 64-channel slice (its table slice stays in LDS: 2 KB per interval) and walks 64-row
+// chunks; inside a chunk lane = channel, so the interval index / local coordinate of a row are wave-uniform (v_readlane), the 8
+// coefficients of an evaluation are two conflict-free ds_read_b128 (round 5; before: [coef][channel] and four
+// ds_read2st64_b32 at half the LDS rate) and the store of a row slice is one contiguous 256-byte line.  Bound: LDS bytes
+// (4 evaluations x 8 coefficients per output) and the HBM write of E.
 #include "common.h"
 #include <mutex>
 #include "prof.h"
@@ -64,16 +65,19 @@ __device__ __noinline__ float geo_direct(float x, const float* __restrict__ W, c
     return acc + bias[col];
 }
 
-__device__ __forceinline__ float poly8(const float* __restrict__ p, float t)
+// p = the lane's float4 slot of the interval's low half (coefficients 0..3); the high half (4..7) lies CS float4 further on.
+// Two ds_read_b128 per evaluation (consecutive lanes, consecutive 16-byte slots: conflict-free at 256 B per clock) instead of
+// four ds_read2st64_b32 at 128 B per clock -- round 5: the kernel is bound by these reads.  Same Horner order: same bits.
+__device__ __forceinline__ float poly8(const float4* __restrict__ p, float t)
 {
-    const float c0 = p[0], c1 = p[CS], c2 = p[2 * CS], c3 = p[3 * CS], c4 = p[4 * CS], c5 = p[5 * CS], c6 = p[6 * CS], c7 = p[7 * CS];
-    float a = fmaf(c7, t, c6);
-    a = fmaf(a, t, c5);
-    a = fmaf(a, t, c4);
-    a = fmaf(a, t, c3);
-    a = fmaf(a, t, c2);
-    a = fmaf(a, t, c1);
-    return fmaf(a, t, c0);
+    const float4 lo = p[0], hi = p[CS];
+    float a = fmaf(hi.w, t, hi.z);
+    a = fmaf(a, t, hi.y);
+    a = fmaf(a, t, hi.x);
+    a = fmaf(a, t, lo.w);
+    a = fmaf(a, t, lo.z);
+    a = fmaf(a, t, lo.y);
+    return fmaf(a, t, lo.x);
 }
 
 // value -> (table interval or -1, local coordinate in [-1, 1))
@@ -107,7 +111,7 @@ __device__ __forceinline__ void geo_table_body(const GeoTableArgs& g)
     }
     __syncthreads();
     const int col = slice * CS + lane;
-    const float* tl = tab + lane;
+    const float4* tl = reinterpret_cast<const float4*>(tab) + lane;
     const long nchunks = (g.rows + 63) >> 6;
     for (long q = (long)blockIdx.y * nwaves + wave; q < nchunks; q += (long)gridDim.y * nwaves) {
         const long row0 = q << 6, row = row0 + lane;
@@ -132,19 +136,19 @@ __device__ __forceinline__ void geo_table_body(const GeoTableArgs& g)
             const float st2 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(t2), e));
             float vd, v0, v1, v2;
             if (__builtin_expect((sjd | sj0 | sj1 | sj2) >= 0, 1)) {
-                vd = poly8(tl + sjd * (NCOEF * CS), std_);
-                v0 = poly8(tl + sj0 * (NCOEF * CS), st0);
-                v1 = poly8(tl + sj1 * (NCOEF * CS), st1);
-                v2 = poly8(tl + sj2 * (NCOEF * CS), st2);
+                vd = poly8(tl + sjd * (2 * CS), std_);
+                v0 = poly8(tl + sj0 * (2 * CS), st0);
+                v1 = poly8(tl + sj1 * (2 * CS), st1);
+                v2 = poly8(tl + sj2 * (2 * CS), st2);
             } else {   // some value of this row lies outside its table (wave-uniform branch)
                 const float sxd = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(xd), e));
                 const float sx0 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(xa0), e));
                 const float sx1 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(xa1), e));
                 const float sx2 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(xa2), e));
-                vd = sjd >= 0 ? poly8(tl + sjd * (NCOEF * CS), std_) : geo_direct(sxd, g.Wd, g.bd, g.div, g.C, col);
-                v0 = sj0 >= 0 ? poly8(tl + sj0 * (NCOEF * CS), st0) : geo_direct(sx0, g.Wa, g.ba, g.div, g.C, col);
-                v1 = sj1 >= 0 ? poly8(tl + sj1 * (NCOEF * CS), st1) : geo_direct(sx1, g.Wa, g.ba, g.div, g.C, col);
-                v2 = sj2 >= 0 ? poly8(tl + sj2 * (NCOEF * CS), st2) : geo_direct(sx2, g.Wa, g.ba, g.div, g.C, col);
+                vd = sjd >= 0 ? poly8(tl + sjd * (2 * CS), std_) : geo_direct(sxd, g.Wd, g.bd, g.div, g.C, col);
+                v0 = sj0 >= 0 ? poly8(tl + sj0 * (2 * CS), st0) : geo_direct(sx0, g.Wa, g.ba, g.div, g.C, col);
+                v1 = sj1 >= 0 ? poly8(tl + sj1 * (2 * CS), st1) : geo_direct(sx1, g.Wa, g.ba, g.div, g.C, col);
+                v2 = sj2 >= 0 ? poly8(tl + sj2 * (2 * CS), st2) : geo_direct(sx2, g.Wa, g.ba, g.div, g.C, col);
             }
             const float val = vd + fmaxf(v0, fmaxf(v1, v2));
             const size_t o = (size_t)(row0 + e) * g.C + col;
@@ -225,7 +229,7 @@ extern "C" int roitr_geo_table_build(int C, const float* div_term, const float* 
                 double s = 0.0;
                 for (int m = p; m < NCOEF; ++m) s += a[m] * tm[m][p];
                 mono[(size_t)p * C + c] = s;
-                table[(((size_t)(c / CS) * nint + J) * NCOEF + p) * CS + (c % CS)] = (float)s;
+                table[((((size_t)(c / CS) * nint + J) * 2 + p / 4) * CS + (c % CS)) * 4 + (p % 4)] = (float)s;
             }
         }
         for (int pi = 0; pi < NPROBE; ++pi) {

@@ -1252,9 +1252,15 @@ __global__ __launch_bounds__(256) void knn_lane_kernel(int m, int nsample, int b
                                                        int self_sorted, const int* __restrict__ qorder, float cap2,
                                                        const int* __restrict__ list, const int* __restrict__ list_count)
 {
-  // list mode (list != nullptr): the queries knn_prefilter_kernel could not decide, *list_count of them, grid-stride
+  // list mode (list != nullptr): the queries knn_prefilter_kernel could not decide, *list_count of them, grid-stride.
+  // Otherwise one query per thread, launched with xcd_grid(blocks): every XCD takes a contiguous eighth of the cell order, so a
+  // cloud's sorted points are fetched into ONE L2 (round 5; blocks b, b + 1, ... of the plain order land on 8 different XCDs and
+  // every L2 pulled every cloud).
   const int total = list ? *list_count : m;
-  for (int t = blockIdx.x * 256 + threadIdx.x; t < total; t += gridDim.x * 256) {
+  const int nblk_ = (m + 255) >> 8;
+  const int blk0 = list ? (int)blockIdx.x : xcd_block_id(nblk_);
+  if (!list && blk0 >= nblk_) return;
+  for (int t = blk0 * 256 + threadIdx.x; t < total; t += gridDim.x * 256) {
     const int q = list ? list[t] : (self_sorted ? __float_as_int(sorted[t].w) : (qorder ? qorder[t] : t));
     int lo = 0, hi = b - 1;
     while (lo < hi) { const int mid = (lo + hi) >> 1; if (q < new_offset[mid]) hi = mid; else lo = mid + 1; }
@@ -1633,7 +1639,7 @@ int knnquery_impl(int b, int n, int m, int nsample, const float* xyz, const floa
         else sort_queries_kernel<GRID_MAX_CELLS><<<b, 1024, 0, stream>>>(new_xyz, new_offset, v.grids, qorder);
     }
 #define LANE_CASE(LC)                                                                                                        \
-    knn_lane_kernel<LC><<<div_up(m, 256), 256, 0, stream>>>(m, nsample, b, xyz, new_xyz, offset, new_offset, v.grids, v.cell_start, \
+    knn_lane_kernel<LC><<<xcd_grid(div_up(m, 256)), 256, 0, stream>>>(m, nsample, b, xyz, new_xyz, offset, new_offset, v.grids, v.cell_start, \
                                                              v.sorted, o, self_sorted, qorder, cap2, nullptr, nullptr)
     // prefilter kernel + the ring-expanding kernel in list mode for what it hands over (a fixed grid-stride launch: the count
     // lives on the device)

@@ -24,7 +24,7 @@ def _exact(x, div, w, b):
 
 
 def _horner(table, n_int, x, h, base):
-    T = table.reshape(C // 64, n_int, 8, 64)
+    T = table.reshape(C // 64, n_int, 2, 64, 4).transpose(0, 1, 2, 4, 3).reshape(C // 64, n_int, 8, 64)   # [half][channel][4] -> [coef][channel]
     x = x.astype(np.float32)
     u = x * np.float32(1.0 / h)
     fl = np.floor(u)
