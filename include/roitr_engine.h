@@ -173,6 +173,8 @@ typedef struct RoitrLocalAttnFold {
     float* xbar;                  /* (M, 4 * in_dim) */
     float* vpart;                 /* (M, H) */
     const void* node_order;       /* optional float4[M]: visiting order */
+    int ldqt;                     /* row stride of qt in floats; 0 = dense (4 * in_dim).  Lets q and q~ be the two column blocks of ONE
+                                   * GEMM's output (engine, round 5: q~_h = (Wk'_h^T Wq'_h) x + Wk'_h^T bq_h straight from the input row) */
 } RoitrLocalAttnFold;
 int roitr_local_attention_fold(const RoitrLocalAttnFold* a, roitr_stream_t stream);
 int roitr_local_attention_fold_supported(int in_dim, int H, int K);

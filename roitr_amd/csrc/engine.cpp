@@ -57,6 +57,9 @@ struct LocalT {  // LocalPPFTransformer (+ derived weights)
     // b' = Wqkv b_in + bqkv -- in_proj and the q/k/v projections are two linear maps with nothing in between
     float* wqkv_x = nullptr; float* bqkv_x = nullptr; unsigned short* wqkv_x_b = nullptr;
     float* wkT_x = nullptr;                        // (in_dim, H): transpose of the k rows of wqkv_x (TransitionDown fold, fp32)
+    // TransitionDown fold at in_dim = 64 (round 5): q AND q~ from one GEMM over the gathered input rows --
+    // rows 0 .. H-1 = Wq' (q = Wq' x + bq), rows H + h in_dim + i = (Wk'_h^T Wq'_h)[i, :] (q~_h = Wk'_h^T q_h); ((H + 4 in_dim), in_dim)
+    float* wqqt_x = nullptr; float* bqqt_x = nullptr;
     // block transformers in fp32: linear(att) + in_proj(x) as ONE GEMM over the K-concatenated operand [att | x]:
     // wcat = [Wlin | Win] (H x (H + in_dim)), bcat = b_lin + b_in; f = in_proj(x) is then never materialised
     float* wcat = nullptr; float* bcat = nullptr;
@@ -366,6 +369,26 @@ int fold_local(Engine& E, LocalT& L, hipStream_t st)
             L.wkT_x = A.get<float>((size_t)I * H);
             if (A.fail) return ROITR_ERR_ARG;
             CHK(roitr_transpose(H, I, L.wqkv_x + (size_t)(H + NQ) * I, I, L.wkT_x, H, st));
+            if (I == 64) {
+                // q~_h = Wk'_h^T (Wq'_h x + bq_h): one (H + 4 I) x I weight instead of the q GEMM followed by the batched q~ GEMM --
+                // at I = 64 those were 1.42 + 1.19 ms per 512-pair step for 2 GB of q / q~ rows (two launches of K = 64 / K = 32);
+                // wider inputs keep the two-step form (the folded weight has (H + 4 I) I entries against H I + H I / 4: more FLOPs
+                // than the launch saves from I = 128 on)
+                const int c = H / HEADS, R2 = H + HEADS * I;
+                float* wqT = A.get<float>((size_t)I * H);
+                L.wqqt_x = A.get<float>((size_t)R2 * I);
+                L.bqqt_x = A.get<float>(R2);
+                if (A.fail) return ROITR_ERR_ARG;
+                CHK(roitr_transpose(H, I, L.wqkv_x, I, wqT, H, st));                                  // (I, H): q rows transposed
+                CHK(d2d(st, L.wqqt_x, L.wqkv_x, sizeof(float) * (size_t)H * I));
+                CHK(d2d(st, L.bqqt_x, L.bqkv_x, sizeof(float) * H));
+                for (int h = 0; h < HEADS; ++h) {
+                    // (Wk'_h^T Wq'_h)[i', i] = sum_c wkT[i', h c + c] wqT[i, h c + c]
+                    CHK(gemm(st, I, I, c, L.wkT_x + (size_t)h * c, H, wqT + (size_t)h * c, H, nullptr, L.wqqt_x + (size_t)(H + h * I) * I, I));
+                    // (Wk'_h^T bq_h)[i'] = sum_c bq[h c + c] wkT[i', h c + c]
+                    CHK(gemm(st, 1, I, c, L.bqkv_x + (size_t)h * c, c, L.wkT_x + (size_t)h * c, H, nullptr, L.bqqt_x + H + (size_t)h * I, I));
+                }
+            }
         }
         if (E.cfg.operand_dtype == 1) {
             L.wqkv_x_b = A.get<unsigned short>((size_t)R * I);
@@ -451,6 +474,21 @@ int local_transformer(Engine& E, hipStream_t st, const LocalT& L, int N_in, cons
         float* hid = A.get<float>((size_t)M * H);
         float* y = A.get<float>((size_t)M * H);
         if (A.fail) { roitr_set_error("arena exhausted (TransitionDown fold)", __FILE__, __LINE__); return ROITR_ERR_ARG; }
+        const float* qe_r = qe; const float* qt_r = qt; int ldq_r = H, ldqt_r = 0;
+        float* xg = nullptr;   // x[node_idx] as a dense (M, I) tensor (the single-GEMM form below)
+        if (L.wqqt_x) {   // q | q~ as the two column blocks of one GEMM over the gathered input rows (fold_local)
+            const int R2 = H + HEADS * I;
+            float* qq = A.get<float>((size_t)M * R2);
+            if (A.fail) { roitr_set_error("arena exhausted (TransitionDown fold)", __FILE__, __LINE__); return ROITR_ERR_ARG; }
+            // the node rows are gathered ONCE (M x 64 floats) instead of by every column tile of the GEMM: a row gather inside the
+            // GEMM is an index load in front of every tile's first slab, and K = 64 has two slabs to hide it behind -- the gathered
+            // K = 64 launches ran at 0.7 - 1 TB/s (round 4: 0.95 ms for f = in_proj(x[node_idx]); round 5: 2.3 ms for this one)
+            xg = A.get<float>((size_t)M * I);
+            if (A.fail) { roitr_set_error("arena exhausted (TransitionDown fold)", __FILE__, __LINE__); return ROITR_ERR_ARG; }
+            CHK(roitr_gather_rows(M, I, x, node_idx, 0, xg, st));
+            CHK(gemm(st, M, R2, I, xg, I, L.wqqt_x, I, L.bqqt_x, qq, R2));
+            qe_r = qq; qt_r = qq + H; ldq_r = R2; ldqt_r = R2;
+        } else {
         CHK(gemm(st, M, H, I, x, I, L.wqkv_x, I, L.bqkv_x, qe, H, false, node_idx));
         {   // qt[(row, h), :] = Wk'_h^T q_h   (batched over heads; no bias: q_h . bk'_h is constant over the neighbours)
             RoitrGemm gq; memset(&gq, 0, sizeof(gq));
@@ -458,9 +496,10 @@ int local_transformer(Engine& E, hipStream_t st, const LocalT& L, int N_in, cons
             gq.C = qt; gq.ldc = HEADS * I; gq.batch = HEADS; gq.sA = c; gq.sW = c; gq.sC = I;
             CHK(roitr_gemm(&gq, st));
         }
+        }
         RoitrLocalAttnFold a;
         memset(&a, 0, sizeof(a));
-        a.M = M; a.in_dim = I; a.H = H; a.x = x; a.ldx = I; a.q = qe; a.ldq = H; a.qt = qt; a.group_idx = group; a.ppf = ppf;
+        a.M = M; a.in_dim = I; a.H = H; a.x = x; a.ldx = I; a.q = qe_r; a.ldq = ldq_r; a.qt = qt_r; a.ldqt = ldqt_r; a.group_idx = group; a.ppf = ppf;
         a.wpe = L.wpe; a.wvpe = L.wvpe; a.bvpe = L.bvpe; a.scale = 1.0f / sqrtf((float)c); a.xbar = xbar; a.vpart = vpart; a.node_order = order;
         CHK(roitr_local_attention_fold(&a, st));
         {   // val[:, h-slice] = Wv'_h xbar_h + bv'_h
@@ -472,7 +511,8 @@ int local_transformer(Engine& E, hipStream_t st, const LocalT& L, int N_in, cons
         // linear(att) + f -> LayerNorm, att = vpart + val (the sum is formed while the operand is staged)
         if (td_cat) {   // LN([vpart + val | x[node_idx]] [Wlin | Win]^T + b_lin + b_in)
             Lin lc; lc.w = L.wcat; lc.b = L.bcat; lc.out = H; lc.in = H + I;
-            CHK(gemm_ln(st, M, vpart, lc, nullptr, nullptr, L.norm_w, L.norm_b, nullptr, false, hid, y, 0, x, I, H, val, nullptr, node_idx));
+            CHK(gemm_ln(st, M, vpart, lc, nullptr, nullptr, L.norm_w, L.norm_b, nullptr, false, hid, y, 0, xg ? xg : x, I, H, val, nullptr,
+                        xg ? nullptr : node_idx));
         } else
         CHK(gemm_ln(st, M, vpart, L.lin, f, nullptr, L.norm_w, L.norm_b, nullptr, false, hid, y, 0, nullptr, 0, 0, val));
         if (bn2_res) {

@@ -318,7 +318,35 @@ __global__ __launch_bounds__(256) void gemm_kernel(RoitrGemm g, int nx, int ny, 
 #pragma unroll
                 for (int i = 0; i < TN; ++i) { fn0[i] = a0[lane + 64 * i]; fn1[i] = a1[lane + 64 * i]; fn2[i] = a2[lane + 64 * i]; }
             }
-            for (int rl = wave; rl < RP; rl += 4) {
+            // residual / post-add rows of the wave's next HB rows requested up front (round 5): inside the row loop every row waited
+            // for its own round trip behind two wave reductions -- the LayerNorm launches of levels 1 - 2 ran at 2 TB/s.  Eight rows
+            // at a time: all sixteen cost the 128-column kernel its fourth wave per SIMD (132 VGPRs).
+            constexpr int RW = RP / 4, HB = TN == 4 ? 2 : (RW > 8 ? 8 : RW);
+            float resv[HB][TN], postv[HB][TN];
+#pragma unroll 1
+            for (int u0 = 0; u0 < RW; u0 += HB) {
+                if (g.ln_res || g.ln_post) {
+#pragma unroll
+                    for (int w = 0; w < HB; ++w) {
+                        const int row_ = m0 + pass * RP + wave + 4 * (u0 + w);
+#pragma unroll
+                        for (int i = 0; i < TN; ++i) { resv[w][i] = 0.f; postv[w][i] = 0.f; }
+                        if (row_ < g.M) {
+                            if (g.ln_res) {
+                                const float* rr = g.ln_res + (size_t)(g.ln_res_idx ? g.ln_res_idx[row_] : row_) * TBN;
+#pragma unroll
+                                for (int i = 0; i < TN; ++i) resv[w][i] = rr[lane + 64 * i];
+                            }
+                            if (g.ln_post) {
+#pragma unroll
+                                for (int i = 0; i < TN; ++i) postv[w][i] = g.ln_post[(size_t)row_ * TBN + lane + 64 * i];
+                            }
+                        }
+                    }
+                }
+#pragma unroll
+              for (int w_ = 0; w_ < HB; ++w_) {
+                const int rl = wave + 4 * (u0 + w_);
                 const int row = m0 + pass * RP + rl;
                 if (row >= g.M) break;   // wave-uniform
                 float fc0[TN], fc1[TN], fc2[TN];
@@ -338,13 +366,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(RoitrGemm g, int nx, int ny, 
                         for (int i = 0; i < TN; ++i) { fn0[i] = a0[lane + 64 * i]; fn1[i] = a1[lane + 64 * i]; fn2[i] = a2[lane + 64 * i]; }
                     }
                 }
-                const float* rr = g.ln_res ? g.ln_res + (size_t)(g.ln_res_idx ? g.ln_res_idx[row] : row) * TBN : nullptr;
                 float t[TN];
                 float s_ = 0.f;
 #pragma unroll
                 for (int i = 0; i < TN; ++i) {
                     t[i] = tile_[rl * (TBN + 1) + lane + 64 * i];
-                    if (rr) t[i] += rr[lane + 64 * i];
+                    if (g.ln_res) t[i] += resv[w_][i];
                     s_ += t[i];
                 }
                 const float mean = wave_sum(s_) / (float)TBN;
@@ -355,7 +382,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(RoitrGemm g, int nx, int ny, 
 #pragma unroll
                 for (int i = 0; i < TN; ++i) {
                     float y = (t[i] - mean) * rstd * gam[i] + bet[i];
-                    if (g.ln_post) y += g.ln_post[(size_t)row * TBN + lane + 64 * i];
+                    if (g.ln_post) y += postv[w_][i];
                     if (g.ln_relu) y = fmaxf(y, 0.f);
                     if (g.ip_feat) {   // TransitionUp: + three-nearest-neighbour interpolation, after the activation
                         float acc = 0.f;
@@ -364,6 +391,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(RoitrGemm g, int nx, int ny, 
                     }
                     C[(size_t)row * g.ldc + lane + 64 * i] = y;
                 }
+              }
             }
         }
         return;

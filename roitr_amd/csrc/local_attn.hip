@@ -345,7 +345,7 @@ __global__ __launch_bounds__(256) void local_attn_fold_kernel(RoitrLocalAttnFold
     for (int n = 0; n < NPW; ++n) {
         g[n] = a.group_idx[(size_t)node[n] * K + i16];
 #pragma unroll
-        for (int hh = 0; hh < 4; ++hh) VecLoad<V>::ld(a.qt + ((size_t)node[n] * 4 + hh) * I + lane * V, qt[n][hh]);
+        for (int hh = 0; hh < 4; ++hh) VecLoad<V>::ld(a.qt + (size_t)node[n] * (a.ldqt ? a.ldqt : 4 * I) + hh * I + lane * V, qt[n][hh]);
         VecLoad<HQ>::ld(a.q + (size_t)node[n] * a.ldq + lane * HQ, qv[n]);
         pf[n] = reinterpret_cast<const float4*>(a.ppf)[(size_t)node[n] * K + kk_l];   // this lane's neighbour
     }
@@ -486,7 +486,7 @@ extern "C" int roitr_local_attention_fold(const RoitrLocalAttnFold* a, hipStream
         roitr_set_error("local_attention_fold: (in_dim, H) must be (64, 128), (128, 256) or (256, 256) with the folded PPF weights given", __FILE__, __LINE__);
         return ROITR_ERR_UNSUPPORTED;
     }
-    if ((a->ldx | a->ldq) % 4 || (((uintptr_t)a->x | (uintptr_t)a->q | (uintptr_t)a->qt | (uintptr_t)a->xbar | (uintptr_t)a->vpart | (uintptr_t)a->ppf |
+    if ((a->ldx | a->ldq | a->ldqt) % 4 || (((uintptr_t)a->x | (uintptr_t)a->q | (uintptr_t)a->qt | (uintptr_t)a->xbar | (uintptr_t)a->vpart | (uintptr_t)a->ppf |
                                    (uintptr_t)a->wpe | (uintptr_t)a->wvpe | (uintptr_t)a->bvpe) & 15)) {
         roitr_set_error("local_attention_fold: rows and arrays must be 16-byte aligned", __FILE__, __LINE__);
         return ROITR_ERR_UNSUPPORTED;

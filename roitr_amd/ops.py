@@ -338,17 +338,19 @@ class _LocalAttnFold(ctypes.Structure):
                 ("x", ctypes.c_void_p), ("ldx", ctypes.c_int), ("q", ctypes.c_void_p), ("ldq", ctypes.c_int),
                 ("qt", ctypes.c_void_p), ("group_idx", ctypes.c_void_p), ("ppf", ctypes.c_void_p),
                 ("wpe", ctypes.c_void_p), ("wvpe", ctypes.c_void_p), ("bvpe", ctypes.c_void_p), ("scale", ctypes.c_float),
-                ("xbar", ctypes.c_void_p), ("vpart", ctypes.c_void_p), ("node_order", ctypes.c_void_p)]
+                ("xbar", ctypes.c_void_p), ("vpart", ctypes.c_void_p), ("node_order", ctypes.c_void_p), ("ldqt", ctypes.c_int)]
 
 
-def local_attention_fold(x, q, qt, group_idx, ppf, wpe, wvpe, bvpe, node_order=None):
+def local_attention_fold(x, q, qt, group_idx, ppf, wpe, wvpe, bvpe, node_order=None, packed=False):
     """TransitionDown form of the local PPF attention with the key / value projections folded into the query side
     (csrc/local_attn.hip local_attn_fold_kernel; include/roitr_engine.h RoitrLocalAttnFold).  x (N_in, I) input rows, q (M, H),
     qt (M, 4, I) = Wk'_h^T q_h per head, group_idx (M, 16) int32 rows of x, ppf (M, 16, 4), wpe / wvpe (H, 4), bvpe (H).
     Returns (xbar (M, 4, I) = sum_j a_hj x_j, vpart (M, H) = Wvpe_h pbar_h + bvpe_h): the attention output of the unfolded form is
-    vpart + [Wv'_h xbar_h + bv'_h]_h."""
+    vpart + [Wv'_h xbar_h + bv'_h]_h.  packed=True: q and qt are handed over as the two column blocks of ONE (M, H + 4 I) buffer (row
+    stride H + 4 I for both: RoitrLocalAttnFold.ldq / ldqt), the way the engine's single q | q~ GEMM leaves them."""
     f = lambda t: t.contiguous().float()
     x, q, qt, ppf, wpe, wvpe, bvpe = f(x), f(q), f(qt), f(ppf), f(wpe), f(wvpe), f(bvpe)
+    both = torch.cat([q, qt.reshape(q.shape[0], -1)], 1).contiguous() if packed else None
     group_idx = _i32c(group_idx)
     M, H, I = int(q.shape[0]), int(q.shape[1]), int(x.shape[1])
     if int(group_idx.shape[1]) != 16:
@@ -358,6 +360,9 @@ def local_attention_fold(x, q, qt, group_idx, ppf, wpe, wvpe, bvpe, node_order=N
     a = _LocalAttnFold()
     a.M, a.in_dim, a.H = M, I, H
     a.x, a.ldx, a.q, a.ldq, a.qt = L.ptr(x), I, L.ptr(q), H, L.ptr(qt)
+    if packed:
+        a.q, a.ldq, a.ldqt = L.ptr(both), H + 4 * I, H + 4 * I
+        a.qt = ctypes.c_void_p(both.data_ptr() + 4 * H)
     a.group_idx, a.ppf, a.wpe, a.wvpe, a.bvpe = L.ptr(group_idx), L.ptr(ppf), L.ptr(wpe), L.ptr(wvpe), L.ptr(bvpe)
     a.scale, a.xbar, a.vpart = 1.0 / float(H // 4) ** 0.5, L.ptr(xbar), L.ptr(vpart)
     no = f(node_order) if node_order is not None else None

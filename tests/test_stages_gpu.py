@@ -609,6 +609,10 @@ def test_local_attention_fold_against_the_unfolded_form(I, H, M, N_in):
     scale_ = ref.abs().mean().item()
     err = (got - ref).abs().max().item() / scale_
     assert err < 2e-5, err
+    # q and q~ as the two column blocks of one (M, H + 4 I) buffer (the engine's single q | q~ GEMM, RoitrLocalAttnFold.ldqt): same bits
+    xbar2, vpart2 = ops.local_attention_fold(x.float().cuda(), q.float().cuda(), qt.float().cuda(), grp.to(torch.int32).cuda(), ppf.float().cuda(),
+                                             wpe.float().cuda(), wvpe.float().cuda(), bvpe.float().cuda(), packed=True)
+    assert torch.equal(xbar2, xbar) and torch.equal(vpart2, vpart)
     # xbar rows are convex combinations of the gathered rows
     lo = x[grp].min(1).values[:, None, :].expand(M, 4, I) - 1e-5
     hi = x[grp].max(1).values[:, None, :].expand(M, 4, I) + 1e-5
