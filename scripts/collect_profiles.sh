@@ -4,7 +4,7 @@
 # 1) rocprofv3 --kernel-trace --stats (csv) of the default bench,
 # 2) two separate --pmc passes (FETCH_SIZE, WRITE_SIZE; kernel-trace only) of the default bench -> profiles/pmc_traffic.json,
 # 3) bench.py JSON lines (config 2 default, one pair per step, config 3, config 4 bf16 / f32, the driver's command),
-# 4) bench.py --config 5 (kNN(64) + PPF stress) + its SQ counter pass (scripts/knn_config5_sq.sh) + the SQ pass of the forward,
+# 4) the SQ counter passes (scripts/knn_config5_sq.sh, scripts/sq_pass.sh) BEFORE the bench lines that attach them, bench.py --config 5,
 # 5) the batch-size curve (scripts/batch_sweep.sh) and the one-pair device timeline (scripts/b1_timeline.sh).
 set -u
 tag=${1:-r02}
@@ -21,6 +21,13 @@ cp $out/${tag}_pmc_traffic.json profiles/pmc_traffic.json
 python scripts/prof_summary.py $out/stats s 5 45 > $out/${tag}_kernel_summary.txt
 cp $out/stats/s_kernel_stats.csv $out/${tag}_kernel_stats.csv
 python scripts/hbm_table.py $out $tag > $out/${tag}_hbm_gbs.txt
+bash scripts/knn_config5_sq.sh $out/knn5sq > $out/${tag}_knn_config5_sq.txt 2>&1
+cp $out/knn5sq/sq_knn_config5.json $out/sq_knn_config5.json
+bash scripts/sq_pass.sh $out/sq > $out/${tag}_sq_pass.txt 2>&1
+python scripts/sq_forward_json.py $out/sq/a $out/sq_forward.json > /dev/null 2>&1
+# the bench lines below attach these counters only when their kernel-source stamp matches the build they time (bench.py attach_traffic)
+cp $out/sq_forward.json profiles/sq_forward.json
+cp $out/sq_knn_config5.json profiles/sq_knn_config5.json
 python bench.py > $out/bench.log 2>&1
 tail -1 $out/bench.log > $out/${tag}_bench.json
 python bench.py --pairs-per-step 1 --steps 200 --warmup 20 --no-cpu-baseline > $out/bench_b1.log 2>&1
@@ -39,10 +46,6 @@ python bench.py --gpus 1 --steps 20 --warmup 5 > $out/bench_driver.log 2>&1
 tail -1 $out/bench_driver.log > $out/${tag}_bench_driver_cmd.json
 python bench.py --config 5 > $out/bench_c5.log 2>&1
 tail -1 $out/bench_c5.log > $out/${tag}_bench_config5.json
-bash scripts/knn_config5_sq.sh $out/knn5sq > $out/${tag}_knn_config5_sq.txt 2>&1
-cp $out/knn5sq/sq_knn_config5.json $out/sq_knn_config5.json
-bash scripts/sq_pass.sh $out/sq > $out/${tag}_sq_pass.txt 2>&1
-python scripts/sq_forward_json.py $out/sq/a $out/sq_forward.json > /dev/null 2>&1
 bash scripts/batch_sweep.sh $out/sweep > $out/${tag}_batch_sweep.txt 2>&1
 bash scripts/b1_timeline.sh $out/b1 > $out/${tag}_b1_timeline.txt 2>&1
 for f in $out/${tag}_bench*.json; do echo $f; cut -c1-400 $f; done
