@@ -392,7 +392,9 @@ typedef struct RoitrForwardIO {
      * stages the descriptors and runs the first sampling level (the longest serial chain of a small-batch forward) on its geometry
      * stream as soon as the event fires, BESIDE the previous forward still occupying `stream`, instead of behind it (calls of up to 128
      * pairs: the whole geometry chain, in scratch the engine alternates between calls); everything that touches the engine's shared
-     * scratch still starts where this forward begins on `stream`.  Results are identical.  Ignored by roitr_engine_forward_graph. */
+     * scratch -- and every kernel that writes one of the OUTPUT buffers above -- still starts where this forward begins on `stream`:
+     * output buffers may be reused from call to call, nothing but `stream` order is required of the caller.  Results are identical.
+     * Ignored by roitr_engine_forward_graph. */
     void* inputs_ready;
 } RoitrForwardIO;
 
