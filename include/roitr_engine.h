@@ -199,6 +199,30 @@ typedef struct RoitrLocalBlock {
 int roitr_local_block(const RoitrLocalBlock* a, roitr_stream_t stream);
 int roitr_local_block_supported(int H, int K);
 
+/* The TransitionDown transformer of the 64 -> 128 wide level in ONE launch (csrc/local_block.hip local_td_kernel, round 5):
+ *   out = out_proj( LN( linear(att) + in_proj(x_n) ) ),  x_n = x[node_idx[node]],                      ppftransformer.py:227-253
+ * att = the folded-attention form of RoitrLocalAttnFold (scores from q~_h = Wk'_h^T q_h against the 16 gathered INPUT rows, value
+ * = Wv'_h (sum_j a_hj x_j) + bv'_h + the positional value term).  A workgroup keeps a tile of 32 nodes on chip from x_n to out: q | q~
+ * (one on-chip GEMM with the folded weight wqqt), the attention, the per-head value projection, the K-concatenated linear with its
+ * LayerNorm, out_proj.  fp32, 4 heads, in_dim = 64, H = 128, K = 16; weights as the engine folds them (csrc/engine.cpp fold_local):
+ * wqqt ((H + 4 in_dim), in_dim) / bqqt, wv (H, in_dim) / bv = the folded value projection, wcat (H, H + in_dim) = [W_linear | W_in] /
+ * bcat, wpe / wvpe (H, 4) / bvpe the folded positional branch.  Everything 16-byte aligned. */
+typedef struct RoitrLocalTd {
+    int M, in_dim, H;
+    const float* x; const int* node_idx;      /* (N_in, in_dim) input rows; (M) row of x of every node */
+    const int* group_idx; const float* ppf;   /* (M, 16) rows of x, (M, 16, 4) */
+    const void* node_order;                   /* optional float4[M]: visiting order */
+    const float* wqqt; const float* bqqt;
+    const float* wv; const float* bv;
+    const float* wpe; const float* wvpe; const float* bvpe;
+    const float* wcat; const float* bcat; const float* norm_w; const float* norm_b;
+    const float* wout; const float* bout;
+    float scale, eps;
+    float* out;                               /* (M, H) */
+} RoitrLocalTd;
+int roitr_local_td(const RoitrLocalTd* a, roitr_stream_t stream);
+int roitr_local_td_supported(int in_dim, int H, int K);
+
 /* The first local transformer of the network (in_planes = 1, model/model.py:152): its q | k | v are rank-1 affine in the scalar
  * input feature, so the whole TransitionDown transformer collapses to per-node scalars + two small on-chip GEMMs
  * (csrc/local_block.hip local_first_kernel).  x (M,) the scalar feature; H = 64.  Constants (built from the layer's weights, see

@@ -464,6 +464,18 @@ int local_transformer(Engine& E, hipStream_t st, const LocalT& L, int N_in, cons
     else CHK(gemm(st, N_in, x, L.in_proj, f));
     // TransitionDown in fp32: the k | v projections folded into the query side (csrc/local_attn.hip local_attn_fold_kernel) --
     // q~ = Wk'^T q per head in front, Wv' applied to the attention-weighted INPUT rows behind; the (N_in, 2H) tensor is never formed
+    if (td_fold && td_cat && L.wqqt_x && !bn2_res && L.out_dim == H && roitr_local_td_supported(L.in_dim, H, K)) {
+        // the whole TransitionDown transformer of the 64 -> 128 wide level in one launch (csrc/local_block.hip local_td_kernel, round 5)
+        RoitrLocalTd t;
+        memset(&t, 0, sizeof(t));
+        t.M = M; t.in_dim = L.in_dim; t.H = H; t.x = x; t.node_idx = node_idx; t.group_idx = group; t.ppf = ppf; t.node_order = order;
+        t.wqqt = L.wqqt_x; t.bqqt = L.bqqt_x; t.wv = L.wqkv_x + (size_t)(2 * H) * L.in_dim; t.bv = L.bqkv_x + 2 * H;
+        t.wpe = L.wpe; t.wvpe = L.wvpe; t.bvpe = L.bvpe; t.wcat = L.wcat; t.bcat = L.bcat; t.norm_w = L.norm_w; t.norm_b = L.norm_b;
+        t.wout = L.out_proj.w; t.bout = L.out_proj.b; t.scale = 1.0f / sqrtf((float)(H / HEADS)); t.eps = 1e-5f; t.out = out;
+        CHK(roitr_local_td(&t, st));
+        A.off = mark;
+        return 0;
+    }
     if (td_fold) {
         const int I = L.in_dim, c = H / HEADS;
         float* qe = A.get<float>((size_t)M * H);

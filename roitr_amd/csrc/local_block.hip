@@ -465,6 +465,275 @@ __global__ __launch_bounds__(256) void local_first_kernel(RoitrLocalFirst a)
     (void)HV;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// The TransitionDown transformer of the 64 -> 128 wide level in one launch (round 5; RoitrLocalTd, include/roitr_engine.h).
+// Before: gather of the node rows, the q | q~ GEMM, local_attn_fold_kernel, the batched value GEMM, the K-concatenated `linear` +
+// LayerNorm GEMM and out_proj -- six launches streaming (M, 128 .. 384) tensors through HBM between them (6.4 ms per 512-pair step).
+// Here a workgroup keeps a tile of TM = 32 nodes on chip:
+//   P0  x_n = x[node_idx[node]]                                   -> R1 (TM x 64)
+//   P1  [q | q~] = x_n [Wq' ; Wk'_h^T Wq'_h]^T + b   (K = 64)      -> R2 (q, TM x 128), R3 (q~, TM x 256)
+//   P2  attention, one wave per node (local_attn_fold_kernel's arithmetic, q / q~ read from LDS): the 16 gathered input rows scored
+//       against the four q~_h; xbar_h = sum_j a_hj x_j -> R3 (over the node's q~ row), positional value term -> R2 (over its q row)
+//   P2b val_h = Wv'_h xbar_h: wave h owns head h (its 32 output columns, the 64 xbar columns of that head as the K range);
+//       att = vpart + val + bv' -> R2
+//   P3  y = LN([att | x_n] Wcat^T + bcat)   (K = 128 + 64)        -> R3 (pitch 260)
+//   P4  out = y Wout^T + bout                                     -> staged through R2, stored row-major
+// HBM per node: the 16 gathered input rows (4 KB, through L2), x_n, ppf + indices, one output row.  A node's result depends on its
+// own operands only, in a fixed order (tile- and batch-independent), like every other kernel of the path.
+template <int HQ> struct TdVec;
+template <> struct TdVec<2> {
+    static __device__ __forceinline__ void ld(const float* p, float (&v)[2]) { const float2 t = *reinterpret_cast<const float2*>(p); v[0] = t.x; v[1] = t.y; }
+    static __device__ __forceinline__ void st(float* p, const float (&v)[2]) { *reinterpret_cast<float2*>(p) = make_float2(v[0], v[1]); }
+};
+__device__ __forceinline__ float td_row_allmax(float v)
+{
+    v = fmaxf(v, dpp_get<0xB1>(v)); v = fmaxf(v, dpp_get<0x4E>(v)); v = fmaxf(v, dpp_get<0x141>(v)); v = fmaxf(v, dpp_get<0x140>(v));
+    return v;
+}
+
+__global__ __launch_bounds__(256, 3) void local_td_kernel(RoitrLocalTd a)
+{
+    constexpr int I = 64, H = 128, K = 16, TM = 32, HQ = 2, HV = 2;
+    constexpr int P2 = H + 4, P3 = 4 * I + 4;                  // LDS pitches (floats): 16-byte aligned rows, conflict-free b128 fragments
+    // 51 KB: three workgroups per CU (the x_n image has no buffer of its own: it sits in R2 until q replaces it, and comes back
+    // into the free columns of R3 for the K-concatenated linear -- with a fourth 8.7 KB buffer only two workgroups fit, and beside
+    // the geometry stream the kernel ran 2.2 x its time alone)
+    __shared__ __attribute__((aligned(16))) float R2[TM * P2];   // x_n -> q -> vpart -> att -> staging of the two epilogues
+    __shared__ __attribute__((aligned(16))) float R3[TM * P3];   // q~ -> xbar -> [y (columns 0..127) | x_n (columns 128..191)]
+    __shared__ __attribute__((aligned(16))) float probs[4][64];  // per wave: [head][neighbour]
+    __shared__ int ids[TM];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ntiles = (a.M + TM - 1) / TM;
+    const int tile = xcd_block_id(ntiles);
+    if (tile >= ntiles) return;
+    const int s0 = tile * TM;
+    if (tid < TM) {
+        const int sl = s0 + tid < a.M ? s0 + tid : s0;            // a dead slot recomputes the tile's first node and stores nothing
+        ids[tid] = a.node_order ? __float_as_int(reinterpret_cast<const float4*>(a.node_order)[sl].w) : sl;
+    }
+    __syncthreads();
+    {   // ---- P0: the node rows (TM x 64 floats = 2 float4 per thread)
+        constexpr int F4 = I / 4, NX = TM * F4 / 256;
+        float4 xr[NX];
+#pragma unroll
+        for (int u = 0; u < NX; ++u) {
+            const int e = tid + 256 * u;
+            xr[u] = *reinterpret_cast<const float4*>(a.x + (size_t)a.node_idx[ids[e / F4]] * I + 4 * (e % F4));
+        }
+#pragma unroll
+        for (int u = 0; u < NX; ++u) {
+            const int e = tid + 256 * u;
+            *reinterpret_cast<float4*>(R2 + (e / F4) * P2 + 4 * (e % F4)) = xr[u];
+        }
+    }
+    __syncthreads();
+    const int c0 = wave * 32;
+    {   // ---- P1: [q | q~] (384 columns = three passes of 128); q (pass 0) replaces x_n in R2 once every wave has read it
+        Acc accq;
+#pragma unroll
+        for (int pass = 0; pass < 3; ++pass) {
+            Acc acc;
+            acc_zero(acc);
+            gemm_phase<H, P2>(acc, R2, I, a.wqqt, I, 0, 0, 128 * pass + c0, tid);
+            if (pass == 0) accq = acc;
+            else {
+                // columns 128 pass + c0 of [q | q~] = columns 128 (pass - 1) + c0 of q~
+#pragma unroll
+                for (int n = 0; n < 2; ++n) {
+                    const int col = 128 * (pass - 1) + c0 + 16 * n + (lane & 15);
+                    const float bv = a.bqqt[H + col];
+#pragma unroll
+                    for (int m = 0; m < 2; ++m)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) R3[(16 * m + 4 * (lane >> 4) + r) * P3 + col] = acc.t[m][n][r] + bv;
+                }
+            }
+        }
+        __syncthreads();                                          // every wave is done with the x_n image
+        acc_store<P2>(accq, a.bqqt, R2, 0, c0, lane);
+    }
+    __syncthreads();
+    {   // ---- P2: attention, wave `wave` takes nodes wave * 8 .. + 7 of the tile, one at a time (their rows of R2 / R3 are its own)
+        const int h = lane >> 4, i16 = lane & 15, kk_l = row16_slot(i16);
+        float4 wpe2[HQ]; float bvpe2[HQ]; float4 wvpe2[HQ];
+#pragma unroll
+        for (int i = 0; i < HQ; ++i) {
+            wpe2[i] = reinterpret_cast<const float4*>(a.wpe)[lane * HQ + i];
+            wvpe2[i] = reinterpret_cast<const float4*>(a.wvpe)[lane * HQ + i];
+            bvpe2[i] = a.bvpe[lane * HQ + i];
+        }
+        constexpr int NPB = TM / 4;
+        // software pipeline over the wave's nodes: the 16 gathered rows of node nn + 1 are in flight while node nn is computed (their
+        // indices were requested one node earlier still) -- one node at a time left every wave waiting out a round trip per node
+        // with two waves per SIMD to cover it
+        int g_cur = a.group_idx[(size_t)ids[wave * NPB] * K + i16];
+        float4 pf_cur = reinterpret_cast<const float4*>(a.ppf)[(size_t)ids[wave * NPB] * K + kk_l];
+        int g_nx = a.group_idx[(size_t)ids[wave * NPB + 1] * K + i16];
+        float4 pf_nx = reinterpret_cast<const float4*>(a.ppf)[(size_t)ids[wave * NPB + 1] * K + kk_l];
+        float xr[K], xn[K];
+#pragma unroll
+        for (int kk = 0; kk < K; ++kk) xr[kk] = a.x[(size_t)__builtin_amdgcn_readlane(g_cur, kk) * I + lane];
+        for (int nn = 0; nn < NPB; ++nn) {
+            const int row = wave * NPB + nn;
+            const float4 pf = pf_cur;
+            if (nn + 1 < NPB) {
+#pragma unroll
+                for (int kk = 0; kk < K; ++kk) xn[kk] = a.x[(size_t)__builtin_amdgcn_readlane(g_nx, kk) * I + lane];
+            }
+            int g_n2 = 0; float4 pf_n2 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (nn + 2 < NPB) {
+                g_n2 = a.group_idx[(size_t)ids[row + 2] * K + i16];
+                pf_n2 = reinterpret_cast<const float4*>(a.ppf)[(size_t)ids[row + 2] * K + kk_l];
+            }
+            float qt[4], qv[HQ];
+#pragma unroll
+            for (int hh = 0; hh < 4; ++hh) qt[hh] = R3[row * P3 + hh * I + lane];
+            TdVec<HQ>::ld(R2 + row * P2 + lane * HQ, qv);
+            // u_h = Wpe_h^T q_h: the PPF coefficients of the score
+            float u0 = 0.f, u1 = 0.f, u2 = 0.f, u3 = 0.f;
+#pragma unroll
+            for (int i = 0; i < HQ; ++i) {
+                u0 = fmaf(wpe2[i].x, qv[i], u0); u1 = fmaf(wpe2[i].y, qv[i], u1); u2 = fmaf(wpe2[i].z, qv[i], u2); u3 = fmaf(wpe2[i].w, qv[i], u3);
+            }
+            u0 = row_allsum(u0); u1 = row_allsum(u1); u2 = row_allsum(u2); u3 = row_allsum(u3);
+            // 64 partial dot products per lane, reduced over the wave in three transposing stages (local_attn_fold_kernel)
+            float z[16];
+            {
+                float w[32];
+#pragma unroll
+                for (int i = 0; i < 32; ++i) {
+                    const int h0 = i >> 4, k0 = i & 15;
+                    w[i] = swap32_sum(qt[h0] * xr[k0], qt[h0 + 2] * xr[k0]);
+                }
+#pragma unroll
+                for (int i = 0; i < 16; ++i) z[i] = swap16_sum(w[i], w[i + 16]);
+            }
+            const float tot = row16_transpose_sum(z, lane);
+            const float s = (tot + (u0 * pf.x + u1 * pf.y + u2 * pf.z + u3 * pf.w)) * a.scale;
+            const float mx = td_row_allmax(s);
+            const float e = expf(s - mx);
+            const float p = e / row_allsum(e);
+            probs[wave][h * 16 + kk_l] = p;
+            const float pb0 = row_allsum(p * pf.x), pb1 = row_allsum(p * pf.y), pb2 = row_allsum(p * pf.z), pb3 = row_allsum(p * pf.w);
+            {
+                float o[HQ];
+#pragma unroll
+                for (int i = 0; i < HQ; ++i) o[i] = wvpe2[i].x * pb0 + wvpe2[i].y * pb1 + wvpe2[i].z * pb2 + wvpe2[i].w * pb3 + bvpe2[i];
+                TdVec<HQ>::st(R2 + row * P2 + lane * HQ, o);        // vpart over the node's q row (consumed above)
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // one wave: LDS operations complete in order
+            // xbar_h = sum_k p(h, k) x_k: the probabilities of a head are wave-uniform LDS broadcasts
+#pragma unroll
+            for (int hh = 0; hh < 4; ++hh) {
+                float acc = 0.f;
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    const float4 p4 = reinterpret_cast<const float4*>(probs[wave])[hh * 4 + q4];
+                    acc = fmaf(p4.x, xr[4 * q4], acc); acc = fmaf(p4.y, xr[4 * q4 + 1], acc);
+                    acc = fmaf(p4.z, xr[4 * q4 + 2], acc); acc = fmaf(p4.w, xr[4 * q4 + 3], acc);
+                }
+                R3[row * P3 + hh * I + lane] = acc;                   // over the node's q~ row (consumed above)
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // probs is rewritten by the next node
+#pragma unroll
+            for (int kk = 0; kk < K; ++kk) xr[kk] = xn[kk];
+            pf_cur = pf_nx; g_nx = g_n2; pf_nx = pf_n2;
+        }
+    }
+    __syncthreads();
+    float4 xn4[2];                                                 // the node rows again (L2-hot), for the K-concatenated linear
+    {
+        constexpr int F4 = I / 4;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int e = tid + 256 * u;
+            xn4[u] = *reinterpret_cast<const float4*>(a.x + (size_t)a.node_idx[ids[e / F4]] * I + 4 * (e % F4));
+        }
+    }
+    {   // ---- P2b: val_h = Wv'_h xbar_h (wave = head); att = vpart + val + bv' in place on R2
+        Acc acc;
+        acc_zero(acc);
+        gemm_phase<H, P3>(acc, R3 + I * wave, I, a.wv, I, 0, 0, c0, tid);
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            const int col = c0 + 16 * n + (lane & 15);
+            const float bv = a.bv[col];
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float* d = R2 + (16 * m + 4 * (lane >> 4) + r) * P2 + col;
+                    *d = *d + (acc.t[m][n][r] + bv);
+                }
+        }
+    }
+    __syncthreads();                                              // every wave is done with the xbar image: x_n takes its columns 128..191
+    {
+        constexpr int F4 = I / 4;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int e = tid + 256 * u;
+            *reinterpret_cast<float4*>(R3 + (e / F4) * P3 + 2 * I + 4 * (e % F4)) = xn4[u];
+        }
+    }
+    Acc acc;
+    // ---- P3: y = LN([att | x_n] Wcat^T + bcat) -> R3 columns 0..127
+    acc_zero(acc);
+    gemm_phase<H, P2>(acc, R2, H, a.wcat, H + I, 0, 0, c0, tid);
+    __syncthreads();                                              // the x_n columns are complete; every wave is done reading R2
+    gemm_phase<H, P3>(acc, R3 + 2 * I, I, a.wcat, H + I, H, 0, c0, tid);
+    acc_store<P2>(acc, a.bcat, R2, 0, c0, lane);
+    __syncthreads();
+    {
+        const int lr = lane >> 4, lc = lane & 15;
+        float4 gam[HV], bet[HV];
+#pragma unroll
+        for (int i = 0; i < HV; ++i) { gam[i] = reinterpret_cast<const float4*>(a.norm_w)[lc + 16 * i]; bet[i] = reinterpret_cast<const float4*>(a.norm_b)[lc + 16 * i]; }
+#pragma unroll
+        for (int u = 0; u < TM / 16; ++u) {
+            const int rl = (u * 4 + wave) * 4 + lr;
+            float4 t[HV];
+            float s_ = 0.f;
+#pragma unroll
+            for (int i = 0; i < HV; ++i) { t[i] = *reinterpret_cast<const float4*>(R2 + rl * P2 + 4 * (lc + 16 * i)); s_ += (t[i].x + t[i].y) + (t[i].z + t[i].w); }
+            const float mean = row_allsum(s_) / (float)H;
+            float q_ = 0.f;
+#pragma unroll
+            for (int i = 0; i < HV; ++i) {
+                const float dx = t[i].x - mean, dy = t[i].y - mean, dz = t[i].z - mean, dw = t[i].w - mean;
+                q_ += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+            }
+            const float rstd = 1.0f / sqrtf(row_allsum(q_) / (float)H + a.eps);
+#pragma unroll
+            for (int i = 0; i < HV; ++i) {
+                float4 y;
+                y.x = (t[i].x - mean) * rstd * gam[i].x + bet[i].x; y.y = (t[i].y - mean) * rstd * gam[i].y + bet[i].y;
+                y.z = (t[i].z - mean) * rstd * gam[i].z + bet[i].z; y.w = (t[i].w - mean) * rstd * gam[i].w + bet[i].w;
+                *reinterpret_cast<float4*>(R3 + rl * P3 + 4 * (lc + 16 * i)) = y;
+            }
+        }
+    }
+    __syncthreads();                                              // the y image is complete
+    // ---- P4: out = y Wout^T + bout
+    acc_zero(acc);
+    gemm_phase<H, P3>(acc, R3, H, a.wout, H, 0, 0, c0, tid);
+    acc_store<P2>(acc, a.bout, R2, 0, c0, lane);                   // R2 was last read before the barrier above
+    __syncthreads();
+    {
+        const int lr = lane >> 4, lc = lane & 15;
+#pragma unroll
+        for (int u = 0; u < TM / 16; ++u) {
+            const int rl = (u * 4 + wave) * 4 + lr;
+            if (s0 + rl < a.M) {
+#pragma unroll
+                for (int i = 0; i < HV; ++i)
+                    *reinterpret_cast<float4*>(a.out + (size_t)ids[rl] * H + 4 * (lc + 16 * i)) = *reinterpret_cast<const float4*>(R2 + rl * P2 + 4 * (lc + 16 * i));
+            }
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int roitr_local_block_supported(int H, int K)
@@ -513,6 +782,27 @@ extern "C" int roitr_local_block(const RoitrLocalBlock* a, hipStream_t stream)
         if (a->K == 8) local_block_kernel<128, 8, 32><<<grid, 256, 0, stream>>>(*a);
         else local_block_kernel<128, 16, 32><<<grid, 256, 0, stream>>>(*a);
     }
+    roitr_prof_end(ROITR_PROF_LOCAL_BLOCK, stream);
+    ROITR_LAUNCH_CHECK();
+    return ROITR_OK;
+}
+
+extern "C" int roitr_local_td_supported(int in_dim, int H, int K) { return in_dim == 64 && H == 128 && K == 16 ? 1 : 0; }
+
+extern "C" int roitr_local_td(const RoitrLocalTd* a, hipStream_t stream)
+{
+    if (a->M <= 0) return ROITR_OK;
+    if (!roitr_local_td_supported(a->in_dim, a->H, 16)) return ROITR_ERR_UNSUPPORTED;
+    if ((((uintptr_t)a->x | (uintptr_t)a->group_idx | (uintptr_t)a->ppf | (uintptr_t)a->out | (uintptr_t)a->wqqt | (uintptr_t)a->wv | (uintptr_t)a->wcat |
+          (uintptr_t)a->wout | (uintptr_t)a->wpe | (uintptr_t)a->wvpe | (uintptr_t)a->bvpe | (uintptr_t)a->norm_w | (uintptr_t)a->norm_b) & 15) != 0 ||
+        !a->node_idx || !a->bqqt || !a->bv || !a->bcat || !a->bout) {
+        roitr_set_error("roitr_local_td: operands must be given and 16-byte aligned", __FILE__, __LINE__);
+        return ROITR_ERR_ARG;
+    }
+    // algorithmic bytes: the node row in, 16 gathered input rows, ppf + indices, one row out; FLOPs of the on-chip GEMMs in aux
+    const double I = a->in_dim, H = a->H;
+    roitr_prof_begin2(ROITR_PROF_LOCAL_BLOCK, (double)a->M * (I * 4 + 16.0 * (I * 4 + 20.0) + H * 4), 2.0 * a->M * ((H + 4 * I) * I + H * I + H * (H + I) + H * H), stream);
+    local_td_kernel<<<xcd_grid(div_up(a->M, 32)), 256, 0, stream>>>(*a);
     roitr_prof_end(ROITR_PROF_LOCAL_BLOCK, stream);
     ROITR_LAUNCH_CHECK();
     return ROITR_OK;

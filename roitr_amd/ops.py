@@ -371,6 +371,40 @@ def local_attention_fold(x, q, qt, group_idx, ppf, wpe, wvpe, bvpe, node_order=N
     return xbar, vpart
 
 
+class _LocalTd(ctypes.Structure):
+    _fields_ = [("M", ctypes.c_int), ("in_dim", ctypes.c_int), ("H", ctypes.c_int),
+                ("x", ctypes.c_void_p), ("node_idx", ctypes.c_void_p), ("group_idx", ctypes.c_void_p), ("ppf", ctypes.c_void_p),
+                ("node_order", ctypes.c_void_p), ("wqqt", ctypes.c_void_p), ("bqqt", ctypes.c_void_p), ("wv", ctypes.c_void_p),
+                ("bv", ctypes.c_void_p), ("wpe", ctypes.c_void_p), ("wvpe", ctypes.c_void_p), ("bvpe", ctypes.c_void_p),
+                ("wcat", ctypes.c_void_p), ("bcat", ctypes.c_void_p), ("norm_w", ctypes.c_void_p), ("norm_b", ctypes.c_void_p),
+                ("wout", ctypes.c_void_p), ("bout", ctypes.c_void_p), ("scale", ctypes.c_float), ("eps", ctypes.c_float), ("out", ctypes.c_void_p)]
+
+
+def local_td(x, node_idx, group_idx, ppf, w, node_order=None):
+    """The TransitionDown transformer of the 64 -> 128 wide level in one launch (csrc/local_block.hip local_td_kernel;
+    include/roitr_engine.h RoitrLocalTd).  x (N_in, 64) input rows, node_idx (M,) int32 row of x of every node, group_idx (M, 16) int32
+    rows of x, ppf (M, 16, 4); w: dict of the folded weights wqqt (384, 64), bqqt (384), wv (128, 64), bv (128), wpe / wvpe (128, 4),
+    bvpe (128), wcat (128, 192), bcat, norm_w, norm_b, wout (128, 128), bout.  Returns (M, 128)."""
+    f = lambda t: t.contiguous().float()
+    x, ppf = f(x), f(ppf)
+    node_idx, group_idx = _i32c(node_idx), _i32c(group_idx)
+    w = {k: f(v) for k, v in w.items()}
+    M, I, H = int(node_idx.shape[0]), int(x.shape[1]), int(w["wout"].shape[0])
+    if int(group_idx.shape[1]) != 16 or not L.lib().roitr_local_td_supported(I, H, 16):
+        raise L.RoitrError("local_td: in_dim 64, H 128, 16 neighbours per node")
+    out = torch.empty((M, H), dtype=torch.float32, device=x.device)
+    a = _LocalTd()
+    a.M, a.in_dim, a.H = M, I, H
+    a.x, a.node_idx, a.group_idx, a.ppf = L.ptr(x), L.ptr(node_idx), L.ptr(group_idx), L.ptr(ppf)
+    no = f(node_order) if node_order is not None else None
+    a.node_order = L.ptr(no)
+    for k in ("wqqt", "bqqt", "wv", "bv", "wpe", "wvpe", "bvpe", "wcat", "bcat", "norm_w", "norm_b", "wout", "bout"):
+        setattr(a, k, L.ptr(w[k]))
+    a.scale, a.eps, a.out = 1.0 / float(H // 4) ** 0.5, 1e-5, L.ptr(out)
+    L.check(L.lib().roitr_local_td(ctypes.byref(a), L.stream_ptr()), "local_td")
+    return out
+
+
 class _LocalBlock(ctypes.Structure):
     _fields_ = [("M", ctypes.c_int), ("K", ctypes.c_int), ("H", ctypes.c_int),
                 ("x", ctypes.c_void_p), ("kv", ctypes.c_void_p), ("group_idx", ctypes.c_void_p), ("ppf", ctypes.c_void_p),

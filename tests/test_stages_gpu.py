@@ -620,6 +620,57 @@ def test_local_attention_fold_against_the_unfolded_form(I, H, M, N_in):
     assert bool(((xb >= lo) & (xb <= hi)).all())
 
 
+@pytest.mark.parametrize("M,N_in,ordered", [(1000, 4000, False), (4099, 16500, True), (31, 200, False)])
+def test_fused_transition_down_against_float64(M, N_in, ordered):
+    """csrc/local_block.hip local_td_kernel (the TransitionDown transformer of the 64 -> 128 wide level in one launch: q | q~ GEMM,
+    folded attention, per-head value projection, K-concatenated linear + LayerNorm, out_proj on a tile of 32 nodes) against the
+    UNFOLDED layer in float64 (ppftransformer.py:227-253 + attention.py:152-200: k | v projected per point, PPF branch through its
+    embedding-folded weights, softmax over the 16 neighbours, linear + in_proj residual, LayerNorm, out_proj).  Node counts that are
+    not a multiple of the tile, a permuted visiting order; a node's row must not depend on the order."""
+    from roitr_amd import ops
+    I, H, c = 64, 128, 32
+    g = torch.Generator(device="cpu").manual_seed(M + N_in)
+    r = lambda *s_: torch.randn(s_, generator=g, dtype=torch.float64)
+    x = r(N_in, I)
+    node_idx = torch.randint(0, N_in, (M,), generator=g)
+    grp = torch.randint(0, N_in, (M, 16), generator=g)
+    ppf = torch.rand((M, 16, 4), generator=g, dtype=torch.float64) * 3.0
+    wq, wk, wv = r(H, I) / I ** 0.5, r(H, I) / I ** 0.5, r(H, I) / I ** 0.5
+    bq, bk, bv = r(H), r(H), r(H)
+    wpe, bpe, wvpe, bvpe = r(H, 4), r(H), r(H, 4), r(H)
+    wlin, win, bcat = r(H, H) / H ** 0.5, r(H, I) / I ** 0.5, r(H)
+    nw, nb = 1 + 0.1 * r(H), 0.1 * r(H)
+    wout, bout = r(H, H) / H ** 0.5, r(H)
+    # ---- unfolded float64 reference
+    xn = x[node_idx]
+    q = (xn @ wq.T + bq).reshape(M, 1, 4, c)
+    k = (x @ wk.T + bk)[grp].reshape(M, 16, 4, c)
+    v = (x @ wv.T + bv)[grp].reshape(M, 16, 4, c)
+    p = (ppf @ wpe.T + bpe).reshape(M, 16, 4, c)
+    vp = (ppf @ wvpe.T + bvpe).reshape(M, 16, 4, c)
+    a = torch.softmax(((q * k).sum(-1) + (q * p).sum(-1)) / c ** 0.5, dim=1)
+    att = (a[..., None] * (v + vp)).sum(1).reshape(M, H)
+    z = att @ wlin.T + xn @ win.T + bcat
+    y = (z - z.mean(1, keepdim=True)) / torch.sqrt(z.var(1, unbiased=False, keepdim=True) + 1e-5) * nw + nb
+    ref = y @ wout.T + bout
+    # ---- folded weights (float64 folds, as csrc/engine.cpp fold_local forms them in fp32)
+    wqt = torch.einsum("hci,hcj->hij", wk.reshape(4, c, I), wq.reshape(4, c, I)).reshape(4 * I, I)      # (Wk_h^T Wq_h)[i, j]
+    bqt = torch.einsum("hci,hc->hi", wk.reshape(4, c, I), bq.reshape(4, c)).reshape(4 * I)
+    w = dict(wqqt=torch.cat([wq, wqt]), bqqt=torch.cat([bq, bqt]), wv=wv, bv=bv, wpe=wpe, wvpe=wvpe, bvpe=bvpe,
+             wcat=torch.cat([wlin, win], 1), bcat=bcat, norm_w=nw, norm_b=nb, wout=wout, bout=bout)
+    wd = {k_: v_.float().cuda() for k_, v_ in w.items()}
+    args = (x.float().cuda(), node_idx.to(torch.int32).cuda(), grp.to(torch.int32).cuda(), ppf.float().cuda(), wd)
+    got = ops.local_td(*args)
+    err = (got.double().cpu() - ref).abs().max().item() / ref.abs().mean().item()
+    assert err < 5e-5, err
+    if ordered:   # a visiting order (float4 with the node index in .w): same rows, bit for bit
+        perm = torch.randperm(M, generator=g)
+        order = torch.zeros((M, 4), dtype=torch.float32)
+        order[:, 3] = perm.to(torch.int32).view(torch.float32)
+        got2 = ops.local_td(*args, node_order=order.cuda())
+        assert torch.equal(got2, got)
+
+
 @pytest.mark.parametrize("M,K,N,R", [(1000, 64, 64, 260), (777, 128, 128, 200), (333, 256, 256, 90)])
 def test_transition_up_interpolation_in_the_layernorm_epilogue(M, K, N, R):
     """TransitionUp (model/model.py:112-116): relu(LN(linear1(x1))) + interpolation(p2, p1, feat) -- the interpolation
