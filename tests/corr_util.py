@@ -88,15 +88,23 @@ def matching_scores_error(out, ref):
 
 
 def descriptor_error(got, ref):
-    """(relative error against max(1, |ref|), ABSOLUTE error, largest |ref|) of a descriptor tensor.  The north star reads "fp32 features
-    within 1e-4": the tests assert the relative form (the selective weights scale the unnormalised point descriptors to |x| ~ 4 - 40) AND
-    an absolute bound of 1e-4 per unit of max(1, scale / 8) -- i.e. plain 1e-4 absolute up to |x| = 8 -- and print what was measured."""
+    """(relative error against max(1, |ref|), ABSOLUTE error, largest |ref|) of a descriptor tensor."""
     got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64)
     d = np.abs(got - ref)
     return float((d / np.maximum(1.0, np.abs(ref))).max()), float(d.max()), float(np.abs(ref).max())
 
 
 def assert_descriptors_close(got, ref, name, rel=1e-4):
-    r, a, scale = descriptor_error(got, ref)
-    print(f"[descriptor] {name}: max |ref| {scale:.3g}  abs err {a:.2e}  rel err {r:.2e}")
-    assert r < rel and a < 1e-4 * max(1.0, scale / 8.0), (name, r, a, scale)
+    """The north star reads "fp32 features within 1e-4".  Asserted as written -- PLAIN absolute 1e-4 -- on every element with
+    |ref| <= 8 (round 6; all of the 3DMatch descriptors and all but the tails of the 4DMatch point descriptors, whose selective
+    `fine_proj` gain puts a few entries at |x| ~ 40, where one fp32 ulp is already 3.8e-6); elements above 8 are held to 1e-4
+    RELATIVE to their own magnitude.  The measured values are printed (pytest -s)."""
+    got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64)
+    d = np.abs(got - ref)
+    small = np.abs(ref) <= 8.0
+    a_small = float(d[small].max()) if small.any() else 0.0
+    r_big = float((d[~small] / np.abs(ref[~small])).max()) if (~small).any() else 0.0
+    print(f"[descriptor] {name}: max |ref| {np.abs(ref).max():.3g}  abs err on |ref| <= 8: {a_small:.2e}  "
+          f"rel err on the {int((~small).sum())} elements above: {r_big:.2e}")
+    assert a_small < 1e-4, (name, a_small)
+    assert r_big < rel, (name, r_big)
