@@ -58,6 +58,9 @@ typedef struct RoitrGemm {
      * `linear(att) + in_proj(x[node_idx])` of a TransitionDown transformer as one GEMM (model/model.py:59-62 samples the rows).
      * With A_cat an addend A2 applies to the A part only (columns k < k_cat). */
     const int* a_cat_idx;
+    /* optional (ABI 3): device int; batches (tiles of batch index) >= *batch_live leave at once -- a batch list whose live length is
+     * only known on the device (the compacted patch list of the adaptive matching, RIGA_v2.py:126-152) without a host round trip. */
+    const int* batch_live;
 } RoitrGemm;
 #define ROITR_BF16_W 1
 #define ROITR_BF16_A 2
@@ -291,6 +294,16 @@ int roitr_coarse_matching(const RoitrCoarse* a, roitr_stream_t stream);
 /* model/modules.py:75-124 AdaptiveSuperPointMatching (4DMatch); needs a->xy; a->num_corr = output capacity per pair */
 int roitr_adaptive_matching(const RoitrCoarse* a, int min_num, float threshold, roitr_stream_t stream);
 
+/* Patch layouts of the four operators below (ABI 3).  STRIDED (pair_off == NULL): per-patch arrays have pairs * num_corr slots,
+ * patch p of pair b at slot b * num_corr + p, live while p < n_corr[b] (dead slots are zero-filled / skipped).  COMPACTED
+ * (pair_off != NULL, pairs + 1 cumulative int32 from roitr_patch_offsets): the live patches of all pairs back to back in `slots`
+ * slots, pair b owns [pair_off[b], pair_off[b + 1]); slots past pair_off[pairs] are never read or written.  That is how the
+ * reference runs the tail -- on the SELECTED node pairs only (model/RIGA_v2.py:126-152, modules.py:102-111): the adaptive 4DMatch
+ * matching selects between 128 and n_t * n_s = 15 625 pairs per cloud pair, typically ~1 000.  The coarse lists tgt_corr /
+ * src_corr / corr_scores stay (pairs, num_corr) in both layouts. */
+/* pair_off[0] = 0, pair_off[b + 1] = min(slots, n_corr[0] + .. + n_corr[b]); the caller detects a cut from n_corr */
+int roitr_patch_offsets(int pairs, const int* n_corr, int slots, int* pair_off, roitr_stream_t stream);
+
 /* model/RIGA_v2.py:125-147: per patch correspondence the `limit` point rows / points / masks of both sides.
  * rows index the concatenated point arrays (-1 = the zero pad row). */
 typedef struct RoitrPatch {
@@ -298,6 +311,7 @@ typedef struct RoitrPatch {
     const int* n_corr; const int* tgt_corr; const int* src_corr;
     const int* node_offset; const int* pt_offset; const int* knn_idx; const int* knn_mask; const float* points;
     int* tgt_rows; int* src_rows; int* tgt_masks; int* src_masks; float* tgt_pts; float* src_pts;
+    const int* pair_off; int slots;   /* compacted layout (see above); NULL / 0 = strided */
 } RoitrPatch;
 int roitr_patch_gather(const RoitrPatch* a, roitr_stream_t stream);
 
@@ -306,6 +320,7 @@ typedef struct RoitrOT {
     int pairs, num_corr, limit, num_iter;
     const int* n_corr; const float* scores; const int* row_masks; const int* col_masks; const float* alpha;
     float* out;
+    const int* pair_off; int slots;   /* compacted layout; NULL / 0 = strided */
 } RoitrOT;
 int roitr_optimal_transport(const RoitrOT* a, roitr_stream_t stream);
 /* Diagnostics of the data-dependent work of that stage (synchronous): reads out[0] = live patches, out[1] = Sinkhorn iterations skipped by
@@ -325,6 +340,8 @@ typedef struct RoitrFine {
     long out_cap;   /* rows the out_* arrays hold (0 = caller guarantees pairs*num_corr*limit*limit): the emitter never writes past
                        it and *n_out is clamped to it.  Worst case per patch: limit*k rows when mutual, 2*limit*k otherwise
                        (row top-k OR column top-k, modules.py:259-266). */
+    const int* pair_off; int slots;   /* compacted layout; NULL / 0 = strided.  out_patch then holds slot numbers */
+    int* pair_starts;                 /* optional (pairs + 1): first output row of every pair, then the total */
 } RoitrFine;
 int roitr_fine_matching(const RoitrFine* a, roitr_stream_t stream);
 
@@ -393,7 +410,11 @@ typedef struct RoitrForwardIO {
     const float* points_out;   /* (T,3): src_pcd / tgt_pcd; NULL = points_geom */
     const float* rot;          /* (B,3,3) or NULL: skips the ground-truth side outputs */
     const float* trans;        /* (B,3) */
-    /* outputs, device, caller-allocated; any may be NULL.  T4 = total nodes, P = num_corr, L = point_limit */
+    /* outputs, device, caller-allocated; any may be NULL.  T4 = total nodes, P = num_corr, L = point_limit.  The per-patch outputs
+     * -- *_knn_pts, *_knn_masks, matching_scores, fine_offsets -- have B * P slots, patch p of pair b at slot b * P + p, EXCEPT with
+     * adaptive_coarse (4DMatch): there P = nmax4^2 only bounds the coarse lists tgt_corr / src_corr / corr_scores, and the per-patch
+     * outputs hold the SELECTED patches of all pairs back to back in `patch_slots` slots (pair b at patch_offsets[b] ..
+     * patch_offsets[b + 1]); see patch_slots below. */
     float* node_xyz;           /* (T4,3) */
     float* node_feats;         /* (T4, 256f) */
     float* point_feats;        /* (T, 256f) */
@@ -420,6 +441,15 @@ typedef struct RoitrForwardIO {
      * output buffers may be reused from call to call, nothing but `stream` order is required of the caller.  Results are identical.
      * Ignored by roitr_engine_forward_graph. */
     void* inputs_ready;
+    /* ABI 3.  patch_slots: with adaptive_coarse, the number of patch slots the per-patch outputs above (and the engine's own patch
+     * scratch) hold for the WHOLE call; 0 = the bound B * nmax4^2.  Patches beyond it are cut from the END of the call's list: the
+     * true counts are in n_corr, the kept ones in patch_offsets -- a caller that sees sum(n_corr) > patch_slots repeats the call with
+     * that sum (roitr_amd/riga.py does).  Ignored without adaptive_coarse (the slots are exactly B * num_corr there).
+     * patch_offsets (B + 1): first patch slot of every pair, then the live total.  pair_starts (B + 1): first row of every pair in
+     * out_scores / out_*_pts, then the total (== *n_out).  Both optional. */
+    int* patch_offsets;
+    int* pair_starts;
+    int patch_slots;
 } RoitrForwardIO;
 
 void* roitr_engine_create(const RoitrEngineConfig* cfg);

@@ -168,6 +168,16 @@ __device__ __forceinline__ int xcd_block_id(int n)
     return (b & 7) * ((n + 7) >> 3) + (b >> 3);
 }
 
+// The same map for a launch whose LIVE block count n is only known on the device (n <= the count the grid was sized for): blocks
+// past the live range return -1 (the plain form would fold them onto the next XCD's tiles).
+__device__ __forceinline__ int xcd_block_id_live(int n)
+{
+    const int b = blockIdx.x, per = (n + 7) >> 3;
+    if ((b >> 3) >= per) return -1;
+    const int t = (b & 7) * per + (b >> 3);
+    return t < n ? t : -1;
+}
+
 // Wave-wide reductions on the DPP cross-lane path (no LDS traffic, unlike ds_bpermute-backed __shfl_xor for the 16/32
 // strides): row_shr 1/2/4/8 build the 16-lane row result in lane 15 of each row, row_bcast:15 / row_bcast:31 fold the
 // four rows, lane 63 holds the wave result and v_readlane broadcasts it.  Lanes without a source read `old`

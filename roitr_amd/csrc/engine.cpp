@@ -995,6 +995,12 @@ static int forward_body(void* h, const RoitrForwardIO* io, hipStream_t st)
     }
     const int T1 = V.T[0], T4 = V.T[3];
     if (E.cfg.adaptive_coarse) P_ = V.nmax[3] * V.nmax[3];  // every node pair may be selected (modules.py:111-112)
+    // Patch slots of the call.  3DMatch: exactly B * num_corr, strided.  Adaptive matching: the SELECTED patches of all pairs back to back
+    // (roitr_patch_offsets) in as many slots as the caller's per-patch outputs hold (RoitrForwardIO::patch_slots; 0 = the bound B * n^2)
+    const bool compact = E.cfg.adaptive_coarse != 0;
+    size_t NPs = (size_t)B * P_;
+    if (compact && io->patch_slots > 0 && (size_t)io->patch_slots < NPs) NPs = (size_t)io->patch_slots;
+    if (NPs * (size_t)(LIM * LIM) > 0x7fffffffffLL || NPs > 0x7ffffff0u / (size_t)LIM) { roitr_set_error("too many patch slots for one call", __FILE__, __LINE__); return ROITR_ERR_UNSUPPORTED; }
     if (V.nmax[3] > 1024) { roitr_set_error("more than 1024 superpoints per cloud", __FILE__, __LINE__); return ROITR_ERR_UNSUPPORTED; }
     std::vector<long> eoff(NC);
     long etot = 0;
@@ -1003,7 +1009,7 @@ static int forward_body(void* h, const RoitrForwardIO* io, hipStream_t st)
     // ---------------- arena sizing (upper bound from the sizes)
     {
         size_t need = (size_t)T1 * 4 * (64 * f * 14 + 256 * f * 2 + 600) + (size_t)etot * (C4 * 4 + 64) /* E once + its index arrays */ + (size_t)T4 * C4 * 4 * 40 +
-                      (size_t)B * P_ * (LIM * LIM * 3 + (LIM + 1) * (LIM + 1) + LIM * 16) * 4 + ((size_t)64 << 20);
+                      NPs * (LIM * LIM * 3 + (LIM + 1) * (LIM + 1) + LIM * 16) * 4 + (size_t)B * P_ * 16 + ((size_t)64 << 20);
         if (E.cfg.operand_dtype == 1) need += (size_t)T1 * C4 * 2 + 1024;   // bf16 copy of the point descriptors (patch scores)
         for (int l = 0; l < 4; ++l) need += roitr_knn_workspace_bytes(NC, V.T[l], T1) + 1024;
         need += (size_t)B * (roitr_coarse_scratch_floats(V.nmax[3], V.nmax[3]) + (size_t)2 * V.nmax[3] * V.nmax[3]) * 4 + 1024;
@@ -1539,7 +1545,8 @@ static int forward_body(void* h, const RoitrForwardIO* io, hipStream_t st)
     int* src_corr = io->src_corr ? io->src_corr : A.get<int>((size_t)B * P_);
     float* cscore = io->corr_scores ? io->corr_scores : A.get<float>((size_t)B * P_);
     int* n_corr = io->n_corr ? io->n_corr : A.get<int>(B);
-    const size_t NP = (size_t)B * P_;
+    const size_t NP = NPs;
+    int* pair_off = compact ? (io->patch_offsets ? io->patch_offsets : A.get<int>((size_t)B + 1)) : nullptr;
     int* trows = A.get<int>(NP * LIM); int* srows = A.get<int>(NP * LIM);
     int* tmask = io->tgt_knn_masks ? io->tgt_knn_masks : A.get<int>(NP * LIM);
     int* smask = io->src_knn_masks ? io->src_knn_masks : A.get<int>(NP * LIM);
@@ -1576,11 +1583,15 @@ static int forward_body(void* h, const RoitrForwardIO* io, hipStream_t st)
         if (E.cfg.adaptive_coarse) CHK(roitr_adaptive_matching(&c, E.cfg.num_corr, 0.75f, st));
         else CHK(roitr_coarse_matching(&c, st));
     }
+    // the tail runs on the selected patches only (RIGA_v2.py:126-152): their slots, pair after pair
+    if (compact) CHK(roitr_patch_offsets(B, n_corr, (int)NP, pair_off, st));
+    const int* live_patches = compact ? pair_off + B : nullptr;
     {
         RoitrPatch pg; memset(&pg, 0, sizeof(pg));
         pg.pairs = B; pg.num_corr = P_; pg.limit = LIM; pg.n_corr = n_corr; pg.tgt_corr = tgt_corr; pg.src_corr = src_corr;
         pg.node_offset = D.off[3]; pg.pt_offset = D.off[0]; pg.knn_idx = kidx; pg.knn_mask = kmask; pg.points = pts_out;
         pg.tgt_rows = trows; pg.src_rows = srows; pg.tgt_masks = tmask; pg.src_masks = smask; pg.tgt_pts = tpts; pg.src_pts = spts;
+        pg.pair_off = pair_off; pg.slots = compact ? (int)NP : 0;
         CHK(roitr_patch_gather(&pg, st));
     }
     {   // matching_scores = einsum('bnd,bmd->bnm', tgt, src) / sqrt(C)   (RIGA_v2.py:150-152)
@@ -1588,6 +1599,7 @@ static int forward_body(void* h, const RoitrForwardIO* io, hipStream_t st)
         g.M = LIM; g.N = LIM; g.K = C4; g.A = point_feats; g.lda = C4; g.a_idx = trows; g.a_limit = T1; g.W = point_feats; g.ldw = C4;
         g.w_idx = srows; g.w_limit = T1; g.alpha = 1.0f / sqrtf((float)C4); g.C = mscore; g.ldc = LIM; g.batch = (int)NP;
         g.sC = (long)LIM * LIM; g.sAidx = LIM; g.sWidx = LIM;
+        g.batch_live = live_patches;   // compacted list: the products of the live patches only
         if (E.cfg.operand_dtype == 1) {
             // bf16 operand mode: both operands of this contraction are the point descriptors -- one bf16 copy of them, products on
             // the bf16 matrix cores, fp32 accumulate; the scores (and the optimal transport behind them) stay fp32
@@ -1606,6 +1618,7 @@ static int forward_body(void* h, const RoitrForwardIO* io, hipStream_t st)
         RoitrOT o; memset(&o, 0, sizeof(o));
         o.pairs = B; o.num_corr = P_; o.limit = LIM; o.num_iter = 100; o.n_corr = n_corr; o.scores = mscore; o.row_masks = tmask;
         o.col_masks = smask; o.alpha = E.ot_alpha; o.out = ot;
+        o.pair_off = pair_off; o.slots = compact ? (int)NP : 0;
         CHK(roitr_optimal_transport(&o, st));
     }
     {
@@ -1615,6 +1628,7 @@ static int forward_body(void* h, const RoitrForwardIO* io, hipStream_t st)
         fm.global_scores = E.cfg.fine_use_global_score ? cscore : nullptr;
         fm.flags = flags; fm.counts = counts; fm.offsets = offsets; fm.n_out = n_out;
         fm.out_row_pts = o_t; fm.out_col_pts = o_s; fm.out_scores = o_sc; fm.out_patch = io->out_patch; fm.out_cap = (long)cap;
+        fm.pair_off = pair_off; fm.slots = compact ? (int)NP : 0; fm.pair_starts = io->pair_starts;
         CHK(roitr_fine_matching(&fm, st));
     }
     roitr_prof_end(ROITR_PROF_PH_MATCH, st);
@@ -1645,8 +1659,9 @@ extern "C" int roitr_engine_forward_graph(void* h, const RoitrForwardIO* io, hip
     for (int c = 0; c < 2 * io->pairs; ++c) { key.push_back(io->n_points[c]); int s4[4]; roitr_level_sizes(io->n_points[c], s4); t4 += s4[3]; }
     {   // every pointer field of the io block (they follow `n_points` in the struct)
         const void* const* pp = reinterpret_cast<const void* const*>(&io->points_geom);
-        const size_t n_ptr = (reinterpret_cast<const char*>(io) + sizeof(RoitrForwardIO) - reinterpret_cast<const char*>(&io->points_geom)) / sizeof(void*);
+        const size_t n_ptr = (reinterpret_cast<const char*>(&io->patch_slots) - reinterpret_cast<const char*>(&io->points_geom)) / sizeof(void*);
         for (size_t i = 0; i < n_ptr; ++i) key.push_back((long)(uintptr_t)pp[i]);
+        key.push_back(io->patch_slots);
     }
     Engine::GraphEntry* ge = nullptr;
     for (auto& g : E.graphs) if (g.key == key) { ge = &g; break; }

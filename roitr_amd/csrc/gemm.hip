@@ -83,8 +83,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(RoitrGemm g, int nx, int ny, 
     float* Bs = smem + 2 * BM * LDR;
     // 1-D XCD-aware tile grid: XCD x = blockIdx % 8 gets the contiguous tile range [x T/8, (x+1) T/8), N tiles of one
     // row block adjacent, so the A rows of a row block are fetched into ONE L2 instead of nx different ones
-    const int tile = xcd_block_id(T);
-    if (tile >= T) return;
+    if (g.batch_live) {   // batch list with a device-side live length: the tile map covers the live tiles only (all eight XCDs stay busy)
+        const long tl = (long)*g.batch_live * nx * ny;
+        if (tl < T) T = (int)tl;
+    }
+    const int tile = xcd_block_id_live(T);
+    if (tile < 0) return;
     const int bz = tile / (nx * ny);
     const int rem = tile - bz * nx * ny;
     const int by_ = rem / nx, bx_ = rem - by_ * nx;
@@ -461,8 +465,12 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(RoitrGemm g, int nx, in
 {
     __shared__ __attribute__((aligned(16))) float As[SM * SLD];
     __shared__ __attribute__((aligned(16))) float Bs[SM * SLD];
-    const int tile = xcd_block_id(T);
-    if (tile >= T) return;
+    if (g.batch_live) {   // batch list with a device-side live length: the tile map covers the live tiles only (all eight XCDs stay busy)
+        const long tl = (long)*g.batch_live * nx * ny;
+        if (tl < T) T = (int)tl;
+    }
+    const int tile = xcd_block_id_live(T);
+    if (tile < 0) return;
     const int bz = tile / (nx * ny);
     const int rem = tile - bz * nx * ny;
     const int by_ = rem / nx, bx_ = rem - by_ * nx;
@@ -595,7 +603,9 @@ extern "C" int roitr_gemm(const RoitrGemm* g, hipStream_t stream)
     const int T = (int)Tl;
     const unsigned grid = (unsigned)xcd_grid(T);
     const int prof_cls = roitr_prof_is_enabled() ? roitr_gemm_prof_class(g) : ROITR_PROF_GEMM;
-    roitr_prof_begin2(prof_cls, 2.0 * g->M * g->N * (double)g->K * g->batch, roitr_gemm_algorithmic_bytes(g), stream);
+    if (g->batch_live)   // priced on the LIVE batches (device-side count), not on the capacity of the list
+        roitr_prof_begin_live(prof_cls, 2.0 * g->M * g->N * (double)g->K, roitr_gemm_algorithmic_bytes(g) / g->batch, g->batch_live, stream);
+    else roitr_prof_begin2(prof_cls, 2.0 * g->M * g->N * (double)g->K * g->batch, roitr_gemm_algorithmic_bytes(g), stream);
     // Measured and dropped (A/B on the forward bench): 64x128 / 128x128 multi-accumulator tiles (19.7 / 22.0 vs 16.9 ms of
     // GEMM per 128-pair forward), two K-slabs per barrier pair (7.9 vs 7.5 ms at 32 pairs), and a persistent-block
     // variant that opens the next tile (row pointers + first slab in flight) before the store epilogue (18.3-19.8 vs

@@ -81,8 +81,12 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(RoitrGemm g, int nx, int
     __shared__ __attribute__((aligned(16))) unsigned char smem_raw[STAGE_BYTES > TILE_BYTES ? STAGE_BYTES : TILE_BYTES];
     unsigned short* As = reinterpret_cast<unsigned short*>(smem_raw);
     unsigned short* Bs = As + BM * PITCH;
-    const int tile = xcd_block_id(T);
-    if (tile >= T) return;
+    if (g.batch_live) {   // batch list with a device-side live length: the tile map covers the live tiles only (all eight XCDs stay busy)
+        const long tl = (long)*g.batch_live * nx * ny;
+        if (tl < T) T = (int)tl;
+    }
+    const int tile = xcd_block_id_live(T);
+    if (tile < 0) return;
     const int bz = tile / (nx * ny);
     const int rem = tile - bz * nx * ny;
     const int by_ = rem / nx, bx_ = rem - by_ * nx;
@@ -318,7 +322,9 @@ int roitr_gemm_bf16_launch(const RoitrGemm* g, hipStream_t stream)
     const unsigned grid = (unsigned)xcd_grid(T);
     const bool a_h = (g->bf16 & ROITR_BF16_A) != 0;
     const int prof_cls = roitr_prof_is_enabled() ? roitr_gemm_prof_class(g) : ROITR_PROF_GEMM;
-    roitr_prof_begin2(prof_cls, 2.0 * g->M * g->N * (double)g->K * g->batch, roitr_gemm_algorithmic_bytes(g), stream);
+    if (g->batch_live)   // priced on the LIVE batches (device-side count), not on the capacity of the list
+        roitr_prof_begin_live(prof_cls, 2.0 * g->M * g->N * (double)g->K, roitr_gemm_algorithmic_bytes(g) / g->batch, g->batch_live, stream);
+    else roitr_prof_begin2(prof_cls, 2.0 * g->M * g->N * (double)g->K * g->batch, roitr_gemm_algorithmic_bytes(g), stream);
     if (g->ln_gamma) {
         if (a_h) {
             if (tn == 1) gemm_bf16_kernel<false, 1, true><<<grid, 256, 0, stream>>>(*g, nx, ny, T);

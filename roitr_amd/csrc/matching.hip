@@ -360,14 +360,59 @@ __global__ __launch_bounds__(1024) void adaptive_match_kernel(RoitrCoarse a, int
 
 // ------------------------------------------------------------------ patch assembly (RIGA_v2.py:125-147)
 // per (pair, corr p, slot i): global feature-row index (or -1 = zero pad), knn point, mask, for both sides
-__global__ void patch_gather_kernel(RoitrPatch a)
+// Patch slot -> (pair, position in the pair's coarse list).  Strided layout (pair_off == NULL): slot = pair * num_corr + p, live
+// while p < n_corr[pair].  Compacted layout (round 6; the adaptive 4DMatch matching selects anything between 128 and n_t * n_s
+// node pairs per cloud pair, RIGA_v2.py:126-152 runs the tail on the SELECTED ones only): the live patches of all pairs back to
+// back, pair b owns slots [pair_off[b], pair_off[b + 1]); slots from pair_off[pairs] on are dead and never touched.
+struct PatchSlot { int pair, p; bool live; };
+__device__ __forceinline__ PatchSlot patch_slot(int slot, int pairs, int num_corr, const int* __restrict__ n_corr, const int* __restrict__ pair_off)
+{
+    PatchSlot r;
+    if (pair_off) {
+        r.live = slot < pair_off[pairs];
+        r.pair = r.live ? segment_of(slot, pair_off + 1, pairs) : 0;
+        r.p = slot - pair_off[r.pair];
+    } else {
+        r.pair = slot / num_corr; r.p = slot % num_corr;
+        r.live = r.p < n_corr[r.pair];
+    }
+    return r;
+}
+
+// pair_off[0] = 0, pair_off[b + 1] = min(slots, n_corr[0] + ... + n_corr[b]): one block, pairs <= a few thousand
+__global__ __launch_bounds__(1024) void patch_offsets_kernel(int pairs, const int* __restrict__ n_corr, int slots, int* __restrict__ pair_off)
+{
+    __shared__ int wsum[16];
+    __shared__ int carry_s;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) { carry_s = 0; pair_off[0] = 0; }
+    __syncthreads();
+    for (int base = 0; base < pairs; base += 1024) {
+        const int i = base + tid;
+        int incl = i < pairs ? n_corr[i] : 0;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        int wb = 0;
+        for (int w = 0; w < wave; ++w) wb += wsum[w];
+        const int carry = carry_s;
+        if (i < pairs) pair_off[i + 1] = min(slots, carry + wb + incl);
+        __syncthreads();
+        if (tid == 1023) carry_s = carry + wb + incl;
+        __syncthreads();
+    }
+}
+
+__global__ void patch_gather_kernel(RoitrPatch a, long total)
 {
     const long t = blockIdx.x * 256L + threadIdx.x;
-    const long per_pair = (long)a.num_corr * a.limit;
-    if (t >= per_pair * a.pairs) return;
-    const int pair = (int)(t / per_pair);
-    const int p = (int)((t % per_pair) / a.limit), i = (int)(t % a.limit);
-    const bool live = p < a.n_corr[pair];
+    if (t >= total) return;
+    const int slot = (int)(t / a.limit), i = (int)(t % a.limit);
+    const PatchSlot ps = patch_slot(slot, a.pairs, a.num_corr, a.n_corr, a.pair_off);
+    if (a.pair_off && !ps.live) return;   // compacted: dead slots are never read
+    const int pair = ps.pair, p = ps.p;
+    const bool live = ps.live;
 #pragma unroll
     for (int side = 0; side < 2; ++side) {  // 0 = tgt (rows of the score matrix), 1 = src (columns)
         const int cloud = side == 0 ? a.pairs + pair : pair;
@@ -440,9 +485,8 @@ __global__ __launch_bounds__(64) void ot_kernel(RoitrOT a, unsigned long long* s
     __shared__ float T[64][65];
     __shared__ __attribute__((aligned(16))) float av[64];
     const int patch = blockIdx.x;
-    const int pair = patch / a.num_corr, p = patch % a.num_corr;
     const int lane = threadIdx.x;
-    if (p >= a.n_corr[pair]) return;
+    if (a.pair_off ? patch >= a.pair_off[a.pairs] : (patch % a.num_corr) >= a.n_corr[patch / a.num_corr]) return;
     float* out = a.out + (size_t)patch * OTN * OTN;
     const float alpha = *a.alpha;
     const float* sc = a.scores + (size_t)patch * 64 * 64;
@@ -587,9 +631,8 @@ __global__ __launch_bounds__(64) void ot_log_kernel(RoitrOT a, unsigned long lon
 {
     __shared__ float T[64][65];
     const int patch = blockIdx.x;
-    const int pair = patch / a.num_corr, p = patch % a.num_corr;
     const int lane = threadIdx.x;
-    if (p >= a.n_corr[pair]) return;
+    if (a.pair_off ? patch >= a.pair_off[a.pairs] : (patch % a.num_corr) >= a.n_corr[patch / a.num_corr]) return;
     float* out = a.out + (size_t)patch * OTN * OTN;
     {
         const float corner = out[64 * OTN + 64];
@@ -667,14 +710,12 @@ __global__ __launch_bounds__(256) void fine_flag_kernel(RoitrFine a)
     __shared__ unsigned long long rowm[64], colm[64];
     __shared__ int cnt_s[4];
     const int patch = blockIdx.x;
-    const int pair = patch / a.num_corr, p = patch % a.num_corr;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int L = a.limit;   // == 64 (checked by the launcher)
     unsigned char* fl = a.flags + (size_t)patch * L * L;
     uint4* fl16 = reinterpret_cast<uint4*>(fl) + tid;   // thread -> row tid/4, 16 columns from (tid%4)*16
-    if (p >= a.n_corr[pair]) {
-        *fl16 = make_uint4(0, 0, 0, 0);
-        if (tid == 0) a.counts[patch] = 0;
+    if (a.pair_off ? patch >= a.pair_off[a.pairs] : (patch % a.num_corr) >= a.n_corr[patch / a.num_corr]) {
+        if (tid == 0) a.counts[patch] = 0;   // the emitter leaves on counts == 0 before it reads the flags of a dead patch
         return;
     }
     const float* sc = a.ot + (size_t)patch * (L + 1) * (L + 1);
@@ -735,8 +776,11 @@ __global__ __launch_bounds__(256) void fine_flag_kernel(RoitrFine a)
 }
 
 // exclusive scan of per-patch counts (single block), total -> *n_out
+// pair_starts (optional, pairs + 1 entries): first output row of every PAIR (+ the total): what a caller needs to split the
+// correspondence list per pair without touching the per-patch offsets
 __global__ __launch_bounds__(1024) void fine_scan_kernel(int n, const int* __restrict__ counts, int* __restrict__ offsets, int* __restrict__ n_out,
-                                                         long out_cap)
+                                                         long out_cap, int pairs, int num_corr, const int* __restrict__ pair_off,
+                                                         int* __restrict__ pair_starts)
 {
     __shared__ int wsum[16];
     __shared__ int carry_s;
@@ -761,7 +805,15 @@ __global__ __launch_bounds__(1024) void fine_scan_kernel(int n, const int* __res
         if (tid == 1023) carry_s = carry + wb + incl;
         __syncthreads();
     }
-    if (tid == 0) *n_out = (out_cap > 0 && carry_s > out_cap) ? (int)out_cap : carry_s;
+    const int total = (out_cap > 0 && carry_s > out_cap) ? (int)out_cap : carry_s;
+    if (tid == 0) *n_out = total;
+    if (pair_starts) {
+        __threadfence_block();
+        for (int b = tid; b <= pairs; b += 1024) {
+            const long first = pair_off ? (long)pair_off[b] : (long)b * num_corr;   // first patch slot of pair b (pairs: one past the last)
+            pair_starts[b] = (b < pairs && first < n) ? offsets[first] : total;
+        }
+    }
 }
 
 // row-major (patch, i, j) compaction -- the order of torch.nonzero (modules.py:282)
@@ -787,7 +839,11 @@ __global__ __launch_bounds__(256) void fine_emit_kernel(RoitrFine a)
     __syncthreads();
     int pos = a.offsets[patch] + incl - c;
     for (int w = 0; w < wave; ++w) pos += wsum[w];
-    const float g = a.global_scores ? a.global_scores[patch] : 1.0f;
+    float g = 1.0f;
+    if (a.global_scores) {   // coarse score of the patch's node pair: (pairs, num_corr), strided in both layouts
+        const PatchSlot ps = patch_slot(patch, a.pairs, a.num_corr, a.n_corr, a.pair_off);
+        g = a.global_scores[(size_t)ps.pair * a.num_corr + ps.p];
+    }
     const long cap = a.out_cap > 0 ? a.out_cap : 0x7fffffffL;
 #pragma unroll
     for (int u = 0; u < per; ++u) {
@@ -862,9 +918,18 @@ extern "C" int roitr_adaptive_matching(const RoitrCoarse* a, int min_num, float 
 
 extern "C" int roitr_patch_gather(const RoitrPatch* a, hipStream_t stream)
 {
-    const long total = (long)a->pairs * a->num_corr * a->limit;
+    const long total = (a->pair_off ? (long)a->slots : (long)a->pairs * a->num_corr) * a->limit;
     if (total <= 0) return ROITR_OK;
-    patch_gather_kernel<<<div_up(total, 256), 256, 0, stream>>>(*a);
+    patch_gather_kernel<<<div_up(total, 256), 256, 0, stream>>>(*a, total);
+    ROITR_LAUNCH_CHECK();
+    return ROITR_OK;
+}
+
+extern "C" int roitr_patch_offsets(int pairs, const int* n_corr, int slots, int* pair_off, hipStream_t stream)
+{
+    if (pairs <= 0) return ROITR_OK;
+    if (!n_corr || !pair_off || slots < 0) return ROITR_ERR_ARG;
+    patch_offsets_kernel<<<1, 1024, 0, stream>>>(pairs, n_corr, slots, pair_off);
     ROITR_LAUNCH_CHECK();
     return ROITR_OK;
 }
@@ -917,12 +982,15 @@ extern "C" int roitr_optimal_transport(const RoitrOT* a, hipStream_t stream)
 {
     if (a->pairs <= 0) return ROITR_OK;
     if (a->limit != 64) return ROITR_ERR_UNSUPPORTED;
-    roitr_prof_begin(ROITR_PROF_OT, (double)a->pairs * a->num_corr * (64.0 * 64 + 65.0 * 65) * 4.0, stream);
+    const int patches = a->pair_off ? a->slots : a->pairs * a->num_corr;
+    if (patches <= 0) return ROITR_OK;
+    if (a->pair_off) roitr_prof_begin_live(ROITR_PROF_OT, (64.0 * 64 + 65.0 * 65) * 4.0, 0.0, a->pair_off + a->pairs, stream);   // live patches
+    else roitr_prof_begin(ROITR_PROF_OT, (double)patches * (64.0 * 64 + 65.0 * 65) * 4.0, stream);
     // data-dependent work of this stage (roitr_ot_stats): live patches, Sinkhorn iterations skipped by the exact fixed-point exit,
     // patches the exponential form handed to the log-domain kernel
     unsigned long long* sd = ot_stats().for_current_device();
-    ot_kernel<<<a->pairs * a->num_corr, 64, 0, stream>>>(*a, sd);
-    ot_log_kernel<<<a->pairs * a->num_corr, 64, 0, stream>>>(*a, sd);   // the patches the exponential form declined; the others leave at once
+    ot_kernel<<<patches, 64, 0, stream>>>(*a, sd);
+    ot_log_kernel<<<patches, 64, 0, stream>>>(*a, sd);   // the patches the exponential form declined; the others leave at once
     roitr_prof_end(ROITR_PROF_OT, stream);
     ROITR_LAUNCH_CHECK();
     return ROITR_OK;
@@ -932,10 +1000,15 @@ extern "C" int roitr_fine_matching(const RoitrFine* a, hipStream_t stream)
 {
     if (a->pairs <= 0) return ROITR_OK;
     if (a->limit != 64) return ROITR_ERR_UNSUPPORTED;
-    const int patches = a->pairs * a->num_corr;
+    const int patches = a->pair_off ? a->slots : a->pairs * a->num_corr;
+    if (patches <= 0) {
+        ROITR_HIP(hipMemsetAsync(a->n_out, 0, sizeof(int), stream));
+        if (a->pair_starts) ROITR_HIP(hipMemsetAsync(a->pair_starts, 0, sizeof(int) * ((size_t)a->pairs + 1), stream));
+        return ROITR_OK;
+    }
     fine_flag_kernel<<<patches, 256, 0, stream>>>(*a);
     ROITR_LAUNCH_CHECK();
-    fine_scan_kernel<<<1, 1024, 0, stream>>>(patches, a->counts, a->offsets, a->n_out, a->out_cap);
+    fine_scan_kernel<<<1, 1024, 0, stream>>>(patches, a->counts, a->offsets, a->n_out, a->out_cap, a->pairs, a->num_corr, a->pair_off, a->pair_starts);
     ROITR_LAUNCH_CHECK();
     fine_emit_kernel<<<patches, 256, 0, stream>>>(*a);
     ROITR_LAUNCH_CHECK();

@@ -10,7 +10,13 @@
 #include "roitr_engine.h"
 
 namespace {
-struct Rec { int cls; hipEvent_t a, b; double bytes, aux; };
+// pin >= 0: a launch whose work is only known on the device (a batch list with a device-side live length): bytes / aux are PER UNIT,
+// the unit count arrives in g_pin[pin] by an async copy queued in front of the launch, and the open phases (phase_mask) get their
+// share when the bracket is folded instead of when it is opened
+struct Rec { int cls; hipEvent_t a, b; double bytes, aux; int pin = -1; unsigned phase_mask = 0; };
+constexpr int PIN_SLOTS = 4096;
+int* g_pin = nullptr;
+int g_pin_next = 0;
 std::mutex g_mu;
 bool g_on = false;
 std::vector<Rec> g_open;   // begun, not ended (one per class at a time)
@@ -19,6 +25,26 @@ std::vector<hipEvent_t> g_pool;
 double g_ms[ROITR_PROF_CLASSES], g_bytes[ROITR_PROF_CLASSES], g_aux[ROITR_PROF_CLASSES];
 long g_launches[ROITR_PROF_CLASSES];
 double g_next_bytes[ROITR_PROF_CLASSES];
+
+bool is_mfma(int cls) { return cls == ROITR_PROF_GEMM || cls == ROITR_PROF_GEMM_HBM || cls == ROITR_PROF_GEO_EMBED; }
+
+void fold(Rec& r)
+{
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+        double bytes = r.bytes, aux = r.aux;
+        if (r.pin >= 0) {
+            const double units = (double)g_pin[r.pin];
+            bytes *= units; aux *= units;
+            for (int ph = ROITR_PROF_PH_GEOM; ph <= ROITR_PROF_PH_FORWARD; ++ph)
+                if (r.phase_mask & (1u << ph)) {
+                    if (is_mfma(r.cls)) { g_bytes[ph] += bytes; g_aux[ph] += aux; } else g_aux[ph] += bytes;
+                }
+        }
+        g_ms[r.cls] += ms; g_bytes[r.cls] += bytes; g_aux[r.cls] += aux; g_launches[r.cls] += 1;
+    }
+    g_pool.push_back(r.a); g_pool.push_back(r.b);
+}
 
 hipEvent_t get_event()
 {
@@ -34,10 +60,7 @@ void recycle()
 {
     size_t n = 0;
     while (n < g_done.size() && hipEventQuery(g_done[n].b) == hipSuccess) {
-        Rec& r = g_done[n];
-        float ms = 0.f;
-        if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) { g_ms[r.cls] += ms; g_bytes[r.cls] += r.bytes; g_aux[r.cls] += r.aux; g_launches[r.cls] += 1; }
-        g_pool.push_back(r.a); g_pool.push_back(r.b);
+        fold(g_done[n]);
         ++n;
     }
     if (n) g_done.erase(g_done.begin(), g_done.begin() + n);
@@ -47,9 +70,7 @@ void drain()
 {
     for (auto& r : g_done) {
         (void)hipEventSynchronize(r.b);
-        float ms = 0.f;
-        if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) { g_ms[r.cls] += ms; g_bytes[r.cls] += r.bytes; g_aux[r.cls] += r.aux; g_launches[r.cls] += 1; }
-        g_pool.push_back(r.a); g_pool.push_back(r.b);
+        fold(r);
     }
     g_done.clear();
 }
@@ -108,22 +129,39 @@ extern "C" void roitr_prof_next_bytes(int cls, double bytes)
 
 void roitr_prof_begin(int cls, double bytes, hipStream_t st) { roitr_prof_begin2(cls, bytes, 0.0, st); }
 
-void roitr_prof_begin2(int cls, double bytes, double aux, hipStream_t st)
+static void begin_impl(int cls, double bytes, double aux, const int* dev_units, hipStream_t st);
+void roitr_prof_begin2(int cls, double bytes, double aux, hipStream_t st) { begin_impl(cls, bytes, aux, nullptr, st); }
+// bytes / aux PER UNIT; the number of units is the device int *dev_units at the time the launch runs (fetched by an async copy on `st`)
+void roitr_prof_begin_live(int cls, double bytes_per_unit, double aux_per_unit, const int* dev_units, hipStream_t st)
+{
+    begin_impl(cls, bytes_per_unit, aux_per_unit, dev_units, st);
+}
+
+static void begin_impl(int cls, double bytes, double aux, const int* dev_units, hipStream_t st)
 {
     if (!g_on) return;
     std::lock_guard<std::mutex> lk(g_mu);
     if (g_pool.size() < 2 && g_done.size() > 256) recycle();
     Rec r; r.cls = cls; r.bytes = bytes >= 0.0 ? bytes : g_next_bytes[cls]; r.aux = aux; r.a = get_event(); r.b = get_event();
     if (bytes < 0.0) g_next_bytes[cls] = 0.0;   // consumed: a later launch of the class without its own figure counts 0
+    if (dev_units) {
+        if (!g_pin && hipHostMalloc((void**)&g_pin, sizeof(int) * PIN_SLOTS, hipHostMallocDefault) != hipSuccess) g_pin = nullptr;
+        if (g_pin) {
+            r.pin = g_pin_next; g_pin_next = (g_pin_next + 1) % PIN_SLOTS;
+            g_pin[r.pin] = 0;
+            (void)hipMemcpyAsync(&g_pin[r.pin], dev_units, sizeof(int), hipMemcpyDeviceToHost, st);
+        }
+    }
     // Work issued inside an open engine phase is also booked on the phase: the "bytes" of a phase class are the FLOPs of its
     // GEMM / geo_embed launches (bench.py prices the global-transformer phase against the MFMA peak with them), its "aux" the
     // algorithmic HBM bytes of every instrumented launch inside it (MFMA classes carry them in aux, the others in bytes)
-    const bool mfma = cls == ROITR_PROF_GEMM || cls == ROITR_PROF_GEMM_HBM || cls == ROITR_PROF_GEO_EMBED;
+    const bool mfma = is_mfma(cls);
     const bool phase = cls >= ROITR_PROF_PH_GEOM && cls <= ROITR_PROF_PH_FORWARD;
     if (!phase && cls != ROITR_PROF_GEO_ALGO)
         for (auto& o : g_open)
             if (o.cls >= ROITR_PROF_PH_GEOM && o.cls <= ROITR_PROF_PH_FORWARD) {
-                if (mfma) { o.bytes += r.bytes; o.aux += r.aux; }
+                if (r.pin >= 0) r.phase_mask |= 1u << o.cls;   // priced when the unit count has arrived (fold)
+                else if (mfma) { o.bytes += r.bytes; o.aux += r.aux; }
                 else if (cls == ROITR_PROF_LOCAL_BLOCK) { o.bytes += r.aux; o.aux += r.bytes; }   // HBM bytes in `bytes`, FLOPs in `aux`
                 else o.aux += r.bytes;
             }

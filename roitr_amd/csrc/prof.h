@@ -29,6 +29,8 @@ enum {
 
 void roitr_prof_begin(int cls, double bytes, hipStream_t st);
 void roitr_prof_begin2(int cls, double bytes, double aux, hipStream_t st);   // aux: second accumulator (prof.cpp roitr_prof_read_aux)
+// a launch over a batch list whose live length is a device int: bytes / aux per unit, multiplied by *dev_units when the bracket is folded
+void roitr_prof_begin_live(int cls, double bytes_per_unit, double aux_per_unit, const int* dev_units, hipStream_t st);
 void roitr_prof_end(int cls, hipStream_t st);
 void roitr_prof_note(int cls, double v);   // adds v to the class total without a timed bracket
 extern "C" void roitr_prof_enable(int on);

@@ -49,14 +49,16 @@ class _Coarse(ctypes.Structure):
 
 class _OT(ctypes.Structure):
     _fields_ = [("pairs", ctypes.c_int), ("num_corr", ctypes.c_int), ("limit", ctypes.c_int), ("num_iter", ctypes.c_int),
-                ("n_corr", _P), ("scores", _P), ("row_masks", _P), ("col_masks", _P), ("alpha", _P), ("out", _P)]
+                ("n_corr", _P), ("scores", _P), ("row_masks", _P), ("col_masks", _P), ("alpha", _P), ("out", _P),
+                ("pair_off", _P), ("slots", ctypes.c_int)]
 
 
 class _Fine(ctypes.Structure):
     _fields_ = [("pairs", ctypes.c_int), ("num_corr", ctypes.c_int), ("limit", ctypes.c_int), ("k", ctypes.c_int),
                 ("mutual", ctypes.c_int), ("conf", ctypes.c_float), ("n_corr", _P), ("ot", _P), ("row_masks", _P),
                 ("col_masks", _P), ("row_pts", _P), ("col_pts", _P), ("global_scores", _P), ("flags", _P), ("counts", _P),
-                ("offsets", _P), ("n_out", _P), ("out_row_pts", _P), ("out_col_pts", _P), ("out_scores", _P), ("out_patch", _P), ("out_cap", ctypes.c_long)]
+                ("offsets", _P), ("n_out", _P), ("out_row_pts", _P), ("out_col_pts", _P), ("out_scores", _P), ("out_patch", _P), ("out_cap", ctypes.c_long),
+                ("pair_off", _P), ("slots", ctypes.c_int), ("pair_starts", _P)]
 
 
 def point_to_node_partition(points, nodes, point_limit):
@@ -154,7 +156,7 @@ class _Gemm(ctypes.Structure):
                 ("ln_gamma", _P), ("ln_beta", _P), ("ln_res", _P), ("ln_res_idx", _P), ("ln_post", _P),
                 ("ln_relu", ctypes.c_int), ("ln_eps", ctypes.c_float), ("bf16", ctypes.c_int),
                 ("A_cat", _P), ("lda_cat", ctypes.c_int), ("k_cat", ctypes.c_int),
-                ("ip_feat", _P), ("ip_idx", _P), ("ip_dist2", _P), ("a_cat_idx", _P)]
+                ("ip_feat", _P), ("ip_idx", _P), ("ip_dist2", _P), ("a_cat_idx", _P), ("batch_live", _P)]
 
 
 BF16_W, BF16_A, BF16_C = 1, 2, 4   # RoitrGemm::bf16 flags (include/roitr_engine.h)

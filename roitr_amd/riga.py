@@ -142,7 +142,7 @@ class _CForwardIO(ctypes.Structure):
                 ("tgt_knn_pts", _P), ("src_knn_pts", _P), ("tgt_knn_masks", _P), ("src_knn_masks", _P),
                 ("matching_scores", _P), ("out_tgt_pts", _P), ("out_src_pts", _P), ("out_scores", _P), ("out_patch", _P),
                 ("fine_offsets", _P), ("n_out", _P), ("gt_node_occ", _P), ("gt_corr_idx", _P), ("gt_corr_overlaps", _P),
-                ("gt_corr_count", _P), ("inputs_ready", _P)]
+                ("gt_corr_count", _P), ("inputs_ready", _P), ("patch_offsets", _P), ("pair_starts", _P), ("patch_slots", ctypes.c_int)]
 
 
 def _cfg_get(config, key, default=None):
@@ -195,6 +195,11 @@ class RIGA_v2(nn.Module):
         self.operand_dtype = str(_cfg_get(config, "operand_dtype", "f32"))
         if self.operand_dtype not in ("f32", "bf16"):
             raise ValueError(f"operand_dtype must be 'f32' or 'bf16', got {self.operand_dtype!r}")
+        # not a reference key (4DMatch only): AVERAGE number of patch slots per pair a call's per-patch buffers are sized for.  The adaptive
+        # matching may select every node pair (n4max^2 = 15 625 per pair at N = 8000: 33 KB of tail buffers each); the reference runs the
+        # tail on the selected ones only (RIGA_v2.py:126-152), so does the engine (compacted patch list).  A call that selects more than
+        # B x this many is repeated once with the exact number (finish_batch): results never depend on the value.
+        self.patch_slots_per_pair = int(_cfg_get(config, "patch_slots_per_pair", 2048))
         if self.fine_use_dustbin:
             raise NotImplementedError("fine_matching_use_dustbin=True is not on the reference's test configs")
         for key, shape, kind in state_dict_layout(self.factor, self.architecture):
@@ -361,7 +366,38 @@ class RIGA_v2(nn.Module):
                                "every pair its ground-truth transform")
         return all(flags)
 
-    def launch_batch(self, pairs, want_gt=True, graph=False, inputs_resident=None):
+    def _patch_geometry(self, B, n4, patch_slots=None):
+        """(P, slots): coarse-list slots per pair, and patch slots of the whole call.  3DMatch: P = num_est_coarse_corr, slots = B * P
+        (strided: patch p of pair b at slot b * P + p).  4DMatch: P = n4max^2 bounds the coarse lists only, the per-patch buffers
+        hold the selected patches of all pairs back to back in `slots` slots (RoitrForwardIO::patch_slots)."""
+        if self.factor == 1:
+            P = self.num_est_coarse_corr
+            return P, B * P
+        n4max = max(n4)
+        P = n4max * n4max
+        slots = B * min(P, self.patch_slots_per_pair) if patch_slots is None else int(patch_slots)
+        return P, max(1, min(slots, B * P))
+
+    def _alloc_outputs(self, dev, B, T, n4, have_gt, patch_slots=None):
+        f32, i32 = torch.float32, torch.int32
+        T4, n4max = sum(n4), max(n4)
+        C = 256 * self.factor
+        P, S = self._patch_geometry(B, n4, patch_slots)
+        Lm = self.point_per_patch
+        cap = S * Lm * self.fine_topk * (1 if self.fine_mutual else 2)   # row top-k OR column top-k when not mutual
+        z = lambda shape, dt=f32: torch.empty(shape, dtype=dt, device=dev)  # every buffer is fully written by the engine (dead patch slots are never read)
+        out = dict(node_xyz=z((T4, 3)), node_feats=z((T4, C)), point_feats=z((T, C)), node_masks=z((T4,), i32),
+                   node_knn_idx=z((T4, Lm), i32), node_knn_mask=z((T4, Lm), i32), tgt_corr=z((B, P), i32), src_corr=z((B, P), i32),
+                   corr_scores=z((B, P)), n_corr=z((B,), i32), tgt_knn_pts=z((S, Lm, 3)), src_knn_pts=z((S, Lm, 3)),
+                   tgt_knn_masks=z((S, Lm), i32), src_knn_masks=z((S, Lm), i32), matching_scores=z((S, Lm + 1, Lm + 1)),
+                   out_tgt_pts=z((cap, 3)), out_src_pts=z((cap, 3)), out_scores=z((cap,)), out_patch=z((cap,), i32),
+                   fine_offsets=z((S,), i32), n_out=z((1,), i32), pair_starts=z((B + 1,), i32))
+        if have_gt:
+            out.update(gt_node_occ=z((T4,)), gt_corr_idx=z((B, n4max * n4max, 2), i32), gt_corr_overlaps=z((B, n4max * n4max)),
+                       gt_corr_count=z((B,), i32))
+        return out, P, S
+
+    def launch_batch(self, pairs, want_gt=True, graph=False, inputs_resident=None, patch_slots=None):
         """Enqueue the batched forward on the current stream and return a handle for finish_batch().  Nothing here waits
         for the GPU: a caller may launch batch s+1 before finishing batch s, so the device never idles while the host
         unpacks results (outputs are per-call tensors, the engine's scratch arena is re-used in stream order).
@@ -416,23 +452,7 @@ class RIGA_v2(nn.Module):
         else:
             geom, pout, nrm, feats, rot, trans = pack_inputs()
         n4 = [self.level_sizes(n)[3] for n in n_all]
-        T4 = sum(n4)
-        C = 256 * self.factor
-        n4max = max(n4)
-        P = self.num_est_coarse_corr if self.factor == 1 else n4max * n4max   # adaptive matching: every node pair may qualify
-        Lm = self.point_per_patch
-        cap = B * P * Lm * self.fine_topk * (1 if self.fine_mutual else 2)   # row top-k OR column top-k when not mutual
-        z = lambda shape, dt=f32: torch.empty(shape, dtype=dt, device=dev)  # every buffer is fully written by the engine
-        i32 = torch.int32
-        out = dict(node_xyz=z((T4, 3)), node_feats=z((T4, C)), point_feats=z((T, C)), node_masks=z((T4,), i32),
-                   node_knn_idx=z((T4, Lm), i32), node_knn_mask=z((T4, Lm), i32), tgt_corr=z((B, P), i32), src_corr=z((B, P), i32),
-                   corr_scores=z((B, P)), n_corr=z((B,), i32), tgt_knn_pts=z((B, P, Lm, 3)), src_knn_pts=z((B, P, Lm, 3)),
-                   tgt_knn_masks=z((B, P, Lm), i32), src_knn_masks=z((B, P, Lm), i32), matching_scores=z((B, P, Lm + 1, Lm + 1)),
-                   out_tgt_pts=z((cap, 3)), out_src_pts=z((cap, 3)), out_scores=z((cap,)), out_patch=z((cap,), i32),
-                   fine_offsets=z((B * P,), i32), n_out=z((1,), i32))
-        if have_gt:
-            out.update(gt_node_occ=z((T4,)), gt_corr_idx=z((B, n4max * n4max, 2), i32), gt_corr_overlaps=z((B, n4max * n4max)),
-                       gt_corr_count=z((B,), i32))
+        out, P, slots = self._alloc_outputs(dev, B, T, n4, have_gt, patch_slots)
         io = _CForwardIO()
         io.pairs = B
         arr = (ctypes.c_int * (2 * B))(*n_all)
@@ -440,19 +460,21 @@ class RIGA_v2(nn.Module):
         io.points_geom, io.normals, io.feats, io.points_out = L.ptr(geom), L.ptr(nrm), L.ptr(feats), L.ptr(pout)
         io.rot, io.trans = L.ptr(rot), L.ptr(trans)
         io.inputs_ready = ready.cuda_event if ready is not None else None
+        io.patch_slots = slots if self.factor != 1 else 0
         for k, v in out.items():
             setattr(io, k, L.ptr(v))
         L.check(L.lib().roitr_engine_forward(self._engine, ctypes.byref(io), L.stream_ptr()), "engine_forward")
         # one D2H transfer for all the counts: [first output row of every pair | total | n_corr per pair | gt counts],
         # queued behind this forward only (an event, not a stream sync, is waited on in finish_batch)
-        parts = [out["fine_offsets"].view(B, P)[:, 0], out["n_out"], out["n_corr"]] + ([out["gt_corr_count"]] if have_gt else [])
+        parts = [out["pair_starts"], out["n_corr"]] + ([out["gt_corr_count"]] if have_gt else [])
         meta_dev = torch.cat(parts)
         meta_host = torch.empty(meta_dev.shape, dtype=meta_dev.dtype, pin_memory=True)
         meta_host.copy_(meta_dev, non_blocking=True)
         done = torch.cuda.Event()
         done.record()
         keep = (geom, pout, nrm, feats, rot, trans, arr, meta_dev, ready)   # inputs stay alive until the forward has run
-        return dict(pairs=pairs, out=out, B=B, P=P, n_all=n_all, n4=n4, have_gt=have_gt, meta_host=meta_host, done=done, keep=keep)
+        return dict(pairs=pairs, out=out, B=B, P=P, slots=slots, n_all=n_all, n4=n4, have_gt=have_gt, meta_host=meta_host, done=done, keep=keep,
+                    relaunch=dict(want_gt=want_gt, inputs_resident=inputs_resident))
 
     def _launch_graph(self, pairs, want_gt):
         dev = pairs[0]["src_pcd"].device
@@ -466,22 +488,10 @@ class RIGA_v2(nn.Module):
         ring = self._graph_slots.setdefault(key, {"pos": 0, "slots": []})
         T = sum(n_all)
         n4 = [self.level_sizes(n)[3] for n in n_all]
-        T4, n4max = sum(n4), max(n4)
-        C = 256 * self.factor
-        P = self.num_est_coarse_corr if self.factor == 1 else n4max * n4max
-        Lm = self.point_per_patch
-        cap = B * P * Lm * self.fine_topk * (1 if self.fine_mutual else 2)   # row top-k OR column top-k when not mutual
+        P, slots = self._patch_geometry(B, n4)
         if len(ring["slots"]) < self.GRAPH_RING:
             z = lambda shape, dt=f32: torch.empty(shape, dtype=dt, device=dev)
-            out = dict(node_xyz=z((T4, 3)), node_feats=z((T4, C)), point_feats=z((T, C)), node_masks=z((T4,), i32),
-                       node_knn_idx=z((T4, Lm), i32), node_knn_mask=z((T4, Lm), i32), tgt_corr=z((B, P), i32), src_corr=z((B, P), i32),
-                       corr_scores=z((B, P)), n_corr=z((B,), i32), tgt_knn_pts=z((B, P, Lm, 3)), src_knn_pts=z((B, P, Lm, 3)),
-                       tgt_knn_masks=z((B, P, Lm), i32), src_knn_masks=z((B, P, Lm), i32), matching_scores=z((B, P, Lm + 1, Lm + 1)),
-                       out_tgt_pts=z((cap, 3)), out_src_pts=z((cap, 3)), out_scores=z((cap,)), out_patch=z((cap,), i32),
-                       fine_offsets=z((B * P,), i32), n_out=z((1,), i32))
-            if have_gt:
-                out.update(gt_node_occ=z((T4,)), gt_corr_idx=z((B, n4max * n4max, 2), i32), gt_corr_overlaps=z((B, n4max * n4max)),
-                           gt_corr_count=z((B,), i32))
+            out, P, slots = self._alloc_outputs(dev, B, T, n4, have_gt)
             n_meta = (B + 1) + B + (B if have_gt else 0)
             slot = dict(geom=z((T, 3)), pout=z((T, 3)), nrm=z((T, 3)), feats=z((T, 1)), rot=z((B, 3, 3)) if have_gt else None,
                         trans=z((B, 3)) if have_gt else None, out=out, meta_dev=z((n_meta,), i32),
@@ -491,6 +501,7 @@ class RIGA_v2(nn.Module):
             io.n_points = ctypes.cast(slot["arr"], ctypes.POINTER(ctypes.c_int))
             io.points_geom, io.normals, io.feats, io.points_out = L.ptr(slot["geom"]), L.ptr(slot["nrm"]), L.ptr(slot["feats"]), L.ptr(slot["pout"])
             io.rot, io.trans = L.ptr(slot["rot"]), L.ptr(slot["trans"])
+            io.patch_slots = slots if self.factor != 1 else 0
             for k, v in out.items():
                 setattr(io, k, L.ptr(v))
             slot["io"] = io
@@ -511,7 +522,7 @@ class RIGA_v2(nn.Module):
                 torch.stack([p["rot"].reshape(3, 3).to(f32) for p in pairs], out=slot["rot"])
                 torch.stack([p["trans"].reshape(3).to(f32) for p in pairs], out=slot["trans"])
             L.check(L.lib().roitr_engine_forward_graph(self._engine, ctypes.byref(slot["io"]), L.stream_ptr()), "engine_forward_graph")
-            parts = [out["fine_offsets"].view(B, P)[:, 0], out["n_out"], out["n_corr"]] + ([out["gt_corr_count"]] if have_gt else [])
+            parts = [out["pair_starts"], out["n_corr"]] + ([out["gt_corr_count"]] if have_gt else [])
             torch.cat(parts, out=slot["meta_dev"])
             slot["meta_host"].copy_(slot["meta_dev"], non_blocking=True)
             done = torch.cuda.Event()
@@ -520,7 +531,8 @@ class RIGA_v2(nn.Module):
         # these output slots (a plain launch_batch, evaluate_batch, user code on the current stream) behind it
         torch.cuda.current_stream().wait_stream(gs)
         keep = (slot["geom"], slot["pout"], slot["nrm"], slot["feats"], slot["rot"], slot["trans"], slot["arr"], slot["meta_dev"])
-        return dict(pairs=pairs, out=out, B=B, P=P, n_all=n_all, n4=n4, have_gt=have_gt, meta_host=slot["meta_host"], done=done, keep=keep)
+        return dict(pairs=pairs, out=out, B=B, P=P, slots=slots, n_all=n_all, n4=n4, have_gt=have_gt, meta_host=slot["meta_host"], done=done, keep=keep,
+                    relaunch=dict(want_gt=want_gt, inputs_resident=False))
 
     def max_scores_per_pair(self):
         """Exact upper bound of the correspondences one pair can emit under the 3DMatch settings (mutual top-k fine matching on
@@ -548,6 +560,20 @@ class RIGA_v2(nn.Module):
         h["done"].synchronize()
         meta = h["meta_host"].tolist()
         starts, n_corr, gt_cnt = meta[:B + 1], meta[B + 1:2 * B + 1], meta[2 * B + 1:]
+        if self.factor == 1:
+            p_off = [b * P for b in range(B + 1)]                 # strided patch slots
+        else:
+            p_off = np.concatenate([[0], np.cumsum(n_corr)]).tolist()   # the selected patches of all pairs back to back (roitr_patch_offsets)
+            if p_off[B] > h["slots"]:
+                # more patches selected than the call's buffers hold (the engine cut the tail of the list): the same call once more with
+                # exactly the slots it needs -- the counts are known now.  Results never depend on patch_slots_per_pair.
+                import warnings
+                warnings.warn(f"adaptive matching selected {p_off[B]} patches in a call sized for {h['slots']} "
+                              f"(patch_slots_per_pair = {self.patch_slots_per_pair}): repeating the call with {p_off[B]} slots")
+                again = self.launch_batch(pairs, patch_slots=p_off[B], **h["relaunch"])
+                res = self.finish_batch(again)
+                h.update(out=again["out"], starts=again["starts"], slots=again["slots"], keep=again["keep"])
+                return res
         h["starts"] = starts   # row offsets of every pair in out_scores (+ total): shard.pack_records reads them
         o_pts = np.cumsum([0] + n_all)
         o_nod = np.cumsum([0] + n4)
@@ -573,11 +599,12 @@ class RIGA_v2(nn.Module):
                 r["gt_node_corr_indices"] = r["gt_node_corr_overlaps"] = r["gt_tgt_node_occ"] = r["gt_src_node_occ"] = None
             r["src_node_corr_indices"] = lambda b=b, nc=nc: out["src_corr"][b, :nc].long()
             r["tgt_node_corr_indices"] = lambda b=b, nc=nc: out["tgt_corr"][b, :nc].long()
-            r["src_node_corr_knn_points"] = out["src_knn_pts"][b, :nc]
-            r["tgt_node_corr_knn_points"] = out["tgt_knn_pts"][b, :nc]
-            r["src_node_corr_knn_masks"] = lambda b=b, nc=nc: out["src_knn_masks"][b, :nc].bool()
-            r["tgt_node_corr_knn_masks"] = lambda b=b, nc=nc: out["tgt_knn_masks"][b, :nc].bool()
-            r["matching_scores"] = out["matching_scores"][b, :nc]
+            p0 = p_off[b]
+            r["src_node_corr_knn_points"] = out["src_knn_pts"][p0:p0 + nc]
+            r["tgt_node_corr_knn_points"] = out["tgt_knn_pts"][p0:p0 + nc]
+            r["src_node_corr_knn_masks"] = lambda p0=p0, nc=nc: out["src_knn_masks"][p0:p0 + nc].bool()
+            r["tgt_node_corr_knn_masks"] = lambda p0=p0, nc=nc: out["tgt_knn_masks"][p0:p0 + nc].bool()
+            r["matching_scores"] = out["matching_scores"][p0:p0 + nc]
             s, e = starts[b], starts[b + 1]
             r["tgt_corr_points"] = out["out_tgt_pts"][s:e]
             r["src_corr_points"] = out["out_src_pts"][s:e]

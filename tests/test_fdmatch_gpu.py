@@ -52,3 +52,51 @@ def test_fdmatch_forward():
     assert frac >= 0.995 and err < 1e-4, (frac, err)
     assert common_order_equal(got, want)
     np.testing.assert_allclose(out["gt_tgt_node_occ"].cpu().numpy(), g["out.gt_tgt_node_occ"], atol=1e-6)
+
+
+def test_patch_list_is_compacted_and_an_overfull_call_is_repeated_exactly():
+    """Round 6: the 4DMatch tail (patch assembly, score contraction, optimal transport, fine matching) runs on the patches the
+    adaptive matching SELECTED, laid out back to back over the pairs of the call (RIGA_v2.py:126-152 indexes with the selected
+    node pairs only), in buffers sized by `patch_slots_per_pair` instead of the n4max^2 bound.  (1) Pairs of different sizes and
+    selection counts in one call: every per-pair output bitwise equal to the pair run alone.  (2) A model whose buffers are far too
+    small (4 slots per pair) warns, repeats the call with the exact count and returns the same bits.  (3) Both through the HIP-graph
+    path.  (4) An explicit patch_slots at the exact total and at the n^2 bound give the same bits as well."""
+    import warnings
+
+    from roitr_amd.synthetic import make_pair
+    from test_timed_shape_gpu import assert_bitwise
+    sizes = (1500, 2600, 1024, 2048, 3100)
+    pairs = [pair_to_device(make_pair(n, config=4, pair_index=40 + i, normals="field")) for i, n in enumerate(sizes)]
+    model = build_model("4DMatch", weights="selective")
+    with torch.no_grad():
+        alone = [model.forward_batch([p])[0] for p in pairs]
+        counts = [int(r["src_node_corr_indices"].shape[0]) for r in alone]
+        assert len(set(counts)) > 1 and min(counts) >= 1, counts            # ragged selection counts: the prefix sums matter
+        together = model.forward_batch(pairs)
+        for i, (a, b) in enumerate(zip(together, alone)):
+            assert_bitwise(a, b, f"pair {i} in a 5-pair call vs alone")
+        total = sum(counts)
+        h = model.launch_batch(pairs, patch_slots=total)                    # exactly full: no slot to spare, no repeat
+        for i, (a, b) in enumerate(zip(model.finish_batch(h), alone)):
+            assert_bitwise(a, b, f"pair {i}, patch_slots = the exact total")
+        h = model.launch_batch(pairs, patch_slots=10 ** 9)                  # clamped to the B * n4max^2 bound
+        for i, (a, b) in enumerate(zip(model.finish_batch(h), alone)):
+            assert_bitwise(a, b, f"pair {i}, patch_slots = the bound")
+        small = build_model("4DMatch", weights="selective")
+        small.patch_slots_per_pair = 4
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            got = small.forward_batch(pairs)
+        assert any("repeating the call" in str(x.message) for x in w), [str(x.message) for x in w]
+        for i, (a, b) in enumerate(zip(got, alone)):
+            assert_bitwise(a, b, f"pair {i} after the repeated call")
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            for _ in range(3):                                              # warm-up, capture, replay: each overfull, each repeated on the plain path
+                got = small.forward_batch(pairs[:2], graph=True)
+                for i, (a, b) in enumerate(zip(got, alone[:2])):
+                    assert_bitwise(a, b, f"pair {i} through the graph path with overfull buffers")
+        for _ in range(3):
+            got = model.forward_batch(pairs[:2], graph=True)
+            for i, (a, b) in enumerate(zip(got, alone[:2])):
+                assert_bitwise(a, b, f"pair {i} through the graph path")
