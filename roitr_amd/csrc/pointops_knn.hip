@@ -1443,29 +1443,37 @@ __global__ __launch_bounds__(64) void knn_lane_brute_kernel(int m, int nsample, 
 // One wave per block: LDS operations of a wave complete in order, so cross-lane hand-offs only need the counter wait.
 __device__ __forceinline__ void lds_sync_wave() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 // reheap (knnquery_cuda_kernel.cu:21-36) with the sinking value kept in registers: the entry at `rt` is always the new one, so a
-// level costs ONE LDS round trip (both children and their indices requested together) instead of three dependent ones;
-// the right child wins only when strictly larger, the walk stops at the first child strictly smaller than the value.
-__device__ __forceinline__ void sift_down(float* hd, int* hi, int k, float nd, int ni)
+// level costs ONE LDS round trip; the right child wins only when strictly larger, the walk stops at the first child strictly
+// smaller than the value.  Round 6: an entry is one 8-byte (distance, index) word and node j lives in slot j + 1, so the two
+// children of a node (2 rt + 1, 2 rt + 2 -> slots 2 rt + 2, 2 rt + 3) are ONE aligned 16-byte read, the parent's update one
+// 8-byte write nobody waits for, and the new root comes back in a register instead of being re-read: the chain per level is
+// ds_read_b128 -> 2 compares / 2 selects -> next address.  Returns the distance now at the root.
+constexpr int REPLAY_SLOTS = 104;   // nsample <= 100 nodes in slots 1 .. 100, the pair read may touch slot nsample + 1
+__device__ __forceinline__ float sift_down(uint2* hp, int k, float nd, int ni)
 {
     int rt = 0, child = 1;
+    float root = nd;
     while (child < k) {
-        const bool two = child + 1 < k;
-        const float c0 = hd[child], c1 = hd[two ? child + 1 : child];
-        const int i0 = hi[child], i1 = hi[two ? child + 1 : child];
-        const bool right = two && c1 > c0;
+        // both children, distances AND indices, in one round trip (left to itself hipcc fetches the indices in a second, dependent
+        // read behind the comparison); the wait is part of the statement: inline asm is invisible to the waitcnt insertion
+        uint4 cc;
+        asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(cc) : "v"((unsigned)(uintptr_t)(hp + child + 1)) : "memory");
+        const float c0 = __uint_as_float(cc.x), c1 = __uint_as_float(cc.z);
+        const bool right = (child + 1 < k) && c1 > c0;
         const float cd = right ? c1 : c0;
         if (nd > cd) break;
-        hd[rt] = cd; hi[rt] = right ? i1 : i0;
+        hp[rt + 1] = make_uint2(__float_as_uint(cd), right ? cc.w : cc.y);
+        root = rt == 0 ? cd : root;
         rt = child + (right ? 1 : 0); child = rt * 2 + 1;
     }
-    hd[rt] = nd; hi[rt] = ni;
+    hp[rt + 1] = make_uint2(__float_as_uint(nd), (unsigned)ni);
+    return root;
 }
 
 __global__ __launch_bounds__(64) void knn_replay_kernel(int nsample, const float* __restrict__ xyz, const float* __restrict__ new_xyz,
                                                         const int* __restrict__ offset, const int* __restrict__ new_offset, KnnOut o)
 {
-    __shared__ float hd[128];
-    __shared__ int hi[128];
+    __shared__ __attribute__((aligned(16))) uint2 hp[REPLAY_SLOTS];
     const int lane = threadIdx.x;
     const int count = *o.tie_count;
     for (int t = blockIdx.x; t < count; t += gridDim.x) {
@@ -1473,8 +1481,9 @@ __global__ __launch_bounds__(64) void knn_replay_kernel(int nsample, const float
         int start, end, seg;
         find_segment(q, offset, new_offset, start, end, seg, o.b);
         Query Q = {new_xyz[(size_t)q * 3], new_xyz[(size_t)q * 3 + 1], new_xyz[(size_t)q * 3 + 2]};
-        for (int p = lane; p < nsample; p += 64) { hd[p] = KNN_FILL; hi[p] = start; }
+        for (int p = lane; p < REPLAY_SLOTS; p += 64) hp[p] = make_uint2(__float_as_uint(KNN_FILL), (unsigned)start);
         __syncthreads();
+        float root = KNN_FILL;
         // the scan is one wave walking the whole cloud: NB batches of 64 distances are loaded together (the admission order
         // below is still strictly the index order), otherwise every step is a dependent HBM / L2 round trip
         constexpr int NB = 8;
@@ -1494,33 +1503,31 @@ __global__ __launch_bounds__(64) void knn_replay_kernel(int nsample, const float
                 const int base = base0 + 64 * u;
                 if (base >= end) break;   // wave-uniform
                 const float cd = cdv[u];
-                float root = hd[0];
                 unsigned long long mk = __ballot(cd < root);
                 while (mk) {
                     const int l = __ffsll((long long)mk) - 1;
                     mk &= mk - 1;
                     const float nd = rl_f(cd, l);
                     if (nd < root) {   // strict admission (l.97); the new point replaces the root, then reheap (l.21-36)
-                        if (lane == 0) sift_down(hd, hi, nsample, nd, base + l);
-                        lds_sync_wave();
-                        root = hd[0];
+                        float nr = 0.f;
+                        if (lane == 0) nr = sift_down(hp, nsample, nd, base + l);
+                        root = rl_f(nr, 0);
                     }
                 }
             }
         }
-        lds_sync_wave();
         if (lane == 0) {  // heap_sort, l.39-48: the root goes to slot i, the old slot-i entry sinks from the root over the first i
             for (int i = nsample - 1; i > 0; i--) {
-                const float td = hd[0], ld_ = hd[i];
-                const int ti = hi[0], li_ = hi[i];
-                hd[i] = td; hi[i] = ti;
-                sift_down(hd, hi, i, ld_, li_);
+                const uint2 top = hp[1], last = hp[i + 1];
+                hp[i + 1] = top;
+                (void)sift_down(hp, i, __uint_as_float(last.x), (int)last.y);
             }
         }
         lds_sync_wave();
         float d[2]; int i[2];
-        d[0] = lane < nsample ? hd[lane] : 0.f; i[0] = lane < nsample ? hi[lane] : 0;
-        d[1] = lane + 64 < nsample ? hd[lane + 64] : 0.f; i[1] = lane + 64 < nsample ? hi[lane + 64] : 0;
+        const uint2 e0 = hp[(lane < nsample ? lane : 0) + 1], e1 = hp[(lane + 64 < nsample ? lane + 64 : 0) + 1];
+        d[0] = lane < nsample ? __uint_as_float(e0.x) : 0.f; i[0] = lane < nsample ? (int)e0.y : 0;
+        d[1] = lane + 64 < nsample ? __uint_as_float(e1.x) : 0.f; i[1] = lane + 64 < nsample ? (int)e1.y : 0;
         write_rows<2>(o, q, nsample, d, i, lane, xyz, Q);
         __syncthreads();
     }
