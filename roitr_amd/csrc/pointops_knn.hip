@@ -1442,34 +1442,53 @@ __global__ __launch_bounds__(64) void knn_lane_brute_kernel(int m, int nsample, 
 // candidate loads in flight (kept) change nothing.  One query per block (up to 1024 blocks) keeps the kernel at one chain.
 // One wave per block: LDS operations of a wave complete in order, so cross-lane hand-offs only need the counter wait.
 __device__ __forceinline__ void lds_sync_wave() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
-// reheap (knnquery_cuda_kernel.cu:21-36) with the sinking value kept in registers: the entry at `rt` is always the new one, so a
-// level costs ONE LDS round trip; the right child wins only when strictly larger, the walk stops at the first child strictly
-// smaller than the value.  Round 6: an entry is one 8-byte (distance, index) word and node j lives in slot j + 1, so the two
-// children of a node (2 rt + 1, 2 rt + 2 -> slots 2 rt + 2, 2 rt + 3) are ONE aligned 16-byte read, the parent's update one
-// 8-byte write nobody waits for, and the new root comes back in a register instead of being re-read: the chain per level is
-// ds_read_b128 -> 2 compares / 2 selects -> next address.  Returns the distance now at the root.
-constexpr int REPLAY_SLOTS = 104;   // nsample <= 100 nodes in slots 1 .. 100, the pair read may touch slot nsample + 1
-__device__ __forceinline__ float sift_down(uint2* hp, int k, float nd, int ni)
+// reheap (knnquery_cuda_kernel.cu:21-36) with the sinking value kept in registers: the entry at `rt` is always the new one; the
+// right child wins only when strictly larger, the walk stops at the first child strictly smaller than the value.
+// Round 6 (temporary s_memtime counters inside the kernel: a replayed query of the config-5 call spent 1.35 M cycles --
+// 461 admissions at 1 840 cycles each = 300 per heap level, 365 k in the candidate loads): the per-level cost was not the LDS
+// round trip but the VALU -> SALU hand-offs of a loop whose every decision was a scalar branch or an exec-mask update.  Now
+//  * an entry is one 8-byte (distance, index) word, node j lives in slot j + 1: the two children of a node are ONE aligned 16-byte
+//    read, the parent's update one 8-byte write nobody waits for, the new root comes back in a register;
+//  * the walk is branch-free with a uniform trip count (the heap's depth): a missing child reads as distance -1 (distances are
+//    >= 0: it neither wins nor is moved), a walk that has stopped keeps comparing +inf (stops again), and its parent writes go
+//    to the unused slot 0 -- every decision is a v_cmp feeding v_cndmask, no exec-mask update and no branch inside the walk.
+// Returns the distance now at the root.
+constexpr int REPLAY_SLOTS = 208;   // nsample <= 100 nodes in slots 1 .. 100; a stopped walk may read the "children" of a leaf
+__device__ __forceinline__ int heap_levels(int k) { return 31 - __builtin_clz(k); }   // depth of node k - 1 = floor(log2 k), k >= 1
+__device__ __forceinline__ float sift_down(uint2* hp, int k, int levels, float nd, int ni)
 {
-    int rt = 0, child = 1;
-    float root = nd;
-    while (child < k) {
+    int rt = 0;
+    float root = nd, ndc = nd;
+    for (int lv = 0; lv < levels; ++lv) {   // wave-uniform trip count
+        const int child = 2 * rt + 1;
         // both children, distances AND indices, in one round trip (left to itself hipcc fetches the indices in a second, dependent
         // read behind the comparison); the wait is part of the statement: inline asm is invisible to the waitcnt insertion
         uint4 cc;
         asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(cc) : "v"((unsigned)(uintptr_t)(hp + child + 1)) : "memory");
-        const float c0 = __uint_as_float(cc.x), c1 = __uint_as_float(cc.z);
-        const bool right = (child + 1 < k) && c1 > c0;
+        const float c0 = child < k ? __uint_as_float(cc.x) : -1.f, c1 = child + 1 < k ? __uint_as_float(cc.z) : -1.f;
+        const bool right = c1 > c0;
         const float cd = right ? c1 : c0;
-        if (nd > cd) break;
-        hp[rt + 1] = make_uint2(__float_as_uint(cd), right ? cc.w : cc.y);
-        root = rt == 0 ? cd : root;
-        rt = child + (right ? 1 : 0); child = rt * 2 + 1;
+        const unsigned ci = right ? cc.w : cc.y;
+        const bool move = !(ndc > cd);          // reheap swaps on equality (l.29)
+        hp[move ? rt + 1 : 0] = make_uint2(__float_as_uint(cd), ci);
+        if (lv == 0) root = move ? cd : nd;
+        rt = move ? child + (right ? 1 : 0) : rt;
+        ndc = move ? ndc : INFINITY;
     }
     hp[rt + 1] = make_uint2(__float_as_uint(nd), (unsigned)ni);
     return root;
 }
 
+// Round 6, second step: the admissions of a query form a PIPELINE across four lanes.  A sift-down touches every depth of the heap
+// once, top to bottom; the next admission only needs (a) the new root -- known after the FIRST level of the one before -- to be
+// decided, and (b) at each depth the values the one before left there.  So admission j + 1 may start two levels behind admission
+// j: lane a holds the walk of the a-th admission in flight (state: node, value, index), one `step` advances all of them by one
+// level with ONE 16-byte LDS read per lane, and a new walk enters every other step -- 2 levels of latency per admission instead
+// of 6 - 7.  Order of effects = the sequential reheap: walk j writes depth d (the child moving up, or its own value settling)
+// at its step d, walk j + 1 reads depth d at its step d - 1, two steps after walk j started = one step AFTER that write (LDS
+// operations of a wave complete in order).  Slots of missing nodes hold distance -1: a walk that runs off the heap stops there
+// (-1 neither wins a comparison nor is moved) and settles one step later, still in time.  Bit-exact by construction; the whole
+// tie suite (lattice, duplicate, plane clouds: every query tied) is the test.
 __global__ __launch_bounds__(64) void knn_replay_kernel(int nsample, const float* __restrict__ xyz, const float* __restrict__ new_xyz,
                                                         const int* __restrict__ offset, const int* __restrict__ new_offset, KnnOut o)
 {
@@ -1481,23 +1500,52 @@ __global__ __launch_bounds__(64) void knn_replay_kernel(int nsample, const float
         int start, end, seg;
         find_segment(q, offset, new_offset, start, end, seg, o.b);
         Query Q = {new_xyz[(size_t)q * 3], new_xyz[(size_t)q * 3 + 1], new_xyz[(size_t)q * 3 + 2]};
-        for (int p = lane; p < REPLAY_SLOTS; p += 64) hp[p] = make_uint2(__float_as_uint(KNN_FILL), (unsigned)start);
+        for (int p = lane; p < REPLAY_SLOTS; p += 64)
+            hp[p] = (p >= 1 && p <= nsample) ? make_uint2(__float_as_uint(KNN_FILL), (unsigned)start) : make_uint2(__float_as_uint(-1.f), 0u);
         __syncthreads();
         float root = KNN_FILL;
+        // walk state of this lane (lanes 0 .. 3 carry walks, the others idle along)
+        bool act = false; int rt = 0; float w_nd = 0.f, w_cmp = INFINITY; unsigned w_ni = 0u;
+        int slot = 0; bool last_started = false;
+        const unsigned hp_addr = (unsigned)(uintptr_t)hp;
+        // one level for every walk in flight; optionally a new walk (snd, sni) enters at the root in lane `slot`
+        auto step = [&](bool start_walk, float snd, int sni) {
+            if (start_walk && lane == slot) { act = true; rt = 0; w_nd = snd; w_cmp = snd; w_ni = (unsigned)sni; }
+            uint4 cc;
+            asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(cc) : "v"(hp_addr + (unsigned)(2 * rt + 2) * 8u) : "memory");
+            const float c0 = __uint_as_float(cc.x), c1 = __uint_as_float(cc.z);
+            const bool right = c1 > c0;                       // the right child wins only when strictly larger (l.27)
+            const float cd = right ? c1 : c0;
+            const unsigned ci = right ? cc.w : cc.y;
+            const bool move = !(w_cmp > cd);                  // reheap swaps on equality (l.29); an idle lane compares +inf: never
+            const uint2 wv = move ? make_uint2(__float_as_uint(cd), ci) : make_uint2(__float_as_uint(w_nd), w_ni);
+            hp[act ? rt + 1 : 0] = wv;                        // the child moves up, or the walk's own value settles here
+            if (start_walk) { root = rl_f(move ? cd : snd, slot); slot = (slot + 1) & 3; }   // the new root is final after a walk's first level
+            rt = move ? 2 * rt + 1 + (right ? 1 : 0) : rt;
+            act = act && move;
+            w_cmp = move ? w_cmp : INFINITY;
+            last_started = start_walk;
+        };
         // the scan is one wave walking the whole cloud: NB batches of 64 distances are loaded together (the admission order
         // below is still strictly the index order), otherwise every step is a dependent HBM / L2 round trip
         constexpr int NB = 8;
+        // coordinates of the NEXT 512 candidates are requested before the admission chain of the current ones starts (24 loads in
+        // flight under ~10 k cycles of heap work): the probe showed 8 dependent round trips per 512 candidates, 27 % of the kernel
+        float px[NB], py[NB], pz[NB];
+        auto request = [&](int b0) {
+#pragma unroll
+            for (int u = 0; u < NB; ++u) {
+                const int k = min(b0 + 64 * u + lane, end - 1);
+                const float* p = xyz + (size_t)k * 3;
+                px[u] = p[0]; py[u] = p[1]; pz[u] = p[2];
+            }
+        };
+        request(start);
         for (int base0 = start; base0 < end; base0 += 64 * NB) {
             float cdv[NB];
 #pragma unroll
-            for (int u = 0; u < NB; ++u) {
-                const int k = base0 + 64 * u + lane;
-                cdv[u] = INFINITY;
-                if (k < end) {
-                    const float* p = xyz + (size_t)k * 3;
-                    cdv[u] = sqdist3(Q.x, Q.y, Q.z, p[0], p[1], p[2]);
-                }
-            }
+            for (int u = 0; u < NB; ++u) cdv[u] = base0 + 64 * u + lane < end ? sqdist3(Q.x, Q.y, Q.z, px[u], py[u], pz[u]) : INFINITY;
+            if (base0 + 64 * NB < end) request(base0 + 64 * NB);   // wave-uniform
 #pragma unroll
             for (int u = 0; u < NB; ++u) {
                 const int base = base0 + 64 * u;
@@ -1509,18 +1557,19 @@ __global__ __launch_bounds__(64) void knn_replay_kernel(int nsample, const float
                     mk &= mk - 1;
                     const float nd = rl_f(cd, l);
                     if (nd < root) {   // strict admission (l.97); the new point replaces the root, then reheap (l.21-36)
-                        float nr = 0.f;
-                        if (lane == 0) nr = sift_down(hp, nsample, nd, base + l);
-                        root = rl_f(nr, 0);
+                        if (last_started) step(false, 0.f, 0);   // a walk enters two levels behind the one before
+                        step(true, nd, base + l);
                     }
                 }
             }
         }
+        for (int d = 0; d < 8; ++d) step(false, 0.f, 0);   // drain: a walk settles after at most depth + 1 <= 7 levels
+        lds_sync_wave();
         if (lane == 0) {  // heap_sort, l.39-48: the root goes to slot i, the old slot-i entry sinks from the root over the first i
             for (int i = nsample - 1; i > 0; i--) {
                 const uint2 top = hp[1], last = hp[i + 1];
                 hp[i + 1] = top;
-                (void)sift_down(hp, i, __uint_as_float(last.x), (int)last.y);
+                (void)sift_down(hp, i, heap_levels(i), __uint_as_float(last.x), (int)last.y);
             }
         }
         lds_sync_wave();
