@@ -245,11 +245,14 @@ def forward_bench(args, rank, world, distributed):
         barrier()
         gc.collect()
         gc.disable()   # a generation-2 collection of the result dicts costs ~40 ms every dozen steps
+        if not stub:
+            model.host_ms.update(launch=0.0, unpack=0.0, calls=0)
         t0 = time.perf_counter()
         n_corr_total, records = benchloop.run_steps(model, batch, B, args.warmup, args.steps, rank, world, True, spp, trace)
         barrier()
         dt = time.perf_counter() - t0
         gc.enable()
+        host_ms = None if stub else {k: round(v / max(args.steps, 1), 3) for k, v in model.host_ms.items() if k != "calls"}
 
         # ---- the same steps once more with the HIP-event instrumentation on (not part of `value`)
         prof, prof_steps, ot_counts = {}, 0, [0, 0, 0]
@@ -329,6 +332,10 @@ def forward_bench(args, rank, world, distributed):
         if gt else "fp32 MFMA GEMM form (geo_embed_kernel)")
     if gt:
         out["config"]["geometric_embedding_table"] = {"interval": gt["interval"], "lds_bytes": gt["lds_bytes"], "rel_fit_d": gt["rel_d"], "rel_fit_a": gt["rel_a"]}
+    if host_ms:
+        # host-side Python per step on THIS rank inside the timed region: launch = packing + allocation + the engine call (its ~350 kernel
+        # launches), unpack = finish_batch after the device answered; both run while the device works on the other batch in flight
+        out["host_ms_per_step"] = host_ms
     if rank == 0:
         if records is not None:
             out["result_gather"] = benchloop.gather_summary(records, B, args.steps, spp)

@@ -11,6 +11,7 @@ engine (csrc/engine.cpp).  There is no PyTorch compute path and no CPU fallback.
 """
 import ctypes
 import math
+import time
 
 import numpy as np
 import torch
@@ -213,6 +214,9 @@ class RIGA_v2(nn.Module):
                 t = torch.tensor(1.0)
             _attach(self, key, t, kind)
         self._engine = None
+        # host-side milliseconds spent inside launch_batch (packing, allocation, the engine call's ~350 launches) and inside finish_batch
+        # AFTER the device has answered (per-pair unpacking); bench.py reports them per step (host share at 8 ranks)
+        self.host_ms = {"launch": 0.0, "unpack": 0.0, "calls": 0}
         # launch_batch default: True = the pairs handed to it are complete device tensors with nothing pending on the current
         # stream (a resident pool, a loader that synchronised its copies) -- see launch_batch(inputs_resident=...)
         self.inputs_resident = False
@@ -414,6 +418,7 @@ class RIGA_v2(nn.Module):
         self._ensure_engine()
         if graph:
             return self._launch_graph(pairs, want_gt)
+        t_host = time.perf_counter()
         dev = pairs[0]["src_pcd"].device
         B = len(pairs)
         f32 = torch.float32
@@ -473,6 +478,8 @@ class RIGA_v2(nn.Module):
         done = torch.cuda.Event()
         done.record()
         keep = (geom, pout, nrm, feats, rot, trans, arr, meta_dev, ready)   # inputs stay alive until the forward has run
+        self.host_ms["launch"] += 1e3 * (time.perf_counter() - t_host)
+        self.host_ms["calls"] += 1
         return dict(pairs=pairs, out=out, B=B, P=P, slots=slots, n_all=n_all, n4=n4, have_gt=have_gt, meta_host=meta_host, done=done, keep=keep,
                     relaunch=dict(want_gt=want_gt, inputs_resident=inputs_resident))
 
@@ -558,6 +565,7 @@ class RIGA_v2(nn.Module):
         """Wait for the forward of launch_batch() and unpack it per pair (the one host synchronisation of the path)."""
         pairs, out, B, P, n_all, n4, have_gt = h["pairs"], h["out"], h["B"], h["P"], h["n_all"], h["n4"], h["have_gt"]
         h["done"].synchronize()
+        t_host = time.perf_counter()
         meta = h["meta_host"].tolist()
         starts, n_corr, gt_cnt = meta[:B + 1], meta[B + 1:2 * B + 1], meta[2 * B + 1:]
         if self.factor == 1:
@@ -618,6 +626,7 @@ class RIGA_v2(nn.Module):
             r["_src_node_masks"] = lambda sc=sc: out["node_masks"][o_nod[sc]:o_nod[sc + 1]].bool()
             r["_tgt_node_masks"] = lambda tc=tc: out["node_masks"][o_nod[tc]:o_nod[tc + 1]].bool()
             results.append(r)
+        self.host_ms["unpack"] += 1e3 * (time.perf_counter() - t_host)
         return results
 
     def forward(self, src_pcd, tgt_pcd, src_feats, tgt_feats, src_normals, tgt_normals, rot, trans, src_raw_pcd):
