@@ -61,14 +61,24 @@ typedef struct RoitrGemm {
     /* optional (ABI 3): device int; batches (tiles of batch index) >= *batch_live leave at once -- a batch list whose live length is
      * only known on the device (the compacted patch list of the adaptive matching, RIGA_v2.py:126-152) without a host round trip. */
     const int* batch_live;
+    /* ROITR_BF16_X3 (ABI 3; alone in `bf16`): fp32 arithmetic on the bf16 matrix cores by a three-way operand split (csrc/gemm_x3.hip).
+     * `W` points to THREE bf16 images of the fp32 weight (roitr_split_bf16x3): piece p of element (n, k) at W[p * w_piece + n * ldw + k]
+     * (uint16, ldw / w_piece in elements); A (A2, A_cat) stay fp32 and are split while they are staged; C fp32.  Six bf16 products per
+     * multiply (error ~ one fp32 rounding per product; rows bitwise independent of the row count).  Needs K % 32 == 0, batch == 1. */
+    long w_piece;
 } RoitrGemm;
 #define ROITR_BF16_W 1
 #define ROITR_BF16_A 2
 #define ROITR_BF16_C 4
+#define ROITR_BF16_X3 8
 int roitr_gemm(const RoitrGemm* g, roitr_stream_t stream);
 int roitr_gemm_bf16_supported(const RoitrGemm* g);
 /* fp32 -> bf16 (round to nearest even), n elements; dst 4-byte aligned */
 int roitr_f32_to_bf16(long n, const float* src, unsigned short* dst, roitr_stream_t stream);
+/* shapes / layouts the split kernel takes (RoitrGemm::bf16 == ROITR_BF16_X3) */
+int roitr_gemm_x3_supported(const RoitrGemm* g);
+/* src (n fp32) -> its three bf16 pieces at dst, dst + piece, dst + 2 * piece (piece >= n, even): src[i] == h[i] + m[i] + l[i] exactly */
+int roitr_split_bf16x3(long n, const float* src, unsigned short* dst, long piece, roitr_stream_t stream);
 
 /* ------------------------------------------------------------------ row-wise layers */
 /* out = act( LayerNorm(x + res[res_idx]) * gamma + beta (+ post_add) ); res, res_idx, post_add optional.

@@ -579,11 +579,13 @@ void shape_log(const RoitrGemm* g, bool fast, float ms)
 }  // namespace
 
 int roitr_gemm_bf16_launch(const RoitrGemm* g, hipStream_t stream);   // gemm_bf16.hip
+int roitr_gemm_x3_launch(const RoitrGemm* g, hipStream_t stream);     // gemm_x3.hip
 
 extern "C" int roitr_gemm(const RoitrGemm* g, hipStream_t stream)
 {
     if (g->M <= 0 || g->N <= 0 || g->batch <= 0) return ROITR_OK;
     if (g->K <= 0 || !g->A || !g->W || !g->C) { roitr_set_error("roitr_gemm: K <= 0 or a null operand", __FILE__, __LINE__); return ROITR_ERR_ARG; }
+    if (g->bf16 & ROITR_BF16_X3) return roitr_gemm_x3_launch(g, stream);
     if (g->bf16) return roitr_gemm_bf16_launch(g, stream);
     auto al16 = [](const void* p, long stride_floats) { return ((uintptr_t)p & 15) == 0 && (stride_floats % 4) == 0; };
     const bool fast = g->K % BK == 0 && g->K <= ZERO_ROW_LEN && g->lda % 4 == 0 && g->ldw % 4 == 0 && al16(g->A, g->sA) && al16(g->W, g->sW) &&

@@ -156,10 +156,18 @@ class _Gemm(ctypes.Structure):
                 ("ln_gamma", _P), ("ln_beta", _P), ("ln_res", _P), ("ln_res_idx", _P), ("ln_post", _P),
                 ("ln_relu", ctypes.c_int), ("ln_eps", ctypes.c_float), ("bf16", ctypes.c_int),
                 ("A_cat", _P), ("lda_cat", ctypes.c_int), ("k_cat", ctypes.c_int),
-                ("ip_feat", _P), ("ip_idx", _P), ("ip_dist2", _P), ("a_cat_idx", _P), ("batch_live", _P)]
+                ("ip_feat", _P), ("ip_idx", _P), ("ip_dist2", _P), ("a_cat_idx", _P), ("batch_live", _P), ("w_piece", ctypes.c_long)]
 
 
-BF16_W, BF16_A, BF16_C = 1, 2, 4   # RoitrGemm::bf16 flags (include/roitr_engine.h)
+BF16_W, BF16_A, BF16_C, BF16_X3 = 1, 2, 4, 8   # RoitrGemm::bf16 flags (include/roitr_engine.h)
+
+
+def split_bf16x3(weight):
+    """roitr_split_bf16x3: (N, K) fp32 -> (3, N, K) bf16 with weight == pieces.float().sum(0) exactly (csrc/gemm_x3.hip)."""
+    w = weight.contiguous().float()
+    out = torch.empty((3,) + tuple(w.shape), dtype=torch.bfloat16, device=w.device)
+    L.check(L.lib().roitr_split_bf16x3(ctypes.c_long(w.numel()), L.ptr(w), L.ptr(out), ctypes.c_long(w.numel()), L.stream_ptr()), "split_bf16x3")
+    return out
 
 
 def _bf16_flags(bf16, x, weight, out_bf16):
@@ -193,7 +201,14 @@ def _k_cat(g, x, x_cat, keep, x_cat_idx=None, addend=None):
         g.a_cat_idx = L.ptr(ix)
 
 
-def linear(x, weight, bias=None, relu=False, alpha=1.0, bf16=False, out_bf16=False, x_cat=None, x_cat_idx=None, addend=None):
+def _x3(g, weight, keep):
+    """RoitrGemm::bf16 = ROITR_BF16_X3: the weight as its three bf16 pieces (csrc/gemm_x3.hip)."""
+    w3 = split_bf16x3(weight)
+    keep.append(w3)
+    g.W, g.bf16, g.w_piece = L.ptr(w3), BF16_X3, weight.numel()
+
+
+def linear(x, weight, bias=None, relu=False, alpha=1.0, bf16=False, out_bf16=False, x_cat=None, x_cat_idx=None, addend=None, x3=False):
     """act(alpha * x @ weight.T + bias): the kernel behind every nn.Linear of the path.  Default: the fp32 MFMA GEMM.
     bf16=True: the bf16-operand kernel (csrc/gemm_bf16.hip; weights stored bf16, fp32 accumulate); x may be a bfloat16
     tensor (stored-bf16 activation), out_bf16 stores the result in bf16.  x_cat: a second operand block, the product is
@@ -209,12 +224,14 @@ def linear(x, weight, bias=None, relu=False, alpha=1.0, bf16=False, out_bf16=Fal
     keep = []
     _k_cat(g, x, x_cat, keep, x_cat_idx, addend)
     g.ldw = weight.shape[1]
+    if x3:   # fp32 in, fp32 out, products on the bf16 matrix cores by the three-way split (csrc/gemm_x3.hip)
+        _x3(g, weight, keep)
     L.check(L.lib().roitr_gemm(ctypes.byref(g), L.stream_ptr()), "gemm")
     return out
 
 
 def linear_layernorm(x, weight, bias, gamma, beta, res=None, res_idx=None, post=None, relu=False, eps=1e-5, bf16=False, out_bf16=False,
-                     x_cat=None, interp=None, x_cat_idx=None, addend=None):
+                     x_cat=None, interp=None, x_cat_idx=None, addend=None, x3=False):
     """[relu](LayerNorm(x @ weight.T + bias + res[res_idx]) * gamma + beta + post) in ONE launch (64 / 128 / 256 output
     channels): the nn.Linear -> (+ residual) -> nn.LayerNorm call sites of attention.py:319, model/model.py:89-97,138-140.
     bf16 / out_bf16 as in linear().  interp = (feat (R, N), idx (M, 3) int32, dist2 (M, 3)): TransitionUp's three-nearest-neighbour
@@ -234,6 +251,8 @@ def linear_layernorm(x, weight, bias, gamma, beta, res=None, res_idx=None, post=
     if interp is not None:
         keep += [c(interp[0]), c(interp[1], torch.int32), c(interp[2])]
         g.ip_feat, g.ip_idx, g.ip_dist2 = L.ptr(keep[-3]), L.ptr(keep[-2]), L.ptr(keep[-1])
+    if x3:
+        _x3(g, weight, keep)
     L.check(L.lib().roitr_gemm(ctypes.byref(g), L.stream_ptr()), "gemm+layernorm")
     return out
 

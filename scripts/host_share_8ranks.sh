@@ -3,10 +3,10 @@
 # eight processes share cuda:0 (the device time per step is then ~8x a real rank's and says nothing) -- what is read is the HOST side:
 # `host_ms_per_step` of every process (launch = packing + allocation + the engine call's ~350 launches, unpack = finish_batch after the
 # device answered), each process pinned to its own 8 cores like one rank of an 8-GPU node, against the same process running alone.
-#   bash scripts/host_share_8ranks.sh [outdir]
+#   PAIRS=128 bash scripts/host_share_8ranks.sh [outdir]     (eight 512-pair processes do not fit one GPU's 288 GB: 128 pairs per call; the host cost is per pair)
 cd ${GRAFT_REPO_ROOT:-.}
 out=${1:-gpurun_out/host8}; rm -rf $out; mkdir -p $out
-ARGS="--steps 6 --warmup 3 --no-cpu-baseline --no-single-pair --no-profile-pass --no-rccl-selftest"
+ARGS="--pairs-per-step ${PAIRS:-128} --steps 6 --warmup 3 --no-cpu-baseline --no-single-pair --no-profile-pass --no-rccl-selftest"
 nc=$(nproc)
 taskset -c 0-7 timeout 300 python bench.py $ARGS > $out/alone.json 2> $out/alone.err
 for r in 0 1 2 3 4 5 6 7; do

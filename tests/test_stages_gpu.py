@@ -697,3 +697,83 @@ def test_transition_up_interpolation_in_the_layernorm_epilogue(M, K, N, R):
         got = ops.linear_layernorm(x, w, b, gam, bet, relu=True, interp=(feat, idx, d2))
         assert torch.allclose(got.double(), ref, atol=3e-5, rtol=3e-5), float((got.double() - ref).abs().max())
         assert (got - two).abs().max().item() <= 2e-6 * max(1.0, two.abs().max().item())   # the same formula in both epilogues
+
+
+# ---------------------------------------------------------------- fp32 by a three-way bf16 split (csrc/gemm_x3.hip, round 6)
+def test_split_bf16x3_is_exact():
+    """Every fp32 value is the exact sum of its three bf16 pieces (roitr_split_bf16x3)."""
+    from roitr_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(3)
+    w = (torch.randn((257, 96), generator=g) * torch.exp(torch.randn((257, 96), generator=g) * 4)).cuda()
+    p = ops.split_bf16x3(w)
+    assert p.dtype == torch.bfloat16 and tuple(p.shape) == (3, 257, 96)
+    back = (p[0].double() + p[1].double() + p[2].double()).float()
+    assert torch.equal(back, w)
+
+
+@pytest.mark.parametrize("M,N,K,gather,addend,cat,relu", [(333, 768, 256, True, False, False, False), (64 * 5 + 7, 256, 512, False, True, True, True),
+                                                            (40000, 512, 256, False, False, False, True), (70001, 256, 384, True, True, True, False),
+                                                            (130, 192, 256, False, False, False, False)])
+def test_gemm_x3_against_float64(M, N, K, gather, addend, cat, relu):
+    """The split kernel through the C ABI (RoitrGemm::bf16 = ROITR_BF16_X3) against a float64 product: ragged last row tile, row gather
+    with out-of-range rows (zero rows), the addend on A, the K-concatenated operand, bias / alpha / ReLU.  Same bound as the fp32
+    kernel's test -- and the measured error is not larger than the fp32 kernel's on the same operands."""
+    from roitr_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(M + N + K)
+    R = M + 50
+    Ka = K // 2 if cat else K
+    a = torch.randn((R, Ka), generator=g).cuda()
+    ac = torch.randn((R, K - Ka), generator=g).cuda() if cat else None
+    a2 = torch.randn((R, Ka), generator=g).cuda() if addend else None
+    w = (torch.randn((N, K), generator=g) / K ** 0.5).cuda()
+    b = torch.randn((N,), generator=g).cuda()
+    idx = torch.randint(0, R + 20, (M,), generator=g).to(torch.int32).cuda() if gather else None   # >= R: zero rows
+
+    def run(x3):
+        import ctypes
+        from roitr_amd import _lib as L
+        out = torch.empty((M, N), device="cuda")
+        gm = ops._Gemm(M, N, K, L.ptr(a), L.ptr(a2), Ka, L.ptr(idx), R if gather else 0, L.ptr(w), K, L.ptr(None), 0, L.ptr(b), 0.75, int(relu),
+                       L.ptr(out), N, 1, 0, 0, 0, 0, 0, 0, L.ptr(None), 0, 0)
+        if cat:
+            gm.A_cat, gm.lda_cat, gm.k_cat = L.ptr(ac), K - Ka, Ka
+        keep = []
+        if x3:
+            ops._x3(gm, w, keep)
+        L.check(L.lib().roitr_gemm(ctypes.byref(gm), L.stream_ptr()), "gemm")
+        torch.cuda.synchronize()
+        return out
+    got, f32 = run(True), run(False)
+    src = idx.long() if gather else torch.arange(M, device="cuda")
+    ok = src < R
+    rows = (a.double() + (a2.double() if addend else 0.0))[src.clamp_max(R - 1)] * ok[:, None]
+    if cat:
+        rows = torch.cat([rows, ac.double()[src.clamp_max(R - 1)] * ok[:, None]], 1)
+    ref = 0.75 * (rows @ w.double().T) + b.double()
+    mass = 0.75 * (rows.abs() @ w.double().abs().T) + b.double().abs()
+    if relu:
+        ref = ref.clamp_min(0)
+    err = ((got.double() - ref).abs() / mass.clamp_min(1e-30)).max().item()
+    err32 = ((f32.double() - ref).abs() / mass.clamp_min(1e-30)).max().item()
+    print(f"[x3 gemm] M {M} N {N} K {K}: error / |a|.|w| mass  x3 {err:.2e}  fp32 MFMA {err32:.2e}")
+    assert err < 2e-6, err
+    assert err <= 1.5 * err32 + 1e-8, (err, err32)
+
+
+def test_gemm_x3_rows_do_not_depend_on_the_row_count_or_the_tile():
+    """Rows through a 3-tile launch (64 x 64 tiles) and through a large launch (64 x 256 tiles), plain and with the LayerNorm epilogue:
+    bit for bit the same."""
+    from roitr_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(6)
+    for N, K in ((256, 256), (512, 256), (256, 512), (768, 256), (192, 256)):
+        x = torch.randn((140000, K), generator=g).cuda()
+        w = (torch.randn((N, K), generator=g) / K ** 0.5).cuda()
+        b = torch.randn((N,), generator=g).cuda()
+        big = ops.linear(x, w, b, relu=True, x3=True)
+        small = ops.linear(x[:156].contiguous(), w, b, relu=True, x3=True)
+        assert torch.equal(big[:156], small), (N, K)
+        if N == 256:
+            gam, bet, res = torch.randn((N,), generator=g).cuda(), torch.randn((N,), generator=g).cuda(), torch.randn((140000, N), generator=g).cuda()
+            ln_big = ops.linear_layernorm(x, w, b, gam, bet, res=res, relu=True, x3=True)
+            ln_small = ops.linear_layernorm(x[:156].contiguous(), w, b, gam, bet, res=res[:156].contiguous(), relu=True, x3=True)
+            assert torch.equal(ln_big[:156], ln_small)
