@@ -14,7 +14,13 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "lib", "obj")
 LIB = os.path.join(HERE, "lib", "libroitr_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function",
+# -fno-slp-vectorize (round 6): hipcc's SLP vectoriser packs neighbouring scalar fp32 operations into v_pk_{mul,add,fma}_f32.  The
+# three angle polynomials of the point-pair feature (common.h roitr_ppf4), packed two at a time with their constants in SGPR pairs,
+# returned WRONG values for the low half in whole 16-lane groups, a few hundred entries in 16 million, differently from run to run
+# (found by the bitwise batch-vs-single tests of tests/test_timed_shape_gpu.py; reproduced on the round-5 build; gone with scalar
+# code: scripts history of round 6).  Packed fp32 buys nothing next to MFMAs anyway (MI355X_MICROARCH.md), and
+# the kernels that want it (pointops_fps.hip) write it by hand.
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-fno-slp-vectorize", "-Wall", "-Wno-unused-function",
          "-I", CSRC, "-I", os.path.join(os.path.dirname(HERE), "include")]
 
 

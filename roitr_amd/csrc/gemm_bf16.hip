@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(RoitrGemm g, int nx, int
     constexpr int TBN = BN * TN;
     constexpr int RP = TN == 4 ? 32 : 64;   // rows parked per LayerNorm pass
     constexpr int STAGE_BYTES = (BM + TBN) * PITCH * 2;
-    constexpr int TILE_BYTES = LN ? RP * (TBN + 1) * 4 : BM * (BN + 4) * 4;
+    constexpr int TILE_BYTES = LN ? RP * (TBN + 1) * 4 : (TN == 1 ? BM * (BN + 4) * 4 : 4 * 32 * 36 * 4);
     __shared__ __attribute__((aligned(16))) unsigned char smem_raw[STAGE_BYTES > TILE_BYTES ? STAGE_BYTES : TILE_BYTES];
     unsigned short* As = reinterpret_cast<unsigned short*>(smem_raw);
     unsigned short* Bs = As + BM * PITCH;
@@ -252,11 +252,40 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(RoitrGemm g, int nx, int
         }
         return;
     }
+    // TN > 1 (round 6: plain launches take 64 x 128 / 64 x 256 tiles where N allows -- the A rows are staged once per tile, and the
+    // kernel is bound by its operand path): a wave's 32 x 32 blocks leave through its own 32 x 36 LDS scratch as 16-byte (fp32) /
+    // 8-byte (bf16) stores, 8 lanes per row
+    const bool wide = (g.ldc & 3) == 0 && (((uintptr_t)g.C) & 15) == 0 && ((g.sC & 3) == 0);
+    if (TN > 1) __syncthreads();   // the operand images are dead
+    float* sc = reinterpret_cast<float*>(smem_raw) + wave * 32 * 36;
 #pragma unroll
     for (int v = 0; v < TN; ++v) {
-        const int col = n0 + (wn * TN + v) * 32 + (lane & 31);
-        if (col < g.N) {
-            const float bv = bias ? bias[col] : 0.f;
+        const int cb = n0 + (wn * TN + v) * 32;   // first column of this block
+        if (cb >= g.N) continue;                  // wave-uniform
+        const int col = cb + (lane & 31);
+        const float bv = (bias && col < g.N) ? bias[col] : 0.f;
+        if (TN > 1 && wide && cb + 32 <= g.N) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int rl = (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+                float x = acc[v][i] * g.alpha + bv;
+                if (g.relu) x = fmaxf(x, 0.f);
+                sc[rl * 36 + (lane & 31)] = x;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const int c4 = (lane & 7) * 4;
+#pragma unroll
+            for (int pass = 0; pass < 4; ++pass) {
+                const int rl = pass * 8 + (lane >> 3);
+                const int row = m0 + wm * 32 + rl;
+                if (row < g.M) {
+                    const float4 x = *reinterpret_cast<const float4*>(sc + rl * 36 + c4);
+                    if (c_bf16) *reinterpret_cast<uint2*>(Ch + (size_t)row * g.ldc + cb + c4) = make_uint2(pack_bf16(x.x, x.y), pack_bf16(x.z, x.w));
+                    else *reinterpret_cast<float4*>(C + (size_t)row * g.ldc + cb + c4) = x;
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the scratch is reused by the next column block
+        } else if (col < g.N) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int row = m0 + wm * 32 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
@@ -314,8 +343,16 @@ int roitr_gemm_bf16_launch(const RoitrGemm* g, hipStream_t stream)
         roitr_set_error("roitr_gemm: shape / layout not supported by the bf16 kernel (K % 64, 16-byte rows, bf16 weights)", __FILE__, __LINE__);
         return ROITR_ERR_UNSUPPORTED;
     }
-    const int tn = g->ln_gamma ? g->N / BN : 1;
-    const int nx = div_up(g->N, BN * tn), ny = div_up(g->M, BM);
+    // tile width: whole rows for the LayerNorm epilogue; plain launches 256 / 128 columns where N allows and the grid still fills the
+    // chip (round 6: the kernel is bound by its operand path -- an A row is staged once per tile whatever its width; the result of an
+    // element does not depend on the tile: same k order, same instruction)
+    int tn = g->ln_gamma ? g->N / BN : 1;
+    const int ny = div_up(g->M, BM);
+    if (!g->ln_gamma && !g->seg_off && !g->w_idx) {
+        tn = g->N % 256 == 0 ? 4 : (g->N % 128 == 0 ? 2 : 1);
+        while (tn > 1 && (long)ny * div_up(g->N, BN * tn) * g->batch < 2048) tn >>= 1;
+    }
+    const int nx = div_up(g->N, BN * tn);
     const long Tl = (long)nx * ny * g->batch;
     if (Tl > 0x7ffffff0L) return ROITR_ERR_UNSUPPORTED;
     const int T = (int)Tl;
@@ -335,8 +372,15 @@ int roitr_gemm_bf16_launch(const RoitrGemm* g, hipStream_t stream)
             else if (tn == 2) gemm_bf16_kernel<true, 2, true><<<grid, 256, 0, stream>>>(*g, nx, ny, T);
             else gemm_bf16_kernel<true, 4, true><<<grid, 256, 0, stream>>>(*g, nx, ny, T);
         }
-    } else if (a_h) gemm_bf16_kernel<false, 1, false><<<grid, 256, 0, stream>>>(*g, nx, ny, T);
-    else gemm_bf16_kernel<true, 1, false><<<grid, 256, 0, stream>>>(*g, nx, ny, T);
+    } else if (a_h) {
+        if (tn == 1) gemm_bf16_kernel<false, 1, false><<<grid, 256, 0, stream>>>(*g, nx, ny, T);
+        else if (tn == 2) gemm_bf16_kernel<false, 2, false><<<grid, 256, 0, stream>>>(*g, nx, ny, T);
+        else gemm_bf16_kernel<false, 4, false><<<grid, 256, 0, stream>>>(*g, nx, ny, T);
+    } else {
+        if (tn == 1) gemm_bf16_kernel<true, 1, false><<<grid, 256, 0, stream>>>(*g, nx, ny, T);
+        else if (tn == 2) gemm_bf16_kernel<true, 2, false><<<grid, 256, 0, stream>>>(*g, nx, ny, T);
+        else gemm_bf16_kernel<true, 4, false><<<grid, 256, 0, stream>>>(*g, nx, ny, T);
+    }
     roitr_prof_end(prof_cls, stream);
     ROITR_LAUNCH_CHECK();
     return ROITR_OK;

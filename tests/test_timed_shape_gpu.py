@@ -116,3 +116,33 @@ def test_config4_call_of_64_pairs_bf16_equals_single_forwards_and_stays_in_the_s
         got = set(zip(out["tgt_node_corr_indices"].tolist(), out["src_node_corr_indices"].tolist()))
         want = set(zip(ref["tgt_node_corr_indices"].tolist(), ref["src_node_corr_indices"].tolist()))
         assert len(got & want) >= 0.9 * len(want) and len(got) <= 1.15 * len(want), (len(got & want), len(want), len(got))
+
+
+@pytest.mark.parametrize("benchmark,n,config,B,dtype", [("3DMatch", 5000, 2, 256, "f32"), ("4DMatch", 8000, 4, 64, "bf16")])
+def test_timed_calls_are_deterministic_run_to_run(benchmark, n, config, B, dtype):
+    """The same call three times: EVERY pair's outputs and the kNN / PPF taps of levels 2 - 3 bit for bit the same.  (Round 6: this is
+    the test that found hipcc's packed-fp32 code for the three angle polynomials of the point-pair feature returning wrong values in
+    whole 16-lane groups -- a few hundred PPF entries in 16 million, differently from run to run, since round 5; the bf16 operand mode
+    turns such a 1e-2 wobble of one PPF into a visibly different descriptor.  Fixed by -fno-slp-vectorize, roitr_amd/build.py.)"""
+    model = build_model(benchmark, operand_dtype=dtype, weights="selective")
+    pool = [pair_to_device(make_pair(n, config=config, pair_index=i, normals="field")) for i in range(B)]
+    sizes = [n, n // 4, n // 16, n // 64]
+    runs = []
+    for _ in range(3):
+        taps = {}
+        for l in (1, 2):
+            T = 2 * B * sizes[l]
+            for nm, shape, dt in ((f"group.td.{l + 1}", (T, 16), torch.int32), (f"ppf.td.{l + 1}", (T, 16, 4), torch.float32),
+                                  (f"group.self.{l + 1}", (T, 16), torch.int32), (f"ppf.self.{l + 1}", (T, 16, 4), torch.float32)):
+                t = torch.zeros(shape, dtype=dt, device="cuda")
+                model.set_tap(nm, t)
+                taps[nm] = t
+        with torch.no_grad():
+            res = model.forward_batch(pool, want_gt=True)
+        torch.cuda.synchronize()
+        runs.append((res, {k: v.clone() for k, v in taps.items()}))
+    for res, taps in runs[1:]:
+        for k, v in taps.items():
+            assert torch.equal(v, runs[0][1][k]), (k, int((v != runs[0][1][k]).sum()))
+        for j in range(B):
+            assert_bitwise(res[j], runs[0][0][j], f"pair {j}, run to run")
