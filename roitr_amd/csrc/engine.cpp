@@ -134,6 +134,7 @@ struct Engine {
     hipEvent_t gend[2] = {nullptr, nullptr};   // recorded on the main stream where the forward that used the arena ends
     bool gend_rec[2] = {false, false};
     bool ahead_off = false;          // the alternating arenas could not be allocated: every call is ordered on the main stream
+    bool garena_short = false;       // an alternating arena ran out INSIDE a call (its size is a hand-kept sum): the wrapper repeats the call on the main-stream path
     static constexpr int RING = 4;   // descriptor staging slots: the host may run RING forwards ahead
     char* pinned[RING] = {nullptr, nullptr, nullptr, nullptr}; size_t pinned_cap[RING] = {0, 0, 0, 0};
     hipEvent_t pinned_ev[RING] = {nullptr, nullptr, nullptr, nullptr};
@@ -882,11 +883,29 @@ extern "C" int roitr_engine_finalize(void* h, hipStream_t st)
         // interval search there instead of at 2), comma-separated
         const char* ev = getenv("ROITR_GEO_TABLE");
         double opt_range = 0.0, opt_h = 0.0;
-        if (ev) {
-            const char* r = strstr(ev, "range="); if (r) opt_range = atof(r + 6);
-            const char* hh = strstr(ev, "h="); if (hh) opt_h = atof(hh + 2);
+        bool gemm_form = false;
+        if (ev) {   // strict: comma-separated tokens "0" | "range=<units>" | "h=<interval>"; anything else is reported, not guessed at
+            std::string all(ev);
+            size_t pos = 0;
+            while (pos <= all.size()) {
+                size_t end = all.find(',', pos);
+                if (end == std::string::npos) end = all.size();
+                const std::string tok = all.substr(pos, end - pos);
+                char* tail = nullptr;
+                if (tok == "0") gemm_form = true;
+                else if (tok.rfind("range=", 0) == 0 && (opt_range = strtod(tok.c_str() + 6, &tail), tail && *tail == 0 && opt_range > 0)) {}
+                else if (tok.rfind("h=", 0) == 0 && (opt_h = strtod(tok.c_str() + 2, &tail), tail && *tail == 0 && opt_h > 0)) {}
+                else if (!tok.empty()) {
+                    fprintf(stderr, "roitr: ROITR_GEO_TABLE: unknown option '%s' (known: 0, range=<units>, h=<interval>)\n", tok.c_str());
+                    roitr_set_error("ROITR_GEO_TABLE: unknown option", __FILE__, __LINE__);
+                    return ROITR_ERR_ARG;
+                }
+                pos = end + 1;
+            }
         }
-        if (!(ev && ev[0] == '0' && ev[1] == 0) && C4 % 64 == 0) {
+        for (const char* gone : {"ROITR_GEO_TABLE_RANGE", "ROITR_GEO_TABLE_H"})   // round-4 names, folded into ROITR_GEO_TABLE in round 5
+            if (getenv(gone)) fprintf(stderr, "roitr: %s is no longer read: use ROITR_GEO_TABLE=\"range=<units>,h=<interval>\"\n", gone);
+        if (!gemm_form && C4 % 64 == 0) {
             const double d_range = opt_range > 0 ? opt_range : 48.0, a_range = 180.0 / 15.0;
             std::vector<float> hd((size_t)C4 * C4), ha((size_t)C4 * C4), hbd(C4), hba(C4), hdiv(C4 / 2);
             ROITR_HIP(hipStreamSynchronize(st));
@@ -955,10 +974,26 @@ extern "C" int roitr_engine_forward(void* h, const RoitrForwardIO* io, hipStream
     Engine& E = *(Engine*)h;
     E.side_forked = false;
     E.cur_par = -1;
-    const int rc = forward_body(h, io, st);
+    E.garena_short = false;
+    int rc = forward_body(h, io, st);
     if (rc != ROITR_OK && E.side_forked && E.side && E.ev[8]) {
         if (hipEventRecord(E.ev[8], E.side) == hipSuccess) (void)hipStreamWaitEvent(st, E.ev[8], 0);
         else (void)hipStreamSynchronize(E.side);
+    }
+    if (rc != ROITR_OK && E.garena_short) {
+        // the size estimate of the alternating arena missed a buffer: no hard failure -- drain what the attempt queued and
+        // run the call once more with everything ordered on the main stream; the engine stays on that path (the tests assert that the
+        // estimate holds: test_graph_gpu.py, so this is a safety net, not a mode)
+        fprintf(stderr, "roitr: alternating geometry arena too small for this call (%s): falling back to main-stream order\n", roitr_last_error());
+        (void)hipStreamSynchronize(st);
+        if (E.side) (void)hipStreamSynchronize(E.side);
+        E.ahead_off = true;
+        E.side_forked = false; E.cur_par = -1; E.garena_short = false;
+        rc = forward_body(h, io, st);
+        if (rc != ROITR_OK && E.side_forked && E.side && E.ev[8]) {
+            if (hipEventRecord(E.ev[8], E.side) == hipSuccess) (void)hipStreamWaitEvent(st, E.ev[8], 0);
+            else (void)hipStreamSynchronize(E.side);
+        }
     }
     E.side_forked = false;
     if (E.cur_par >= 0 && E.gend[E.cur_par]) {   // the alternating arena is free again where this call ends on the main stream
@@ -1172,7 +1207,7 @@ static int forward_body(void* h, const RoitrForwardIO* io, hipStream_t st)
             p[l] = G.get<float>((size_t)V.T[l] * 3);
             nrm[l] = G.get<float>((size_t)V.T[l] * 3);
         }
-        if (G.fail) { roitr_set_error("arena exhausted (sampling)", __FILE__, __LINE__); return ROITR_ERR_ARG; }
+        if (G.fail) { if (ahead) E.garena_short = true; roitr_set_error("arena exhausted (sampling)", __FILE__, __LINE__); return ROITR_ERR_ARG; }
         // level l's picks and their coordinates / normals: the part of the geometry chain that touches none of the shared scratch
         auto sample_level = [&](int l) -> int {
             // tmp = 1e10 (functions/pointops.py:22)
@@ -1206,7 +1241,7 @@ static int forward_body(void* h, const RoitrForwardIO* io, hipStream_t st)
         d_idx = GF.get<float>(etot);
         a_idx = GF.get<float>((size_t)etot * 3);
         Emb = GF.get<float>((size_t)etot * C4);
-        if (A.fail || G.fail) { roitr_set_error("arena exhausted (geometry)", __FILE__, __LINE__); return ROITR_ERR_ARG; }
+        if (A.fail || G.fail) { if (ahead) E.garena_short = true; roitr_set_error("arena exhausted (geometry)", __FILE__, __LINE__); return ROITR_ERR_ARG; }
 
         // ---- level-1 grid + self kNN (+ PPF): on the main stream (the first transformer needs them at once), or -- ahead mode -- in
         // front of everything else on the geometry stream, beside the previous call
@@ -1286,7 +1321,7 @@ static int forward_body(void* h, const RoitrForwardIO* io, hipStream_t st)
                 int* c4 = GF.get<int>(T4);
                 int* p2n = GF.get<int>(T1);
                 float* p2nd = GF.get<float>(T1);
-                if (GF.fail) { roitr_set_error("arena exhausted (partition)", __FILE__, __LINE__); return ROITR_ERR_ARG; }
+                if (GF.fail) { if (ahead) E.garena_short = true; roitr_set_error("arena exhausted (partition)", __FILE__, __LINE__); return ROITR_ERR_ARG; }
                 CHK(roitr_compose_idx(V.T[2], down[1], down[2], c3, sd));  // level-3 nodes as level-1 rows
                 CHK(roitr_compose_idx(T4, c3, down[3], c4, sd));
                 CHK(roitr_gather_rows(T4, 3, pts_out, c4, 0, node_xyz, sd));
@@ -1303,7 +1338,7 @@ static int forward_body(void* h, const RoitrForwardIO* io, hipStream_t st)
                 float* d2p = GF.get<float>(Tp);
                 void* ws_s = GF.get<char>(roitr_knn_workspace_bytes(B, Tsp, Ttp));
                 void* ws_t = GF.get<char>(roitr_knn_workspace_bytes(B, Ttp, Tsp));
-                if (GF.fail) { roitr_set_error("arena exhausted (gt)", __FILE__, __LINE__); return ROITR_ERR_ARG; }
+                if (GF.fail) { if (ahead) E.garena_short = true; roitr_set_error("arena exhausted (gt)", __FILE__, __LINE__); return ROITR_ERR_ARG; }
                 CHK(roitr_build_padded_clouds(B, T1, pts_out, D.off[0], io->rot, io->trans, pad, poff, sd));
                 const float* src_p = pad; const float* tgt_p = pad + (size_t)Tsp * 3;
                 const int* off_s = poff; const int* off_t = poff + 2 * B;
@@ -1323,7 +1358,7 @@ static int forward_body(void* h, const RoitrForwardIO* io, hipStream_t st)
                     float* om = GF.get<float>((size_t)B * ms);
                     float* nt_ = GF.get<float>((size_t)T4 * 3);
                     float* nr_ = GF.get<float>(T4);
-                    if (GF.fail) { roitr_set_error("arena exhausted (gt)", __FILE__, __LINE__); return ROITR_ERR_ARG; }
+                    if (GF.fail) { if (ahead) E.garena_short = true; roitr_set_error("arena exhausted (gt)", __FILE__, __LINE__); return ROITR_ERR_ARG; }
                     RoitrNodeCorr nc; memset(&nc, 0, sizeof(nc));
                     nc.pairs = B; nc.limit = LIM; nc.max_nodes = V.nmax[3]; nc.pos_radius = E.cfg.matching_radius;
                     nc.nodes = node_xyz; nc.node_offset = D.off[3]; nc.node_masks = node_masks; nc.points = pts_out; nc.pt_offset = D.off[0];

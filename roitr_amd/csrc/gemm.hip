@@ -571,8 +571,8 @@ void shape_log(const RoitrGemm* g, bool fast, float ms)
 {
     static ShapeLog log;
     char key[160];
-    snprintf(key, sizeof key, "M %d N %d K %d batch %d gather %d a2 %d relu %d seg %d fast %d", g->M, g->N, g->K, g->batch, g->a_idx != nullptr,
-             g->A2 != nullptr, g->relu, g->seg_off != nullptr, (int)fast);
+    snprintf(key, sizeof key, "M %d N %d K %d batch %d gather %d a2 %d relu %d seg %d fast %d ln %d bf16 %d", g->M, g->N, g->K, g->batch, g->a_idx != nullptr,
+             g->A2 != nullptr, g->relu, g->seg_off != nullptr, (int)fast, g->ln_gamma != nullptr, g->bf16);
     auto& st = log.m[key];
     st.ms += ms; st.n += 1;
 }
@@ -585,8 +585,19 @@ extern "C" int roitr_gemm(const RoitrGemm* g, hipStream_t stream)
 {
     if (g->M <= 0 || g->N <= 0 || g->batch <= 0) return ROITR_OK;
     if (g->K <= 0 || !g->A || !g->W || !g->C) { roitr_set_error("roitr_gemm: K <= 0 or a null operand", __FILE__, __LINE__); return ROITR_ERR_ARG; }
-    if (g->bf16 & ROITR_BF16_X3) return roitr_gemm_x3_launch(g, stream);
-    if (g->bf16) return roitr_gemm_bf16_launch(g, stream);
+    if (g->bf16) {
+        static const bool shapes_h = getenv("ROITR_GEMM_SHAPES") != nullptr;  // debug: per-shape timing table at exit (synchronous)
+        hipEvent_t h0 = nullptr, h1 = nullptr;
+        if (shapes_h) { hipEventCreate(&h0); hipEventCreate(&h1); hipEventRecord(h0, stream); }
+        const int rc = (g->bf16 & ROITR_BF16_X3) ? roitr_gemm_x3_launch(g, stream) : roitr_gemm_bf16_launch(g, stream);
+        if (shapes_h) {
+            hipEventRecord(h1, stream); hipEventSynchronize(h1);
+            float ms = 0.f; hipEventElapsedTime(&ms, h0, h1);
+            shape_log(g, true, ms);
+            hipEventDestroy(h0); hipEventDestroy(h1);
+        }
+        return rc;
+    }
     auto al16 = [](const void* p, long stride_floats) { return ((uintptr_t)p & 15) == 0 && (stride_floats % 4) == 0; };
     const bool fast = g->K % BK == 0 && g->K <= ZERO_ROW_LEN && g->lda % 4 == 0 && g->ldw % 4 == 0 && al16(g->A, g->sA) && al16(g->W, g->sW) &&
                       (!g->A2 || al16(g->A2, g->sA));

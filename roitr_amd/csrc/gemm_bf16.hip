@@ -215,8 +215,13 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(RoitrGemm g, int nx, int
                     float y = (t[i] - mean) * rstd * gam[i] + bet[i];
                     if (g.ln_post) y += g.ln_post[(size_t)row * TBN + lane + 64 * i];
                     if (g.ln_relu) y = fmaxf(y, 0.f);
-                    if (c_bf16) Ch[(size_t)row * g.ldc + lane + 64 * i] = to_bf16(y);
-                    else C[(size_t)row * g.ldc + lane + 64 * i] = y;
+                    if (c_bf16) {
+                        // two columns per 4-byte store from the even lanes (round 6: 2-byte stores made this epilogue 2.6x slower than
+                        // its fp32-output twin: 1.43 vs 0.55 ms per level-1 launch of the 64-pair 4DMatch call)
+                        const float yo = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(y), 0xB1, 0xf, 0xf, true));   // lane ^ 1
+                        if ((g.ldc & 1) == 0) { if ((lane & 1) == 0) *reinterpret_cast<unsigned*>(Ch + (size_t)row * g.ldc + lane + 64 * i) = pack_bf16(y, yo); }
+                        else Ch[(size_t)row * g.ldc + lane + 64 * i] = to_bf16(y);
+                    } else C[(size_t)row * g.ldc + lane + 64 * i] = y;
                 }
             }
         }

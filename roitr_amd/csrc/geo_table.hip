@@ -155,9 +155,12 @@ __device__ __forceinline__ void geo_table_body(const GeoTableArgs& g)
             if (OH) {
                 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
                 typedef float f32x2_t __attribute__((ext_vector_type(2)));
-                f32x2_t pr = {val, 0.f};
-                reinterpret_cast<unsigned short*>(g.out)[o] =
-                    (unsigned short)(__builtin_bit_cast(unsigned, __builtin_convertvector(pr, bf16x2_t)) & 0xffffu);
+                // lane = channel: the even lanes store their own and their right neighbour's value as one 4-byte word (round 6: 2-byte
+                // stores are ~6x slower per byte than 4-byte ones on this part, MI355X_MICROARCH.md)
+                const float vo = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(val), 0xB1, 0xf, 0xf, true));   // lane ^ 1
+                f32x2_t pr = {val, vo};
+                if ((threadIdx.x & 1) == 0)
+                    *reinterpret_cast<unsigned*>(reinterpret_cast<unsigned short*>(g.out) + o) = __builtin_bit_cast(unsigned, __builtin_convertvector(pr, bf16x2_t));
             } else reinterpret_cast<float*>(g.out)[o] = val;
         }
     }

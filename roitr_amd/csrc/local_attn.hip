@@ -486,6 +486,10 @@ extern "C" int roitr_local_attention_fold(const RoitrLocalAttnFold* a, hipStream
         roitr_set_error("local_attention_fold: (in_dim, H) must be (64, 128), (128, 256) or (256, 256) with the folded PPF weights given", __FILE__, __LINE__);
         return ROITR_ERR_UNSUPPORTED;
     }
+    if (a->ldqt != 0 && a->ldqt < 4 * a->in_dim) {   // ABI 2+ field: a client that does not zero the struct passes garbage here
+        roitr_set_error("local_attention_fold: ldqt must be 0 (dense q~ rows) or >= 4 * in_dim", __FILE__, __LINE__);
+        return ROITR_ERR_ARG;
+    }
     if ((a->ldx | a->ldq | a->ldqt) % 4 || (((uintptr_t)a->x | (uintptr_t)a->q | (uintptr_t)a->qt | (uintptr_t)a->xbar | (uintptr_t)a->vpart | (uintptr_t)a->ppf |
                                    (uintptr_t)a->wpe | (uintptr_t)a->wvpe | (uintptr_t)a->bvpe) & 15)) {
         roitr_set_error("local_attention_fold: rows and arrays must be 16-byte aligned", __FILE__, __LINE__);
