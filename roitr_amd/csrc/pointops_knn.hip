@@ -785,6 +785,9 @@ __global__ __launch_bounds__(256) void knn_cell_kernel(int nsample, const float*
         __syncthreads();
         const int centre0 = run_off[4] - run_s[4];   // slot of sorted[p] (p in the centre row run) = p + centre0
         const int T = (C + 63) >> 6;
+        // the density radius of the first pass depends on the cell only (round 6: it was a powf per query, ~6 % of the kernel's VALU work)
+        const float rho_loc = (float)C / (float)((x1 - x0 + 1) * (y1 - y0 + 1) * (z1 - z0 + 1));
+        const float rcap2 = g.h * g.h * powf(2.5f * (float)S / (4.18879f * fmaxf(rho_loc, 1e-3f)), 0.6667f);
 
         for (int p = qs + w; p < qe; p += 4) {
             const int qslot = p + centre0;
@@ -803,8 +806,6 @@ __global__ __launch_bounds__(256) void knn_cell_kernel(int nsample, const float*
             if (!covered && !(dm > 0.f)) { retry(q); continue; }
             // the list has CELL_NEAR slots: the first pass looks no farther than the radius that holds ~2.5 S points at the local
             // density (a query in the middle of its cell has dm = 1.5 h: 370 points at 26 per cell), the guarantee radius at most
-            const float rho_loc = (float)C / (float)((x1 - x0 + 1) * (y1 - y0 + 1) * (z1 - z0 + 1));
-            const float rcap2 = g.h * g.h * powf(2.5f * (float)S / (4.18879f * fmaxf(rho_loc, 1e-3f)), 0.6667f);
             float lim = covered ? rcap2 : fminf(dm * dm, rcap2);
 
             // ---- A: distances, compaction of the candidates inside the guarantee radius
