@@ -69,7 +69,9 @@ def parse():
     ap.add_argument("--config", type=int, default=2, choices=sorted(WORKLOADS))
     ap.add_argument("--pairs-per-step", type=int, default=None)
     ap.add_argument("--n-points", type=int, default=None)
-    ap.add_argument("--dtype", default=None, choices=["f32", "bf16"], help="operand storage of the dense layers (default: the config's)")
+    ap.add_argument("--dtype", default=None, choices=["f32", "bf16", "f32x3"],
+                    help="operand storage of the dense layers (default: the config's); f32x3 = fp32 with the K >= 256 linear layers on the bf16 "
+                         "matrix cores by a three-way operand split (csrc/gemm_x3.hip)")
     ap.add_argument("--weights", default=None, choices=["plain", "selective"],
                     help="closed-form weight variant (roitr_amd/weights.py); default: selective -- descriptors that discriminate, thousands of "
                          "correspondences per pair (round 4; 'plain' ends in ~34 per pair, i.e. times the matching tail on near-empty outputs)")

@@ -407,7 +407,11 @@ typedef struct RoitrEngineConfig {
                               operands, GEMM-to-GEMM intermediates, the q|k|v tensors, the attention outputs and the geometric
                               embedding E stored bf16, the patch score contraction (RIGA_v2.py:150) on a bf16 copy of the point
                               descriptors; fp32 accumulation / bias / LayerNorm / softmax everywhere; FPS, kNN, PPF, partition,
-                              coarse scores, optimal transport and fine matching stay fp32 */
+                              coarse scores, optimal transport and fine matching stay fp32;
+                              2 = fp32 everywhere like 0, but the plain linear layers with K >= 256 (levels 3 - 4, the global transformer,
+                              the decoder's coarse half) multiply on the bf16 matrix cores by the three-way operand split of
+                              csrc/gemm_x3.hip: fp32-accurate products (error against float64 not above the fp32 MFMA kernel's), rows
+                              bitwise independent of the batch; results differ from mode 0 in the last bits only (round 6) */
 } RoitrEngineConfig;
 
 typedef struct RoitrForwardIO {

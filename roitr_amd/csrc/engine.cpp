@@ -158,7 +158,38 @@ struct Engine {
     long arena_epoch = 0;            // bumped whenever the scratch arena is reallocated (invalidates captured addresses)
     unsigned long graph_clock = 0;
     char* capture_pin = nullptr;     // != nullptr: the forward is being captured and stages its descriptors here
+    // operand_dtype = 2: the three bf16 pieces (csrc/gemm_x3.hip) of every weight block a K >= 256 GEMM has multiplied with, made on first
+    // use (a warm-up call is never captured), dropped at finalize.  Key: (first element, elements) of the contiguous [N x K] block.
+    std::map<std::pair<const float*, long>, unsigned short*> x3;
 };
+
+// the engine whose forward / finalize is running on this thread (the GEMM helpers below are free functions)
+thread_local Engine* g_engine = nullptr;
+
+// operand_dtype = 2: route a plain fp32 GEMM with K >= 256 through the three-way bf16 split (same contract, fp32-accurate products on the
+// bf16 matrix cores; rows bitwise independent of the row count, so the choice may not depend on M -- it depends on (K, layout) only)
+int use_x3(RoitrGemm& g, hipStream_t st)
+{
+    Engine* E = g_engine;
+    if (!E || E->cfg.operand_dtype != 2 || !E->finalized || g.bf16 || g.K < 256 || g.ldw != g.K || g.batch != 1 || g.ln_gamma) return 0;
+    RoitrGemm t = g;
+    t.bf16 = ROITR_BF16_X3; t.w_piece = (long)g.N * g.K;
+    const long numel = (long)g.N * g.K;
+    const auto key = std::make_pair(g.W, numel);
+    auto it = E->x3.find(key);
+    unsigned short* w3 = nullptr;
+    if (it != E->x3.end()) w3 = it->second;
+    else {
+        if (E->capture_pin) return 0;   // no allocation inside a capture: this launch stays on the fp32 kernel (cannot happen after a warm-up)
+        if (hipMalloc((void**)&w3, sizeof(unsigned short) * 3 * (size_t)numel) != hipSuccess) { (void)hipGetLastError(); return 0; }
+        if (roitr_split_bf16x3(numel, g.W, w3, numel, st) != ROITR_OK) { (void)hipFree(w3); return 0; }
+        E->x3[key] = w3;
+    }
+    t.W = reinterpret_cast<const float*>(w3);
+    if (!roitr_gemm_x3_supported(&t)) return 0;
+    g = t;
+    return 0;
+}
 
 const float* P(Engine& E, const std::string& name, long expect)
 {
@@ -208,6 +239,7 @@ int gemm(hipStream_t st, int M, int N, int K, const float* A, int lda, const flo
     g.M = M; g.N = N; g.K = K; g.A = A; g.A2 = A2; g.lda = lda; g.a_idx = a_idx; g.W = W; g.ldw = ldw; g.bias = bias;
     g.alpha = alpha; g.relu = relu ? 1 : 0; g.C = C; g.ldc = ldc; g.batch = 1;
     CHK(use_bf16(g, W, Wb, bf));
+    CHK(use_x3(g, st));
     return roitr_gemm(&g, st);
 }
 int gemm(hipStream_t st, int M, const float* A, const Lin& l, float* C, bool relu = false, const int* a_idx = nullptr, const float* A2 = nullptr,
@@ -261,6 +293,7 @@ int gemm_ln(hipStream_t st, int M, const float* A, const Lin& l, const float* re
         memset(&g, 0, sizeof(g));
         g.M = M; g.N = N; g.K = K; g.A = A; g.lda = lda; g.W = w; g.ldw = ldw; g.bias = b; g.alpha = 1.0f; g.C = tmp; g.ldc = N; g.batch = 1;
         g.A_cat = A_cat; g.lda_cat = lda_cat; g.k_cat = k_cat; g.A2 = A2; g.a_cat_idx = a_cat_idx;
+        CHK(use_x3(g, st));
         CHK(roitr_gemm(&g, st));
     } else
     CHK(gemm(st, M, N, K, A, lda, w, ldw, b, tmp, N, false, nullptr, A2, 1.0f, l.wb, bf));
@@ -346,7 +379,7 @@ int fold_local(Engine& E, LocalT& L, hipStream_t st)
         if (A.fail) return ROITR_ERR_ARG;
         CHK(roitr_f32_to_bf16((long)R * H, L.wqkv, L.wqkv_b, st));
     }
-    const bool cat = E.cfg.operand_dtype == 0 && L.in_dim % 32 == 0;
+    const bool cat = E.cfg.operand_dtype != 1 && L.in_dim % 32 == 0;
     if (cat) {
         const int I = L.in_dim;
         L.wcat = A.get<float>((size_t)H * (H + I));
@@ -365,7 +398,7 @@ int fold_local(Engine& E, LocalT& L, hipStream_t st)
         CHK(roitr_transpose(H, I, L.in_proj.w, I, winT, H, st));                       // (in, H)
         CHK(gemm(st, R, I, H, L.wqkv, H, winT, H, nullptr, L.wqkv_x, I));               // (R, in) = Wqkv Win
         CHK(gemm(st, 1, R, H, L.in_proj.b, H, L.wqkv, H, L.bqkv, L.bqkv_x, R));         // Wqkv b_in + bqkv
-        if (E.cfg.operand_dtype == 0 && NQ == 0) {
+        if (E.cfg.operand_dtype != 1 && NQ == 0) {
             // q~_h = Wk'_h^T q_h needs the k rows transposed: (I, H), head h = columns h c .. (csrc/local_attn.hip, fold form)
             L.wkT_x = A.get<float>((size_t)I * H);
             if (A.fail) return ROITR_ERR_ARG;
@@ -631,7 +664,7 @@ int ffn_apply(Engine& E, hipStream_t st, const Ffn& F, int M, int C, const float
 int build_local_first(Engine& E, const LocalT& L, hipStream_t st)
 {
     const int H = L.H, c = H / HEADS;
-    if (L.in_dim != 1 || H != 64 || E.cfg.operand_dtype != 0) return 0;
+    if (L.in_dim != 1 || H != 64 || E.cfg.operand_dtype == 1) return 0;
     ROITR_HIP(hipStreamSynchronize(st));
     auto get = [&](const float* dev, size_t n, std::vector<double>& out) -> int {
         std::vector<float> h(n);
@@ -708,6 +741,7 @@ extern "C" void roitr_engine_destroy(void* h)
 {
     Engine* E = (Engine*)h;
     if (!E) return;
+    if (g_engine == E) g_engine = nullptr;
     if (E->warena.base) (void)hipFree(E->warena.base);
     if (E->arena.base) (void)hipFree(E->arena.base);
     for (int i = 0; i < 2; ++i) if (E->garena[i].base) (void)hipFree(E->garena[i].base);
@@ -717,6 +751,7 @@ extern "C" void roitr_engine_destroy(void* h)
         if (g.graph) (void)hipGraphDestroy(g.graph);
         if (g.pin) (void)hipHostFree(g.pin);
     }
+    for (auto& kv : E->x3) (void)hipFree(kv.second);
     if (E->side) (void)hipStreamDestroy(E->side);
     for (int i = 0; i < Engine::NEV; ++i) if (E->ev[i]) (void)hipEventDestroy(E->ev[i]);
     for (int i = 0; i < Engine::RING; ++i) {
@@ -750,6 +785,8 @@ extern "C" int roitr_engine_finalize(void* h, hipStream_t st)
 {
     Engine& E = *(Engine*)h;
     E.err.clear();
+    g_engine = &E;
+    E.finalized = false;   // (also: the folds below multiply WEIGHTS with weights in plain fp32 -- use_x3 only serves a finalized engine)
     // captured forwards replay kernels that read the parameter / derived-weight pointers of the previous finalize
     for (auto& g : E.graphs) {
         if (g.exec) (void)hipGraphExecDestroy(g.exec);
@@ -757,9 +794,15 @@ extern "C" int roitr_engine_finalize(void* h, hipStream_t st)
         if (g.pin) (void)hipHostFree(g.pin);
     }
     E.graphs.clear();
+    if (!E.x3.empty()) {   // split copies of the previous weights: a forward may still read them
+        ROITR_HIP(hipStreamSynchronize(st));
+        if (E.side) ROITR_HIP(hipStreamSynchronize(E.side));
+        for (auto& kv : E.x3) (void)hipFree(kv.second);
+        E.x3.clear();
+    }
     const int f = E.cfg.factor;
     const int C4 = 256 * f;
-    if (E.cfg.operand_dtype != 0 && E.cfg.operand_dtype != 1) { roitr_set_error("operand_dtype must be 0 (fp32) or 1 (bf16)", __FILE__, __LINE__); return ROITR_ERR_ARG; }
+    if (E.cfg.operand_dtype < 0 || E.cfg.operand_dtype > 2) { roitr_set_error("operand_dtype must be 0 (fp32), 1 (bf16) or 2 (fp32 by three-way bf16 split)", __FILE__, __LINE__); return ROITR_ERR_ARG; }
     // ---- derived-weight arena (folded / concatenated weights, bf16 copies); the bf16 copies are made while the names resolve
     {
         const size_t want = ((size_t)96 << 20) * (f > 1 ? 2 : 1) + (E.cfg.operand_dtype == 1 ? ((size_t)48 << 20) * f * f : 0);
@@ -975,6 +1018,7 @@ extern "C" int roitr_engine_forward(void* h, const RoitrForwardIO* io, hipStream
     E.side_forked = false;
     E.cur_par = -1;
     E.garena_short = false;
+    g_engine = &E;
     int rc = forward_body(h, io, st);
     if (rc != ROITR_OK && E.side_forked && E.side && E.ev[8]) {
         if (hipEventRecord(E.ev[8], E.side) == hipSuccess) (void)hipStreamWaitEvent(st, E.ev[8], 0);
@@ -1546,7 +1590,7 @@ static int forward_body(void* h, const RoitrForwardIO* io, hipStream_t st)
         if (A.fail) { roitr_set_error("arena exhausted (decoder)", __FILE__, __LINE__); return ROITR_ERR_ARG; }
         (void)pc;
         CHK(gemm_ln(st, Tc, xd[l + 1], U.l2, nullptr, nullptr, U.l2n_w, U.l2n_b, nullptr, true, b0, b1));
-        if (E.cfg.operand_dtype == 0) {
+        if (E.cfg.operand_dtype != 1) {
             // fp32: `linear1(x1) + interpolation(p2, p1, linear2(x2))` in the launch that computes linear1 -- the interpolation rides in
             // the LayerNorm epilogue (after the ReLU), the (Tl, pl) intermediate a1 is never written
             const Interp3 ip = {b1, i3[l], d3[l]};

@@ -192,10 +192,11 @@ class RIGA_v2(nn.Module):
         self.fine_conf = float(_cfg_get(config, "fine_matching_confidence_threshold", 0.05))
         self.fine_use_dustbin = bool(_cfg_get(config, "fine_matching_use_dustbin", False))
         self.fine_use_global_score = bool(_cfg_get(config, "fine_matching_use_global_score", False))
-        # not a reference key: 'f32' (default, the reference's arithmetic) or 'bf16' (bf16 operand storage of the dense layers)
+        # not a reference key: 'f32' (default, the reference's arithmetic), 'bf16' (bf16 operand storage of the dense layers) or 'f32x3'
+        # (fp32 like 'f32'; the K >= 256 linear layers multiply on the bf16 matrix cores by a three-way operand split, csrc/gemm_x3.hip)
         self.operand_dtype = str(_cfg_get(config, "operand_dtype", "f32"))
-        if self.operand_dtype not in ("f32", "bf16"):
-            raise ValueError(f"operand_dtype must be 'f32' or 'bf16', got {self.operand_dtype!r}")
+        if self.operand_dtype not in ("f32", "bf16", "f32x3"):
+            raise ValueError(f"operand_dtype must be 'f32', 'bf16' or 'f32x3', got {self.operand_dtype!r}")
         # not a reference key (4DMatch only): AVERAGE number of patch slots per pair a call's per-patch buffers are sized for.  The adaptive
         # matching may select every node pair (n4max^2 = 15 625 per pair at N = 8000: 33 KB of tail buffers each); the reference runs the
         # tail on the selected ones only (RIGA_v2.py:126-152), so does the engine (compacted patch list).  A call that selects more than
@@ -242,7 +243,7 @@ class RIGA_v2(nn.Module):
         cfg.matching_radius = self.matching_radius
         cfg.adaptive_coarse = 0 if self.factor == 1 else 1
         cfg.occlusion_radius = 0.0375
-        cfg.operand_dtype = 1 if self.operand_dtype == "bf16" else 0
+        cfg.operand_dtype = {"f32": 0, "bf16": 1, "f32x3": 2}[self.operand_dtype]
         lib.roitr_engine_create.restype = ctypes.c_void_p
         h = lib.roitr_engine_create(ctypes.byref(cfg))
         if not h:
