@@ -208,6 +208,7 @@ typedef struct RoitrLocalBlock {
     const float* wout; const float* bout; const float* bn2_w; const float* bn2_b;
     float scale, eps;
     float* out;
+    int kv_bf16;   /* ABI 3: 1 = the k | v rows are STORED in bf16 (`kv` -> uint16, 2 H elements per row); everything else stays fp32 */
 } RoitrLocalBlock;
 int roitr_local_block(const RoitrLocalBlock* a, roitr_stream_t stream);
 int roitr_local_block_supported(int H, int K);

@@ -379,7 +379,11 @@ int fold_local(Engine& E, LocalT& L, hipStream_t st)
         if (A.fail) return ROITR_ERR_ARG;
         CHK(roitr_f32_to_bf16((long)R * H, L.wqkv, L.wqkv_b, st));
     }
-    const bool cat = E.cfg.operand_dtype != 1 && L.in_dim % 32 == 0;
+    // bf16 operand mode (round 6): the block transformers of the 64- / 128-wide levels (in_dim == H <= 128, K = 8 / 16: exactly what
+    // roitr_local_block_supported takes) run in the fused kernel of csrc/local_block.hip as well, behind a bf16 k | v GEMM whose rows
+    // the kernel gathers as stored (RoitrLocalBlock::kv_bf16); the q projection, `linear`, the LayerNorms and out_proj inside the
+    // kernel are its fp32 arithmetic.  TransitionDown transformers (in_dim = H / 2) and the wider levels keep the bf16 launch sequence.
+    const bool cat = (E.cfg.operand_dtype != 1 || (L.in_dim == H && H <= 128)) && L.in_dim % 32 == 0;
     if (cat) {
         const int I = L.in_dim;
         L.wcat = A.get<float>((size_t)H * (H + I));
@@ -477,9 +481,12 @@ int local_transformer(Engine& E, hipStream_t st, const LocalT& L, int N_in, cons
         const int I = L.in_dim;
         float* kv = A.get<float>((size_t)N_in * 2 * H);
         if (A.fail) return ROITR_ERR_ARG;
-        CHK(gemm(st, N_in, 2 * H, I, x, I, L.wqkv_x + (size_t)(H + NQ) * I, I, L.bqkv_x + H + NQ, kv, 2 * H));
+        const unsigned short* wkv_b = (E.cfg.operand_dtype == 1 && L.wqkv_x_b && I % 64 == 0) ? L.wqkv_x_b + (size_t)(H + NQ) * I : nullptr;
+        CHK(gemm(st, N_in, 2 * H, I, x, I, L.wqkv_x + (size_t)(H + NQ) * I, I, L.bqkv_x + H + NQ, kv, 2 * H, false, nullptr, nullptr, 1.0f, wkv_b,
+                 wkv_b ? ROITR_BF16_C : 0));
         RoitrLocalBlock b;
         memset(&b, 0, sizeof(b));
+        b.kv_bf16 = wkv_b ? 1 : 0;
         b.M = M; b.K = K; b.H = H; b.x = x; b.kv = kv; b.group_idx = group; b.ppf = ppf; b.node_order = order;
         b.wq = L.wqkv_x; b.bq = L.bqkv_x; b.wpe = L.wpe; b.bpe = L.bpe; b.wvpe = L.wvpe; b.bvpe = L.bvpe;
         b.wcat = L.wcat; b.bcat = L.bcat; b.norm_w = L.norm_w; b.norm_b = L.norm_b; b.wout = L.out_proj.w; b.bout = L.out_proj.b;

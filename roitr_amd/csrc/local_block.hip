@@ -112,8 +112,20 @@ __device__ __forceinline__ void acc_store(const Acc& acc, const float* __restric
     }
 }
 
+// one float4 of a gathered k | v row: fp32 rows, or (KVH, round 6: the bf16 operand mode of the engine) rows STORED in bf16 -- half the
+// bytes of the gathers the kernel waits on; the arithmetic behind the load is the fp32 kernel's
+template <bool KVH>
+__device__ __forceinline__ float4 ld_kv4(const float* kv, size_t row, int ld, int col)
+{
+    if (KVH) {
+        const uint2 t = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(kv) + row * ld + col);
+        return make_float4(__uint_as_float(t.x << 16), __uint_as_float(t.x & 0xffff0000u), __uint_as_float(t.y << 16), __uint_as_float(t.y & 0xffff0000u));
+    }
+    return *reinterpret_cast<const float4*>(kv + row * ld + col);
+}
+
 // DBG (tuning only, scripts/bench_local_block.py): 0 = the kernel; 1 = without the attention phase; 2 = attention only
-template <int H, int K, int TM, int DBG = 0>
+template <int H, int K, int TM, int DBG = 0, bool KVH = false>
 __global__ __launch_bounds__(256, K <= 8 ? 3 : 2) void local_block_kernel(RoitrLocalBlock a)
 {
     constexpr int AP = H + 4;                 // activation image pitch
@@ -184,10 +196,10 @@ __global__ __launch_bounds__(256, K <= 8 ? 3 : 2) void local_block_kernel(RoitrL
             constexpr bool V_EARLY = K <= 8;
             float4 kr[K], vr[K];
 #pragma unroll
-            for (int kk = 0; kk < K; ++kk) kr[kk] = *reinterpret_cast<const float4*>(a.kv + (size_t)gi[kk] * (2 * H) + 4 * j);
+            for (int kk = 0; kk < K; ++kk) kr[kk] = ld_kv4<KVH>(a.kv, (size_t)gi[kk], 2 * H, 4 * j);
             if (V_EARLY) {
 #pragma unroll
-                for (int kk = 0; kk < K; ++kk) vr[kk] = *reinterpret_cast<const float4*>(a.kv + (size_t)gi[kk] * (2 * H) + H + 4 * j);
+                for (int kk = 0; kk < K; ++kk) vr[kk] = ld_kv4<KVH>(a.kv, (size_t)gi[kk], 2 * H, H + 4 * j);
             }
             int gn[K]; float pn[K];
             if (rd + 1 < NRD) load_ids(rd + 1, gn, pn);
@@ -224,7 +236,7 @@ __global__ __launch_bounds__(256, K <= 8 ? 3 : 2) void local_block_kernel(RoitrL
             }
             if (!V_EARLY) {
 #pragma unroll
-                for (int kk = 0; kk < K; ++kk) vr[kk] = *reinterpret_cast<const float4*>(a.kv + (size_t)gi[kk] * (2 * H) + H + 4 * j);
+                for (int kk = 0; kk < K; ++kk) vr[kk] = ld_kv4<KVH>(a.kv, (size_t)gi[kk], 2 * H, H + 4 * j);
             }
             float sum = 0.f;
 #pragma unroll
@@ -772,14 +784,20 @@ extern "C" int roitr_local_block(const RoitrLocalBlock* a, hipStream_t stream)
     }
     // algorithmic bytes: x in, out out, K gathered k | v rows, ppf + indices per node; FLOPs of the three on-chip GEMMs ride in aux
     const double H = a->H, K = a->K;
-    roitr_prof_begin2(ROITR_PROF_LOCAL_BLOCK, (double)a->M * (2.0 * H * 4 + K * (2.0 * H * 4 + 20.0)), 2.0 * a->M * H * H * 4.0, stream);
+    roitr_prof_begin2(ROITR_PROF_LOCAL_BLOCK, (double)a->M * (2.0 * H * 4 + K * (2.0 * H * (a->kv_bf16 ? 2 : 4) + 20.0)), 2.0 * a->M * H * H * 4.0, stream);
     if (a->H == 64) {
         const int grid = xcd_grid(div_up(a->M, 64));
-        if (a->K == 8) local_block_kernel<64, 8, 64><<<grid, 256, 0, stream>>>(*a);
+        if (a->kv_bf16) {
+            if (a->K == 8) local_block_kernel<64, 8, 64, 0, true><<<grid, 256, 0, stream>>>(*a);
+            else local_block_kernel<64, 16, 64, 0, true><<<grid, 256, 0, stream>>>(*a);
+        } else if (a->K == 8) local_block_kernel<64, 8, 64><<<grid, 256, 0, stream>>>(*a);
         else local_block_kernel<64, 16, 64><<<grid, 256, 0, stream>>>(*a);
     } else {
         const int grid = xcd_grid(div_up(a->M, 32));
-        if (a->K == 8) local_block_kernel<128, 8, 32><<<grid, 256, 0, stream>>>(*a);
+        if (a->kv_bf16) {
+            if (a->K == 8) local_block_kernel<128, 8, 32, 0, true><<<grid, 256, 0, stream>>>(*a);
+            else local_block_kernel<128, 16, 32, 0, true><<<grid, 256, 0, stream>>>(*a);
+        } else if (a->K == 8) local_block_kernel<128, 8, 32><<<grid, 256, 0, stream>>>(*a);
         else local_block_kernel<128, 16, 32><<<grid, 256, 0, stream>>>(*a);
     }
     roitr_prof_end(ROITR_PROF_LOCAL_BLOCK, stream);

@@ -433,7 +433,7 @@ class _LocalBlock(ctypes.Structure):
                 ("wpe", ctypes.c_void_p), ("bpe", ctypes.c_void_p), ("wvpe", ctypes.c_void_p), ("bvpe", ctypes.c_void_p),
                 ("wcat", ctypes.c_void_p), ("bcat", ctypes.c_void_p), ("norm_w", ctypes.c_void_p), ("norm_b", ctypes.c_void_p),
                 ("wout", ctypes.c_void_p), ("bout", ctypes.c_void_p), ("bn2_w", ctypes.c_void_p), ("bn2_b", ctypes.c_void_p),
-                ("scale", ctypes.c_float), ("eps", ctypes.c_float), ("out", ctypes.c_void_p)]
+                ("scale", ctypes.c_float), ("eps", ctypes.c_float), ("out", ctypes.c_void_p), ("kv_bf16", ctypes.c_int)]
 
 
 def local_block(x, kv, group_idx, ppf, w, node_order=None, variant=None):
@@ -441,11 +441,13 @@ def local_block(x, kv, group_idx, ppf, w, node_order=None, variant=None):
     ppftransformer.py:227-253).  x (M, H), kv (M, 2H) = k | v rows of every point, group_idx (M, K) int32, ppf (M, K, 4);
     w: dict of the FOLDED weights (include/roitr_engine.h RoitrLocalBlock): wq (H,H) bq, wpe (H,4) bpe, wvpe (H,4) bvpe,
     wcat (H,2H) bcat, norm_w norm_b, wout (H,H) bout, bn2_w bn2_b.  node_order: optional (M, 4) float32 whose last column
-    holds the node index bits (the grid's sorted-point array).  variant: tuning hook (1: no attention, 2: attention only)."""
+    holds the node index bits (the grid's sorted-point array).  variant: tuning hook (1: no attention, 2: attention only).
+    A bfloat16 `kv` tensor is gathered as stored (RoitrLocalBlock::kv_bf16, the engine's bf16 operand mode)."""
     M, H = int(x.shape[0]), int(x.shape[1])
     K = int(group_idx.shape[1])
     f = lambda t: t.contiguous().float()
-    x, kv, ppf = f(x), f(kv), f(ppf)
+    kv_h = kv.dtype == torch.bfloat16
+    x, kv, ppf = f(x), (kv.contiguous() if kv_h else f(kv)), f(ppf)
     group_idx = _i32c(group_idx)
     keep = {k: f(v) for k, v in w.items()}
     out = torch.empty((M, H), dtype=torch.float32, device=x.device)
@@ -457,6 +459,7 @@ def local_block(x, kv, group_idx, ppf, w, node_order=None, variant=None):
     for k in ("wq", "bq", "wpe", "bpe", "wvpe", "bvpe", "wcat", "bcat", "norm_w", "norm_b", "wout", "bout", "bn2_w", "bn2_b"):
         setattr(a, k, L.ptr(keep[k]))
     a.scale, a.eps, a.out = 1.0 / float(H // 4) ** 0.5, 1e-5, L.ptr(out)
+    a.kv_bf16 = int(kv_h)
     if variant is None:
         L.check(L.lib().roitr_local_block(ctypes.byref(a), L.stream_ptr()), "local_block")
     else:

@@ -524,10 +524,12 @@ def test_gemm_k_concatenated_operand_with_its_own_gather_and_an_addend(N, K, Kc,
     assert (got[:2048].double() - ref).abs().max().item() < 1e-4
 
 
-@pytest.mark.parametrize("H,K,M,order", [(64, 8, 1000, True), (64, 16, 333, False), (128, 16, 777, True), (128, 8, 65, False)])
-def test_local_block_against_float64(H, K, M, order):
+@pytest.mark.parametrize("H,K,M,order,kv_bf16", [(64, 8, 1000, True, False), (64, 16, 333, False, False), (128, 16, 777, True, False), (128, 8, 65, False, False),
+                                                   (128, 8, 1000, True, True), (64, 16, 333, False, True), (128, 16, 130, False, True), (64, 8, 65, True, True)])
+def test_local_block_against_float64(H, K, M, order, kv_bf16):
     """csrc/local_block.hip (the fused block transformer of levels 1-2) against a float64 restatement of its formulas from the
-    same folded weights: tiles that are not full (M % 64, M % 32 != 0), a visiting order, both widths and neighbour counts."""
+    same folded weights: tiles that are not full (M % 64, M % 32 != 0), a visiting order, both widths and neighbour counts; round 6:
+    also with the k | v rows stored in bf16 (the engine's bf16 operand mode) -- same bound, the restatement reads the rounded rows."""
     from roitr_amd import ops
     rng = np.random.default_rng(H + K + M)
     f32 = np.float32
@@ -544,7 +546,11 @@ def test_local_block_against_float64(H, K, M, order):
         perm = rng.permutation(M).astype(np.int32)
         node_order = np.zeros((M, 4), f32)
         node_order[:, 3] = perm.view(f32)
-    got = ops.local_block(dev(x), dev(kv), dev(grp), dev(ppf), {k: dev(v) for k, v in w.items()},
+    kv_dev = dev(kv)
+    if kv_bf16:   # the k | v rows stored bf16 (RoitrLocalBlock::kv_bf16): the float64 restatement reads the same rounded rows
+        kv_dev = kv_dev.to(torch.bfloat16)
+        kv = kv_dev.float().cpu().numpy()
+    got = ops.local_block(dev(x), kv_dev, dev(grp), dev(ppf), {k: dev(v) for k, v in w.items()},
                           node_order=dev(node_order) if order else None).cpu().numpy()
     D = {k: v.astype(np.float64) for k, v in w.items()}
     X, KV, P = x.astype(np.float64), kv.astype(np.float64), ppf.astype(np.float64)
