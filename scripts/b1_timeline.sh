@@ -2,7 +2,7 @@
 # one-pair-per-call forward: kernel time vs gaps on the device timeline (rocprofv3 kernel trace of bench.py --pairs-per-step 1)
 cd ${GRAFT_REPO_ROOT:-.}; export TMPDIR=/tmp
 out=${1:-gpurun_out/b1}; rm -rf $out; mkdir -p $out
-rocprofv3 --kernel-trace --output-format csv -d $out/t -o k -- python bench.py --pairs-per-step 1 --steps 40 --warmup 10 --no-cpu-baseline --no-single-pair --no-profile-pass --no-rccl-selftest > $out/log.txt 2>&1
+timeout 900 rocprofv3 --kernel-trace --output-format csv -d $out/t -o k -- python bench.py --pairs-per-step 1 --steps 40 --warmup 10 --no-cpu-baseline --no-single-pair --no-profile-pass --no-rccl-selftest > $out/log.txt 2>&1
 python - <<PY
 import csv,glob,collections,re
 rows=[]

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round profile collection on the GPU box (run through gpurun from the repo root):
 #   bash scripts/collect_profiles.sh r04
-# 1) rocprofv3 --kernel-trace --stats (csv) of the default bench,
+# 1) timeout 900 rocprofv3 --kernel-trace --stats (csv) of the default bench,
 # 2) two separate --pmc passes (FETCH_SIZE, WRITE_SIZE; kernel-trace only) of the default bench -> profiles/pmc_traffic.json,
 # 3) bench.py JSON lines (config 2 default, one pair per step, config 3, config 4 bf16 / f32, the driver's command),
 # 4) the SQ counter passes (scripts/knn_config5_sq.sh, scripts/sq_pass.sh) BEFORE the bench lines that attach them, bench.py --config 5,
@@ -12,9 +12,9 @@ export TMPDIR=/tmp
 out=gpurun_out/$tag
 rm -rf $out; mkdir -p $out
 P="python bench.py --no-cpu-baseline --no-single-pair --no-rccl-selftest --no-profile-pass"
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o s -- $P --steps 4 --warmup 1 > $out/stats.log 2>&1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -o f -- $P --steps 1 --warmup 1 > $out/pmc_fetch.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -o w -- $P --steps 1 --warmup 1 > $out/pmc_write.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o s -- $P --steps 4 --warmup 1 > $out/stats.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -o f -- $P --steps 1 --warmup 1 > $out/pmc_fetch.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -o w -- $P --steps 1 --warmup 1 > $out/pmc_write.log 2>&1
 python scripts/pmc_summary.py $out/pmc_fetch/f_counter_collection.csv $out/pmc_write/w_counter_collection.csv $out/${tag}_pmc_traffic.json 512 2 2
 # the bench lines below read roofline.traffic from THIS round's counter passes
 cp $out/${tag}_pmc_traffic.json profiles/pmc_traffic.json
@@ -46,6 +46,12 @@ python bench.py --gpus 1 --steps 20 --warmup 5 > $out/bench_driver.log 2>&1
 tail -1 $out/bench_driver.log > $out/${tag}_bench_driver_cmd.json
 python bench.py --config 5 > $out/bench_c5.log 2>&1
 tail -1 $out/bench_c5.log > $out/${tag}_bench_config5.json
+# round 6: the three-way-split engine mode beside the fp32 headline, the split GEMM alone, the host share with eight rank processes
+python bench.py --dtype f32x3 --no-cpu-baseline > $out/bench_x3.log 2>&1
+tail -1 $out/bench_x3.log > $out/${tag}_bench_f32x3.json
+timeout 300 python scripts/bench_gemm_x3.py > $out/${tag}_gemm_x3.txt 2>&1
+PAIRS=128 timeout 600 bash scripts/host_share_8ranks.sh $out/host8 > $out/host8.log 2>&1
+cp $out/host8/host_share.json $out/${tag}_host_share_8ranks.json
 bash scripts/batch_sweep.sh $out/sweep > $out/${tag}_batch_sweep.txt 2>&1
 bash scripts/b1_timeline.sh $out/b1 > $out/${tag}_b1_timeline.txt 2>&1
 for f in $out/${tag}_bench*.json; do echo $f; cut -c1-400 $f; done

@@ -7,7 +7,7 @@
 cd ${GRAFT_REPO_ROOT:-.}; export TMPDIR=/tmp
 out=${1:-gpurun_out/knn5sq}; rm -rf $out; mkdir -p $out
 P="python bench.py --config 5 --steps 3 --warmup 1 --no-cpu-baseline"
-rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVES \
+timeout 900 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVES \
     --output-format csv -d $out/a -o s -- $P > $out/a.log 2>&1
 python - $out <<'PY'
 import csv, collections, glob, json, os, re, sys

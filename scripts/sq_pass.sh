@@ -4,8 +4,8 @@
 cd ${GRAFT_REPO_ROOT:-.}; export TMPDIR=/tmp
 out=${1:-gpurun_out/sq}; rm -rf $out; mkdir -p $out
 P="python bench.py --no-cpu-baseline --no-single-pair --no-rccl-selftest --no-profile-pass --steps 1 --warmup 1"
-rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVES --output-format csv -d $out/a -o s -- $P > $out/a.log 2>&1
-rocprofv3 --kernel-trace --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_MFMA SQ_BUSY_CYCLES SQ_INST_CYCLES_VMEM SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS --output-format csv -d $out/b -o s -- $P > $out/b.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVES --output-format csv -d $out/a -o s -- $P > $out/a.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_MFMA SQ_BUSY_CYCLES SQ_INST_CYCLES_VMEM SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS --output-format csv -d $out/b -o s -- $P > $out/b.log 2>&1
 python - <<PY
 import csv,collections,re,glob
 def load(d):
