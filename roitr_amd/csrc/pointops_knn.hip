@@ -474,10 +474,9 @@ __device__ __forceinline__ int lane_xor(int v, int lane)
 {
     if (J == 1) return __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, true);        // quad_perm [1,0,3,2]
     if (J == 2) return __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, true);        // quad_perm [2,3,0,1]
-    if (J == 4) {
-        const int dn = __builtin_amdgcn_update_dpp(0, v, 0x124, 0xf, 0xf, true);       // row_ror:4  -> from lane - 4
-        const int up = __builtin_amdgcn_update_dpp(0, v, 0x12C, 0xf, 0xf, true);       // row_ror:12 -> from lane + 4
-        return (lane & 4) ? dn : up;
+    if (J == 4) {   // two bank-masked row rotates into one register: banks 1, 3 (lane & 4) read lane - 4, banks 0, 2 read lane + 4
+        const int dn = __builtin_amdgcn_update_dpp(0, v, 0x124, 0xf, 0xa, false);      // row_ror:4  -> from lane - 4
+        return __builtin_amdgcn_update_dpp(dn, v, 0x12C, 0xf, 0x5, false);             // row_ror:12 -> from lane + 4
     }
     if (J == 8) return __builtin_amdgcn_update_dpp(0, v, 0x128, 0xf, 0xf, true);       // row_ror:8  -> lane ^ 8
     return __shfl_xor(v, J, 64);
@@ -692,14 +691,24 @@ __global__ __launch_bounds__(256) void knn_gridsel_kernel(int m, int nsample, co
 constexpr int CELL_CAP = 1024;    // staged candidates per cell (16 KB)
 constexpr int CELL_NEAR = 256;    // candidates inside the guarantee radius kept per query (4 per lane)
 
+// lanes whose pair keeps the SMALLER key: the lower position of an ascending block, the upper position of a descending one
+constexpr unsigned long long sort64_mask(int K, int J)
+{
+    unsigned long long m = 0;
+    for (int l = 0; l < 64; ++l) m |= (unsigned long long)((((l & J) == 0) == ((l & K) == 0)) ? 1 : 0) << l;
+    return m;
+}
+// One compare per step (round 6: 5 VALU + 2 SALU instead of 13 + spilled lane masks): `d > pd` as a lane mask, flipped by a literal
+// for the lanes that keep the larger key.  Two EQUAL keys: the lane that keeps the larger one takes its partner's pair, so the pair
+// (d, j_a) exists twice and (d, j_b) is gone -- the caller's equal-neighbours check after the sort sees the two d side by side and
+// hands the query to the replay, which is where a query with equal distances among its best goes anyway.
 template <int K, int J>
 __device__ __forceinline__ void sort64_step(float& d, int& j, int lane)
 {
+    constexpr unsigned long long M = sort64_mask(K, J);
     const float pd = __int_as_float(lane_xor<J>(__float_as_int(d), lane));
     const int pj = lane_xor<J>(j, lane);
-    const bool up = (lane & K) == 0;       // ascending block (K = 64: the whole wave)
-    const bool lower = (lane & J) == 0;    // this lane holds the lower position of the pair
-    const bool take = (lower == up) ? (d > pd) : (d < pd);   // strict on both sides: equal keys never move (no duplication)
+    const bool take = __builtin_amdgcn_inverse_ballot_w64(~(__ballot(d > pd) ^ M));
     d = take ? pd : d;
     j = take ? pj : j;
 }
@@ -720,8 +729,13 @@ __device__ __forceinline__ void wave_sort64(float& d, int& j, int lane)
 }
 __device__ __forceinline__ int wave_incl_scan(int v, int lane)
 {
-#pragma unroll
-    for (int s_ = 1; s_ < 64; s_ <<= 1) { const int t = __shfl_up(v, s_, 64); if (lane >= s_) v += t; }
+    // Kogge-Stone inside the 16-lane rows (row_shr, zero fill), then the row totals: row_bcast:15 into rows 1 and 3, row_bcast:31 into 2 - 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);
     return v;
 }
 
@@ -731,20 +745,19 @@ __global__ __launch_bounds__(256) void knn_cell_kernel(int nsample, const float*
                                                        int* __restrict__ retry_list)
 {
     __shared__ float4 cand[CELL_CAP];
-    __shared__ float nd_[4][CELL_NEAR];
-    __shared__ int nj_[4][CELL_NEAR];
+    __shared__ uint2 nl_[4][CELL_NEAR];      // per wave: (distance bits, staged slot) of the candidates inside the limit
     __shared__ int hist_[4][64];
     __shared__ float sd_[4][64];
     __shared__ int sj_[4][64];
     __shared__ int run_s[9], run_off[10];
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: everything derived from it stays scalar
     const int seg = blockIdx.y;
     const RoitrGrid g = grids[seg];
     const int* cs = cell_start + (size_t)seg * (GRID_MAX_CELLS + 1);
     const int ncell = g.nx * g.ny * g.nz;
     const int S = nsample - 1;                 // neighbours other than the query itself (<= 64)
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
-    float* nd = nd_[w]; int* nj = nj_[w]; int* hist = hist_[w]; float* sd = sd_[w]; int* sj = sj_[w];
+    uint2* nl = nl_[w]; int* hist = hist_[w]; float* sd = sd_[w]; int* sj = sj_[w];
     const float margin = 2e-4f * g.h;
     auto retry = [&](int q) { if (lane == 0) { const int slot = atomicAdd(retry_count, 1); retry_list[slot] = q; } };
     auto tie = [&](int q) { if (lane == 0) { const int slot = atomicAdd(o.tie_count, 1); o.tie_list[slot] = q; } };
@@ -808,19 +821,33 @@ __global__ __launch_bounds__(256) void knn_cell_kernel(int nsample, const float*
             // density (a query in the middle of its cell has dm = 1.5 h: 370 points at 26 per cell), the guarantee radius at most
             float lim = covered ? rcap2 : fminf(dm * dm, rcap2);
 
-            // ---- A: distances, compaction of the candidates inside the guarantee radius
+            // ---- A: distances, compaction of the candidates inside the guarantee radius.  Four 64-candidate groups per round: the
+            // four LDS reads are in flight together (round 6; one read, one wait per group before).  Which lanes of a group count is a
+            // scalar mask (the tail of the staged run; the query's own slot), the list position one v_mbcnt pair on the ballot.
             int cnt = 0;
+            const int self_t = qslot >> 6;
+            const unsigned long long self_bit = 1ull << (qslot & 63);
+            const unsigned long long tail_mask = (C & 63) ? ((1ull << (C & 63)) - 1ull) : ~0ull;
             auto scan_staged = [&]() {
                 cnt = 0;
-                for (int t = 0; t < T; ++t) {
-                    const int j = t * 64 + lane;
-                    const float4 c = cand[min(j, C - 1)];
-                    const float d = sqdist3(Qp.x, Qp.y, Qp.z, c.x, c.y, c.z);
-                    const bool near = j < C && j != qslot && d < lim;
-                    const unsigned long long mk = __ballot(near);
-                    const int pos = cnt + __popcll(mk & lt_mask);
-                    if (near && pos < CELL_NEAR) { nd[pos] = d; nj[pos] = j; }
-                    cnt += __popcll(mk);
+#pragma unroll 1
+                for (int t0 = 0; t0 < T; t0 += 4) {
+                    float4 c[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) c[u] = cand[min(t0 + u, CELL_CAP / 64 - 1) * 64 + lane];   // past C: never counted
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int t = t0 + u;
+                        if (t < T) {
+                            const float d = sqdist3(Qp.x, Qp.y, Qp.z, c[u].x, c[u].y, c[u].z);
+                            unsigned long long mk = __ballot(d < lim);
+                            mk &= (t == T - 1) ? tail_mask : ~0ull;
+                            mk &= (t == self_t) ? ~self_bit : ~0ull;
+                            const int pos = __builtin_amdgcn_mbcnt_hi((unsigned)(mk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk, cnt));
+                            if (__builtin_amdgcn_inverse_ballot_w64(mk) && pos < CELL_NEAR) nl[pos] = make_uint2(__float_as_uint(d), (unsigned)(t * 64 + lane));
+                            cnt += __popcll(mk);
+                        }
+                    }
                 }
             };
             scan_staged();
@@ -864,7 +891,7 @@ __global__ __launch_bounds__(256) void knn_cell_kernel(int nsample, const float*
                                 const bool near = pp < re && d < lim;
                                 const unsigned long long mk = __ballot(near);
                                 const int pos = cnt + __popcll(mk & lt_mask);
-                                if (near && pos < CELL_NEAR) { nd[pos] = d; nj[pos] = -(pp + 1); }
+                                if (near && pos < CELL_NEAR) nl[pos] = make_uint2(__float_as_uint(d), (unsigned)(-(pp + 1)));
                                 cnt += __popcll(mk);
                             }
                         }
@@ -873,14 +900,13 @@ __global__ __launch_bounds__(256) void knn_cell_kernel(int nsample, const float*
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             float e[4]; int ej[4];
-            float emax = 0.f;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int k = lane + 64 * r;
+                const uint2 t = nl[k];
                 const bool v = k < cnt;
-                e[r] = v ? nd[k] : INFINITY;
-                ej[r] = v ? nj[k] : 0;
-                emax = v ? fmaxf(emax, e[r]) : emax;
+                e[r] = v ? __uint_as_float(t.x) : INFINITY;
+                ej[r] = v ? (int)t.y : 0;
             }
             // ---- B: exact threshold of rank S
             const float hi = lim;   // every listed distance is < lim (finite: capped by the density radius)
