@@ -789,11 +789,12 @@ __global__ __launch_bounds__(256) void knn_cell_kernel(int nsample, const float*
             for (int p = qs + tid; p < qe; p += 256) { const int slot = atomicAdd(retry_count, 1); retry_list[slot] = __float_as_int(sorted[p].w); }
             continue;
         }
-        for (int e = tid; e < C; e += 256) {
+        for (int e = tid; e < ((C + 63) & ~63); e += 256) {
             int r = 0;
 #pragma unroll
             for (int u = 1; u < 9; ++u) r += (e >= run_off[u]) ? 1 : 0;
-            cand[e] = sorted[run_s[r] + (e - run_off[r])];
+            // the tail of the last 64-group: points at infinity, whose distance passes no limit (no validity mask in the scan)
+            cand[e] = e < C ? sorted[run_s[r] + (e - run_off[r])] : make_float4(INFINITY, INFINITY, INFINITY, 0.f);
         }
         __syncthreads();
         const int centre0 = run_off[4] - run_s[4];   // slot of sorted[p] (p in the centre row run) = p + centre0
@@ -822,12 +823,10 @@ __global__ __launch_bounds__(256) void knn_cell_kernel(int nsample, const float*
             float lim = covered ? rcap2 : fminf(dm * dm, rcap2);
 
             // ---- A: distances, compaction of the candidates inside the guarantee radius.  Four 64-candidate groups per round: the
-            // four LDS reads are in flight together (round 6; one read, one wait per group before).  Which lanes of a group count is a
-            // scalar mask (the tail of the staged run; the query's own slot), the list position one v_mbcnt pair on the ballot.
+            // four LDS reads are in flight together (round 6; one read, one wait per group before); the list position is one v_mbcnt
+            // pair on the ballot.  The query ITSELF (distance 0) is listed like any candidate -- cnt counts it, the rank search below
+            // looks for rank S + 1, the selection drops it by its slot -- so the scan carries no per-group mask at all.
             int cnt = 0;
-            const int self_t = qslot >> 6;
-            const unsigned long long self_bit = 1ull << (qslot & 63);
-            const unsigned long long tail_mask = (C & 63) ? ((1ull << (C & 63)) - 1ull) : ~0ull;
             auto scan_staged = [&]() {
                 cnt = 0;
 #pragma unroll 1
@@ -840,11 +839,10 @@ __global__ __launch_bounds__(256) void knn_cell_kernel(int nsample, const float*
                         const int t = t0 + u;
                         if (t < T) {
                             const float d = sqdist3(Qp.x, Qp.y, Qp.z, c[u].x, c[u].y, c[u].z);
-                            unsigned long long mk = __ballot(d < lim);
-                            mk &= (t == T - 1) ? tail_mask : ~0ull;
-                            mk &= (t == self_t) ? ~self_bit : ~0ull;
+                            const bool near = d < lim;
+                            const unsigned long long mk = __ballot(near);
                             const int pos = __builtin_amdgcn_mbcnt_hi((unsigned)(mk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk, cnt));
-                            if (__builtin_amdgcn_inverse_ballot_w64(mk) && pos < CELL_NEAR) nl[pos] = make_uint2(__float_as_uint(d), (unsigned)(t * 64 + lane));
+                            if (near && pos < CELL_NEAR) nl[pos] = make_uint2(__float_as_uint(d), (unsigned)(t * 64 + lane));
                             cnt += __popcll(mk);
                         }
                     }
@@ -852,7 +850,7 @@ __global__ __launch_bounds__(256) void knn_cell_kernel(int nsample, const float*
             };
             scan_staged();
             if (cnt > CELL_NEAR) { retry(q); continue; }   // too dense for the list
-            if (cnt < S) {
+            if (cnt <= S) {   // cnt counts the query itself
                 // Guarantee radius not reached (5.5 % of the queries of a uniform cube: the cells at its faces, whose sphere is cut
                 // by the boundary).  Second ring for THIS query: the 5 x 5 x 5 box's guarantee radius, capped at the radius the
                 // local density says holds ~1.7 S neighbours (the list has CELL_NEAR slots); the staged 27 cells are re-scanned
@@ -868,7 +866,7 @@ __global__ __launch_bounds__(256) void knn_cell_kernel(int nsample, const float*
                 if (z0b > 0) dmin2 = fminf(dmin2, Qp.z - __fmaf_rn((float)z0b, g.h, g.oz));
                 if (z1b < g.nz - 1) dmin2 = fminf(dmin2, __fmaf_rn((float)(z1b + 1), g.h, g.oz) - Qp.z);
                 const float dm2 = dmin2 - margin;
-                const float want = lim * powf(1.7f * (float)S / (float)max(cnt, 1), 0.6667f);   // r^2 ~ count^(2/3)
+                const float want = lim * powf(1.7f * (float)S / (float)max(cnt - 1, 1), 0.6667f);   // r^2 ~ count^(2/3)
                 const float g1 = covered ? INFINITY : dm * dm;               // what the staged cells alone guarantee
                 const float lim2 = dmin2 == INFINITY ? want : fminf(dm2 * dm2, want);
                 if (!(lim2 > lim)) { retry(q); continue; }
@@ -896,7 +894,7 @@ __global__ __launch_bounds__(256) void knn_cell_kernel(int nsample, const float*
                             }
                         }
                     }
-                if (cnt > CELL_NEAR || cnt < S) { retry(q); continue; }
+                if (cnt > CELL_NEAR || cnt <= S) { retry(q); continue; }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             float e[4]; int ej[4];
@@ -908,7 +906,8 @@ __global__ __launch_bounds__(256) void knn_cell_kernel(int nsample, const float*
                 e[r] = v ? __uint_as_float(t.x) : INFINITY;
                 ej[r] = v ? (int)t.y : 0;
             }
-            // ---- B: exact threshold of rank S
+            // ---- B: exact threshold of rank S + 1 (the query's own distance 0 is rank 1)
+            const int S1 = S + 1;
             const float hi = lim;   // every listed distance is < lim (finite: capped by the density radius)
             const float scale = 64.0f / hi;
             hist[lane] = 0;
@@ -922,10 +921,10 @@ __global__ __launch_bounds__(256) void knn_cell_kernel(int nsample, const float*
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             const int h = hist[lane];
             const int incl = wave_incl_scan(h, lane);
-            const unsigned long long ge = __ballot(incl >= S);   // != 0: cnt >= S
+            const unsigned long long ge = __ballot(incl >= S1);   // != 0: cnt >= S + 1
             const int B = __ffsll((long long)ge) - 1;
             const int nB = rl_i(h, B);
-            const int r_need = S - (rl_i(incl, B) - nB);          // 1 .. nB elements of bin B belong to the answer
+            const int r_need = S1 - (rl_i(incl, B) - nB);         // 1 .. nB elements of bin B belong to the answer
             float tau;
             {
                 // the elements of bin B, compacted to lanes 0 .. nB-1 (nB is small: ~2 on uniform clouds)
@@ -935,7 +934,7 @@ __global__ __launch_bounds__(256) void knn_cell_kernel(int nsample, const float*
                 for (int r = 0; r < 4; ++r) {
                     const bool inb = (lane + 64 * r < cnt) && bin[r] == B;
                     const unsigned long long mk = __ballot(inb);
-                    const int pos = base + __popcll(mk & lt_mask);
+                    const int pos = __builtin_amdgcn_mbcnt_hi((unsigned)(mk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk, base));
                     if (inb && pos < 64) sd[pos] = e[r];
                     base += __popcll(mk);
                 }
@@ -956,9 +955,9 @@ __global__ __launch_bounds__(256) void knn_cell_kernel(int nsample, const float*
                 int base = 0;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const bool sel = (lane + 64 * r < cnt) && e[r] <= tau;
+                    const bool sel = e[r] <= tau && ej[r] != qslot;   // idle slots hold +inf; the query itself is not its own neighbour
                     const unsigned long long mk = __ballot(sel);
-                    const int pos = base + __popcll(mk & lt_mask);
+                    const int pos = __builtin_amdgcn_mbcnt_hi((unsigned)(mk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk, base));
                     if (sel && pos < 64) { sd[pos] = e[r]; sj[pos] = ej[r]; }
                     base += __popcll(mk);
                 }
