@@ -60,8 +60,12 @@ __device__ __forceinline__ void acc_zero(Acc& a)
 // B fragments -- 16-byte pieces of ITS 32 weight rows -- come straight from L1 / L2 into registers, one 32-k slab ahead of the
 // MFMAs: no LDS staging, no barrier inside a phase (round 3: staging every slab through LDS with two barriers each held the
 // on-chip GEMMs at 58 TFLOP/s at H = 128, where a 32-row tile re-streams all 256 KB of weights).
-template <int H, int AP>
-__device__ __forceinline__ void gemm_phase(Acc& acc, const float* __restrict__ A, int Ka, const float* __restrict__ W, int ldw, int k_w0,
+// RT (round 6): the wave computes RT regions of 32 rows each (rows r0 + 32 t) against the SAME 32 weight rows -- the B fragments of a
+// slab are fetched once and used RT times.  The on-chip GEMMs are bound by streaming the weights out of L2 (every tile re-reads all
+// of them: 2 KB per node at H = 64 / TM = 64, 8 KB at H = 128 / TM = 32 -- ~6 TB/s in both widths at the measured phase times), not by
+// the matrix pipe, so rows per weight pass is what counts.
+template <int H, int AP, int RT = 1>
+__device__ __forceinline__ void gemm_phase(Acc (&acc)[RT], const float* __restrict__ A, int Ka, const float* __restrict__ W, int ldw, int k_w0,
                                            int r0, int c0, int tid)
 {
     const int lane = tid & 63, i = lane & 15, g = lane >> 4;
@@ -83,18 +87,28 @@ __device__ __forceinline__ void gemm_phase(Acc& acc, const float* __restrict__ A
         }
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
-            const float4 a0 = *reinterpret_cast<const float4*>(A + (r0 + i) * AP + k0 + 16 * c + 4 * g);
-            const float4 a1 = *reinterpret_cast<const float4*>(A + (r0 + 16 + i) * AP + k0 + 16 * c + 4 * g);
             const float4 b0 = bc[c][0], b1 = bc[c][1];
-#define LB_STEP(S)                                                                                        \
-            acc.t[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.S, b0.S, acc.t[0][0], 0, 0, 0);          \
-            acc.t[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.S, b1.S, acc.t[0][1], 0, 0, 0);          \
-            acc.t[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.S, b0.S, acc.t[1][0], 0, 0, 0);          \
-            acc.t[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.S, b1.S, acc.t[1][1], 0, 0, 0)
-            LB_STEP(x); LB_STEP(y); LB_STEP(z); LB_STEP(w);
+#pragma unroll
+            for (int t = 0; t < RT; ++t) {
+                const float4 a0 = *reinterpret_cast<const float4*>(A + (r0 + 32 * t + i) * AP + k0 + 16 * c + 4 * g);
+                const float4 a1 = *reinterpret_cast<const float4*>(A + (r0 + 32 * t + 16 + i) * AP + k0 + 16 * c + 4 * g);
+#define LB_STEP(S)                                                                                                  \
+                acc[t].t[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.S, b0.S, acc[t].t[0][0], 0, 0, 0);          \
+                acc[t].t[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.S, b1.S, acc[t].t[0][1], 0, 0, 0);          \
+                acc[t].t[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.S, b0.S, acc[t].t[1][0], 0, 0, 0);          \
+                acc[t].t[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.S, b1.S, acc[t].t[1][1], 0, 0, 0)
+                LB_STEP(x); LB_STEP(y); LB_STEP(z); LB_STEP(w);
 #undef LB_STEP
+            }
         }
     }
+}
+// one region (local_td_kernel, local_first_kernel)
+template <int H, int AP>
+__device__ __forceinline__ void gemm_phase(Acc& acc, const float* __restrict__ A, int Ka, const float* __restrict__ W, int ldw, int k_w0,
+                                           int r0, int c0, int tid)
+{
+    gemm_phase<H, AP, 1>(reinterpret_cast<Acc (&)[1]>(acc), A, Ka, W, ldw, k_w0, r0, c0, tid);
 }
 
 // D[row][col] = acc + bias[col] into a row-major LDS tile (pitch DP); 16x16 C/D map: col = lane & 15, row = 4 (lane >> 4) + reg
@@ -126,7 +140,7 @@ __device__ __forceinline__ float4 ld_kv4(const float* kv, size_t row, int ld, in
 
 // DBG (tuning only, scripts/bench_local_block.py): 0 = the kernel; 1 = without the attention phase; 2 = attention only
 template <int H, int K, int TM, int DBG = 0, bool KVH = false>
-__global__ __launch_bounds__(256, K <= 8 ? 3 : 2) void local_block_kernel(RoitrLocalBlock a)
+__global__ __launch_bounds__(256, (K <= 8 && TM * H <= 4096) ? 3 : 2) void local_block_kernel(RoitrLocalBlock a)
 {
     constexpr int AP = H + 4;                 // activation image pitch
     constexpr int LPN = H / 4;                // lanes per node in the attention
@@ -162,14 +176,24 @@ __global__ __launch_bounds__(256, K <= 8 ? 3 : 2) void local_block_kernel(RoitrL
             *reinterpret_cast<float4*>(R1 + (e / F4) * AP + 4 * (e % F4)) = xr[u];
         }
     }
-    const int r0 = TM == 64 ? (wave >> 1) * 32 : 0;
-    const int c0 = TM == 64 ? (wave & 1) * 32 : wave * 32;
-    Acc acc;
+    // the TM x H output is (TM / 32) x (H / 32) regions of 32 x 32: a wave takes ONE 32-column strip and RT row regions under each other
+    constexpr int NC = H / 32, RT = TM * H / (32 * 32 * 4);
+    const int r0 = (wave / NC) * 32 * RT;
+    const int c0 = (wave % NC) * 32;
+    Acc acc[RT];
+    auto zero_all = [&]() {
+#pragma unroll
+        for (int t = 0; t < RT; ++t) acc_zero(acc[t]);
+    };
+    auto store_all = [&](const float* bias) {
+#pragma unroll
+        for (int t = 0; t < RT; ++t) acc_store<AP>(acc[t], bias, R2, r0 + 32 * t, c0, lane);
+    };
     // ---- P1: q = x Wq^T + bq -> R2
     __syncthreads();                                              // the x image is complete
-    acc_zero(acc);
-    if (DBG != 2) gemm_phase<H, AP>(acc, R1, H, a.wq, H, 0, r0, c0, tid);
-    acc_store<AP>(acc, a.bq, R2, r0, c0, lane);
+    zero_all();
+    if (DBG != 2) gemm_phase<H, AP, RT>(acc, R1, H, a.wq, H, 0, r0, c0, tid);
+    store_all(a.bq);
     __syncthreads();
     // ---- P2: attention, in place on R2 (a wave touches only the rows of its own nodes)
     if (DBG != 1) {
@@ -267,13 +291,13 @@ __global__ __launch_bounds__(256, K <= 8 ? 3 : 2) void local_block_kernel(RoitrL
     }
     // ---- P3: y = LN([att | x] Wcat^T + bcat)
     __syncthreads();                                              // the attention rows of every wave are in place
-    acc_zero(acc);
+    zero_all();
     if (DBG != 2) {
-    gemm_phase<H, AP>(acc, R2, H, a.wcat, 2 * H, 0, r0, c0, tid);
-    gemm_phase<H, AP>(acc, R1, H, a.wcat, 2 * H, H, r0, c0, tid);
+    gemm_phase<H, AP, RT>(acc, R2, H, a.wcat, 2 * H, 0, r0, c0, tid);
+    gemm_phase<H, AP, RT>(acc, R1, H, a.wcat, 2 * H, H, r0, c0, tid);
     }
     __syncthreads();                                              // every wave is done reading R1 / R2
-    acc_store<AP>(acc, a.bcat, R2, r0, c0, lane);
+    store_all(a.bcat);
     __syncthreads();
     {
         // LayerNorm over the H channels of a row: 16 lanes per row (HV float4 per lane), four rows per wave at a time -- the row
@@ -318,10 +342,10 @@ __global__ __launch_bounds__(256, K <= 8 ? 3 : 2) void local_block_kernel(RoitrL
         }
     }
     __syncthreads();                                              // the y image is complete
-    acc_zero(acc);
-    if (DBG != 2) gemm_phase<H, AP>(acc, R1, H, a.wout, H, 0, r0, c0, tid);
+    zero_all();
+    if (DBG != 2) gemm_phase<H, AP, RT>(acc, R1, H, a.wout, H, 0, r0, c0, tid);
     __syncthreads();                                              // every wave is done reading the y image
-    acc_store<AP>(acc, a.bout, R2, r0, c0, lane);
+    store_all(a.bout);
     __syncthreads();
     {
         const int lr = lane >> 4, lc = lane & 15;
@@ -757,15 +781,18 @@ extern "C" int roitr_local_block_supported(int H, int K)
 extern "C" int roitr_local_block_dbg(const RoitrLocalBlock* a, int variant, hipStream_t stream)
 {
     if (a->M <= 0 || !roitr_local_block_supported(a->H, a->K)) return ROITR_ERR_UNSUPPORTED;
-    const int grid = xcd_grid(div_up(a->M, a->H == 64 ? 64 : 32));
+    // variant = 10 * big + phase: phase 0 = the kernel, 1 = without the attention phase, 2 = attention only; big = 1: twice the rows per tile
+    const int big = variant / 10, ph = variant % 10;
+    const int tm = (a->H == 64 ? 64 : 32) * (big ? 2 : 1);
+    const int grid = xcd_grid(div_up(a->M, tm));
 #define LB_DBG(HH, KK, TT)                                                                     \
     do {                                                                                       \
-        if (variant == 1) local_block_kernel<HH, KK, TT, 1><<<grid, 256, 0, stream>>>(*a);     \
-        else if (variant == 2) local_block_kernel<HH, KK, TT, 2><<<grid, 256, 0, stream>>>(*a); \
+        if (ph == 1) local_block_kernel<HH, KK, TT, 1><<<grid, 256, 0, stream>>>(*a);     \
+        else if (ph == 2) local_block_kernel<HH, KK, TT, 2><<<grid, 256, 0, stream>>>(*a); \
         else local_block_kernel<HH, KK, TT, 0><<<grid, 256, 0, stream>>>(*a);                  \
     } while (0)
-    if (a->H == 64 && a->K == 8) LB_DBG(64, 8, 64);
-    else if (a->H == 128 && a->K == 16) LB_DBG(128, 16, 32);
+    if (a->H == 64 && a->K == 8) { if (big) LB_DBG(64, 8, 128); else LB_DBG(64, 8, 64); }
+    else if (a->H == 128 && a->K == 16) { if (big) LB_DBG(128, 16, 64); else LB_DBG(128, 16, 32); }
     else return ROITR_ERR_UNSUPPORTED;
 #undef LB_DBG
     ROITR_LAUNCH_CHECK();
@@ -785,21 +812,27 @@ extern "C" int roitr_local_block(const RoitrLocalBlock* a, hipStream_t stream)
     // algorithmic bytes: x in, out out, K gathered k | v rows, ppf + indices per node; FLOPs of the three on-chip GEMMs ride in aux
     const double H = a->H, K = a->K;
     roitr_prof_begin2(ROITR_PROF_LOCAL_BLOCK, (double)a->M * (2.0 * H * 4 + K * (2.0 * H * (a->kv_bf16 ? 2 : 4) + 20.0)), 2.0 * a->M * H * H * 4.0, stream);
-    if (a->H == 64) {
-        const int grid = xcd_grid(div_up(a->M, 64));
-        if (a->kv_bf16) {
-            if (a->K == 8) local_block_kernel<64, 8, 64, 0, true><<<grid, 256, 0, stream>>>(*a);
-            else local_block_kernel<64, 16, 64, 0, true><<<grid, 256, 0, stream>>>(*a);
-        } else if (a->K == 8) local_block_kernel<64, 8, 64><<<grid, 256, 0, stream>>>(*a);
-        else local_block_kernel<64, 16, 64><<<grid, 256, 0, stream>>>(*a);
-    } else {
-        const int grid = xcd_grid(div_up(a->M, 32));
-        if (a->kv_bf16) {
-            if (a->K == 8) local_block_kernel<128, 8, 32, 0, true><<<grid, 256, 0, stream>>>(*a);
-            else local_block_kernel<128, 16, 32, 0, true><<<grid, 256, 0, stream>>>(*a);
-        } else if (a->K == 8) local_block_kernel<128, 8, 32><<<grid, 256, 0, stream>>>(*a);
-        else local_block_kernel<128, 16, 32><<<grid, 256, 0, stream>>>(*a);
-    }
+    // Rows per tile: twice as many (two row regions per wave under the same weight fragments: half the weight bytes streamed out of L2
+    // per node, half the tiles) once that still leaves >= LB_BIG_MIN_TILES tiles -- level 1 / 2 of a 512-pair step 3.32 -> 2.97 and
+    // 2.77 -> 2.48 ms per launch (scripts/bench_local_block.py).  A node's result is the same bits in either tile shape (one fixed
+    // sequence of operations per row), so the choice may depend on M.
+    constexpr int LB_BIG_MIN_TILES = 1024;
+    const int tm_small = a->H == 64 ? 64 : 32;
+    const bool big = div_up(a->M, 2 * tm_small) >= LB_BIG_MIN_TILES;
+    const int grid = xcd_grid(div_up(a->M, big ? 2 * tm_small : tm_small));
+#define LB_GO(HH, KK, TT, KVH_) local_block_kernel<HH, KK, TT, 0, KVH_><<<grid, 256, 0, stream>>>(*a)
+#define LB_PICK(HH, TS)                                                                           \
+    do {                                                                                          \
+        if (a->kv_bf16) {                                                                         \
+            if (a->K == 8) { if (big) LB_GO(HH, 8, 2 * TS, true); else LB_GO(HH, 8, TS, true); }      \
+            else { if (big) LB_GO(HH, 16, 2 * TS, true); else LB_GO(HH, 16, TS, true); }              \
+        } else if (a->K == 8) { if (big) LB_GO(HH, 8, 2 * TS, false); else LB_GO(HH, 8, TS, false); } \
+        else { if (big) LB_GO(HH, 16, 2 * TS, false); else LB_GO(HH, 16, TS, false); }                \
+    } while (0)
+    if (a->H == 64) LB_PICK(64, 64);
+    else LB_PICK(128, 32);
+#undef LB_PICK
+#undef LB_GO
     roitr_prof_end(ROITR_PROF_LOCAL_BLOCK, stream);
     ROITR_LAUNCH_CHECK();
     return ROITR_OK;

@@ -22,7 +22,7 @@ for H, K, n_cloud in ((64, 8, 5000), (128, 16, 1250)):
     r = lambda *s: torch.randn(s, device=dev, generator=g) / (s[-1] ** 0.5)
     w = dict(wq=r(H, H), bq=r(H), wpe=r(H, 4), bpe=r(H), wvpe=r(H, 4), bvpe=r(H), wcat=r(H, 2 * H), bcat=r(H), norm_w=1 + 0.1 * r(H),
              norm_b=0.1 * r(H), wout=r(H, H), bout=r(H), bn2_w=1 + 0.1 * r(H), bn2_b=0.1 * r(H))
-    for variant, name in ((None, "kernel"), (1, "no attention"), (2, "attention only")):
+    for variant, name in ((None, "kernel"), (1, "no attention"), (2, "attention only"), (10, "kernel, 2x rows"), (11, "no attention, 2x"), (12, "attn only, 2x")):
         for _ in range(2):
             ops.local_block(x, kv, grp, ppf, w, variant=variant)
         torch.cuda.synchronize()
@@ -33,4 +33,4 @@ for H, K, n_cloud in ((64, 8, 5000), (128, 16, 1250)):
         e1.record(); torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / 5
         flops = 8.0 * M * H * H
-        print(f"H={H} K={K} M={M}: {name:15s} {ms:7.3f} ms   ({flops / ms / 1e9:6.1f} TFLOP/s on the on-chip GEMMs)")
+        print(f"H={H} K={K} M={M}: {name:20s} {ms:7.3f} ms   ({flops / ms / 1e9:6.1f} TFLOP/s on the on-chip GEMMs)")

@@ -576,6 +576,28 @@ def test_local_block_against_float64(H, K, M, order, kv_bf16):
     assert err < 3e-5, err
 
 
+@pytest.mark.parametrize("H,K,kv_bf16", [(64, 8, False), (128, 16, False), (64, 16, True), (128, 8, True)])
+def test_local_block_rows_do_not_depend_on_the_tile_shape(H, K, kv_bf16):
+    """roitr_local_block takes tiles of twice the rows (two row regions per wave under the same weight fragments) from 1024 such tiles on
+    (round 6): the same nodes computed in a call below that size -- the small tile shape -- give the same bits."""
+    from roitr_amd import ops
+    M = (2 * (64 if H == 64 else 32)) * 1024 + 77                  # big tiles, the last one not full
+    g = torch.Generator(device="cuda").manual_seed(H + K)
+    x = torch.randn((M, H), device="cuda", generator=g)
+    kv = torch.randn((M, 2 * H), device="cuda", generator=g)
+    if kv_bf16:
+        kv = kv.to(torch.bfloat16)
+    grp = torch.randint(0, M, (M, K), device="cuda", generator=g).to(torch.int32)
+    ppf = torch.rand((M, K, 4), device="cuda", generator=g)
+    r = lambda *s: torch.randn(s, device="cuda", generator=g) / (s[-1] ** 0.5)
+    w = dict(wq=r(H, H), bq=r(H), wpe=r(H, 4), bpe=r(H), wvpe=r(H, 4), bvpe=r(H), wcat=r(H, 2 * H), bcat=r(H), norm_w=1 + 0.1 * r(H),
+             norm_b=0.1 * r(H), wout=r(H, H), bout=r(H), bn2_w=1 + 0.1 * r(H), bn2_b=0.1 * r(H))
+    big = ops.local_block(x, kv, grp, ppf, w)
+    for lo, hi in ((0, 50000), (M - 30011, M)):
+        small = ops.local_block(x[lo:hi], kv, grp[lo:hi], ppf[lo:hi], w)
+        assert torch.equal(small, big[lo:hi]), (lo, hi)
+
+
 @pytest.mark.parametrize("I,H,M,N_in", [(64, 128, 1000, 4000), (128, 256, 517, 2100), (256, 256, 130, 700)])
 def test_local_attention_fold_against_the_unfolded_form(I, H, M, N_in):
     """csrc/local_attn.hip local_attn_fold_kernel (the TransitionDown layers of the fp32 engine): scores from q~_h = Wk_h^T q_h
