@@ -209,6 +209,10 @@ typedef struct RoitrLocalBlock {
     float scale, eps;
     float* out;
     int kv_bf16;   /* ABI 3: 1 = the k | v rows are STORED in bf16 (`kv` -> uint16, 2 H elements per row); everything else stays fp32 */
+    /* ABI 4 (optional, all three or none, with kv_bf16 = 1): bf16 copies of wq (H x H), wcat (H x 2H), wout (H x H).  Given: the three
+     * on-chip GEMMs take bf16 matrix operands (v_mfma_f32_32x32x16_bf16, fp32 accumulate; the activations are rounded on their way into
+     * the operand registers, like the A operand of a ROITR_BF16_W GEMM) -- the fused block of the engine's bf16 operand mode */
+    const unsigned short* wq_h; const unsigned short* wcat_h; const unsigned short* wout_h;
 } RoitrLocalBlock;
 int roitr_local_block(const RoitrLocalBlock* a, roitr_stream_t stream);
 int roitr_local_block_supported(int H, int K);

@@ -62,7 +62,7 @@ struct LocalT {  // LocalPPFTransformer (+ derived weights)
     float* wqqt_x = nullptr; float* bqqt_x = nullptr;
     // block transformers in fp32: linear(att) + in_proj(x) as ONE GEMM over the K-concatenated operand [att | x]:
     // wcat = [Wlin | Win] (H x (H + in_dim)), bcat = b_lin + b_in; f = in_proj(x) is then never materialised
-    float* wcat = nullptr; float* bcat = nullptr;
+    float* wcat = nullptr; float* bcat = nullptr; unsigned short* wcat_b = nullptr;   // wcat_b: bf16 copy (bf16 operand mode, fused block)
     // the PPF coefficient rows of the query, qp[h] = [Wpe_h^T q_h, q_h . bpe_h]: computed inside the attention kernel from
     // wpe (H,4) / bpe (H) (nq = 0: [q|k|v] is 3 H wide = whole 64-column GEMM tiles), or as 5 extra GEMM columns per head (nq = 20)
     const float* wpe = nullptr; const float* bpe = nullptr; int nq = 0;
@@ -392,6 +392,11 @@ int fold_local(Engine& E, LocalT& L, hipStream_t st)
         ROITR_HIP(hipMemcpy2DAsync(L.wcat, sizeof(float) * (H + I), L.lin.w, sizeof(float) * H, sizeof(float) * H, H, hipMemcpyDeviceToDevice, st));
         ROITR_HIP(hipMemcpy2DAsync(L.wcat + H, sizeof(float) * (H + I), L.in_proj.w, sizeof(float) * I, sizeof(float) * I, H, hipMemcpyDeviceToDevice, st));
         CHK(roitr_add_vectors(H, L.lin.b, L.in_proj.b, L.bcat, st));
+        if (E.cfg.operand_dtype == 1) {
+            L.wcat_b = A.get<unsigned short>((size_t)H * (H + I));
+            if (A.fail) return ROITR_ERR_ARG;
+            CHK(roitr_f32_to_bf16((long)H * (H + I), L.wcat, L.wcat_b, st));
+        }
     }
     if ((L.in_dim != H || cat) && L.in_dim % 32 == 0) {
         const int I = L.in_dim;
@@ -491,6 +496,9 @@ int local_transformer(Engine& E, hipStream_t st, const LocalT& L, int N_in, cons
         b.wq = L.wqkv_x; b.bq = L.bqkv_x; b.wpe = L.wpe; b.bpe = L.bpe; b.wvpe = L.wvpe; b.bvpe = L.bvpe;
         b.wcat = L.wcat; b.bcat = L.bcat; b.norm_w = L.norm_w; b.norm_b = L.norm_b; b.wout = L.out_proj.w; b.bout = L.out_proj.b;
         b.bn2_w = L.bn2_w; b.bn2_b = L.bn2_b; b.scale = 1.0f / sqrtf((float)(H / HEADS)); b.eps = 1e-5f; b.out = out;
+        if (wkv_b && I == H && L.wcat_b && L.out_proj.wb) {   // bf16 operand mode: bf16 matrix operands inside the kernel as well
+            b.wq_h = L.wqkv_x_b; b.wcat_h = L.wcat_b; b.wout_h = L.out_proj.wb;
+        }
         CHK(roitr_local_block(&b, st));
         A.off = mark;
         return 0;

@@ -18,8 +18,9 @@ extern "C" const char* roitr_last_error(void) { return g_err; }
 // 2: RoitrForwardIO::inputs_ready and RoitrGemm::a_cat_idx (round 4), RoitrLocalAttnFold::ldqt and the RoitrLocalTd operator (round 5)
 // 3: RoitrGemm::batch_live, the compacted patch layout (RoitrPatch / RoitrOT / RoitrFine ::pair_off, ::slots, RoitrFine::pair_starts,
 //    roitr_patch_offsets) and RoitrForwardIO::patch_slots / patch_offsets / pair_starts (round 6)
+// 4: RoitrLocalBlock::wq_h / wcat_h / wout_h (round 6: bf16 matrix operands in the fused block of the bf16 operand mode)
 // A client built against an older version passes shorter structs: it must check this number.
-extern "C" int roitr_abi_version(void) { return 3; }
+extern "C" int roitr_abi_version(void) { return 4; }
 
 // Dynamic-LDS limit of a kernel, raised once per (kernel, device) and checked: hipFuncSetAttribute applies to the CURRENT device
 // only, so a process that drives several devices needs it on each of them (one process per GPU is the normal case, but nothing

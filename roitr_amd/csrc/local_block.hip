@@ -30,6 +30,10 @@
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
 
 template <int CTRL> __device__ __forceinline__ float dpp_mov(float v)
@@ -126,6 +130,80 @@ __device__ __forceinline__ void acc_store(const Acc& acc, const float* __restric
     }
 }
 
+// ---- the on-chip GEMMs with bf16 matrix operands (round 6; the engine's bf16 operand mode, RoitrLocalBlock::wq_h / wcat_h / wout_h) -------
+// v_mfma_f32_32x32x16_bf16, fp32 accumulator: a wave's region is one 32 x 32 tile per row region.  A: the fp32 LDS image, 8 consecutive
+// k of row r0 + 32 t + (lane & 31) from k0 + 8 (lane >> 5) (two ds_read_b128), rounded to bf16 on the way into the operand registers
+// (what the bf16 GEMM of csrc/gemm_bf16.hip does while it stages A); W: bf16 as the engine stores it, one 16-byte load per 16-k block
+// straight into the operand registers, a 32-k slab ahead.  Half the weight bytes out of L2 and an eighth of the matrix cycles of the
+// fp32 form; same row independence (an output row is a fixed sequence of operations on its own operands).
+__device__ __forceinline__ unsigned lb_pack_bf16(float x, float y)   // low half = x; round to nearest even
+{
+    f32x2 v = {x, y};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+}
+template <int AP, int RT>
+__device__ __forceinline__ void gemm_phase_bf16(f32x16 (&acc)[RT], const float* __restrict__ A, int Ka, const unsigned short* __restrict__ Wb, int ldw,
+                                                int k_w0, int r0, int c0, int tid)
+{
+    const int lane = tid & 63, ml = lane & 31, kh = lane >> 5;
+    const unsigned short* w = Wb + (size_t)(c0 + ml) * ldw + k_w0 + 8 * kh;
+    uint4 bn[2];
+    bn[0] = *reinterpret_cast<const uint4*>(w); bn[1] = *reinterpret_cast<const uint4*>(w + 16);
+    for (int k0 = 0; k0 < Ka; k0 += 32) {
+        uint4 bc[2] = {bn[0], bn[1]};
+        if (k0 + 32 < Ka) { bn[0] = *reinterpret_cast<const uint4*>(w + k0 + 32); bn[1] = *reinterpret_cast<const uint4*>(w + k0 + 48); }
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const bf16x8 b = __builtin_bit_cast(bf16x8, bc[c]);
+#pragma unroll
+            for (int t = 0; t < RT; ++t) {
+                const float* ap = A + (r0 + 32 * t + ml) * AP + k0 + 16 * c + 8 * kh;
+                const float4 x0 = *reinterpret_cast<const float4*>(ap), x1 = *reinterpret_cast<const float4*>(ap + 4);
+                const uint4 h = make_uint4(lb_pack_bf16(x0.x, x0.y), lb_pack_bf16(x0.z, x0.w), lb_pack_bf16(x1.x, x1.y), lb_pack_bf16(x1.z, x1.w));
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, h), b, acc[t], 0, 0, 0);
+            }
+        }
+    }
+}
+// 32 x 32 C/D map: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+template <int DP>
+__device__ __forceinline__ void acc_store32(const f32x16& acc, const float* __restrict__ bias, float* __restrict__ D, int r0, int c0, int lane)
+{
+    const int col = c0 + (lane & 31);
+    const float bv = bias[col];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) D[(r0 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5)) * DP + col] = acc[i] + bv;
+}
+// the accumulators of a wave's RT row regions in either form
+template <bool MB, int RT> struct RegionAcc { Acc a[RT]; };
+template <int RT> struct RegionAcc<true, RT> { f32x16 a[RT]; };
+template <bool MB, int RT> __device__ __forceinline__ void region_zero(RegionAcc<MB, RT>& r)
+{
+#pragma unroll
+    for (int t = 0; t < RT; ++t) {
+        if constexpr (MB) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) r.a[t][i] = 0.f;
+        } else acc_zero(r.a[t]);
+    }
+}
+template <bool MB, int H, int AP, int RT>
+__device__ __forceinline__ void region_gemm(RegionAcc<MB, RT>& r, const float* __restrict__ A, int Ka, const float* __restrict__ W,
+                                            const unsigned short* __restrict__ Wb, int ldw, int k_w0, int r0, int c0, int tid)
+{
+    if constexpr (MB) gemm_phase_bf16<AP, RT>(r.a, A, Ka, Wb, ldw, k_w0, r0, c0, tid);
+    else gemm_phase<H, AP, RT>(r.a, A, Ka, W, ldw, k_w0, r0, c0, tid);
+}
+template <bool MB, int DP, int RT>
+__device__ __forceinline__ void region_store(const RegionAcc<MB, RT>& r, const float* __restrict__ bias, float* __restrict__ D, int r0, int c0, int lane)
+{
+#pragma unroll
+    for (int t = 0; t < RT; ++t) {
+        if constexpr (MB) acc_store32<DP>(r.a[t], bias, D, r0 + 32 * t, c0, lane);
+        else acc_store<DP>(r.a[t], bias, D, r0 + 32 * t, c0, lane);
+    }
+}
+
 // one float4 of a gathered k | v row: fp32 rows, or (KVH, round 6: the bf16 operand mode of the engine) rows STORED in bf16 -- half the
 // bytes of the gathers the kernel waits on; the arithmetic behind the load is the fp32 kernel's
 template <bool KVH>
@@ -139,7 +217,8 @@ __device__ __forceinline__ float4 ld_kv4(const float* kv, size_t row, int ld, in
 }
 
 // DBG (tuning only, scripts/bench_local_block.py): 0 = the kernel; 1 = without the attention phase; 2 = attention only
-template <int H, int K, int TM, int DBG = 0, bool KVH = false>
+// MB: bf16 matrix operands in the three on-chip GEMMs (RoitrLocalBlock::wq_h / wcat_h / wout_h; the engine's bf16 operand mode)
+template <int H, int K, int TM, int DBG = 0, bool KVH = false, bool MB = false>
 __global__ __launch_bounds__(256, (K <= 8 && TM * H <= 4096) ? 3 : 2) void local_block_kernel(RoitrLocalBlock a)
 {
     constexpr int AP = H + 4;                 // activation image pitch
@@ -180,19 +259,13 @@ __global__ __launch_bounds__(256, (K <= 8 && TM * H <= 4096) ? 3 : 2) void local
     constexpr int NC = H / 32, RT = TM * H / (32 * 32 * 4);
     const int r0 = (wave / NC) * 32 * RT;
     const int c0 = (wave % NC) * 32;
-    Acc acc[RT];
-    auto zero_all = [&]() {
-#pragma unroll
-        for (int t = 0; t < RT; ++t) acc_zero(acc[t]);
-    };
-    auto store_all = [&](const float* bias) {
-#pragma unroll
-        for (int t = 0; t < RT; ++t) acc_store<AP>(acc[t], bias, R2, r0 + 32 * t, c0, lane);
-    };
+    RegionAcc<MB, RT> acc;
+    auto zero_all = [&]() { region_zero<MB, RT>(acc); };
+    auto store_all = [&](const float* bias) { region_store<MB, AP, RT>(acc, bias, R2, r0, c0, lane); };
     // ---- P1: q = x Wq^T + bq -> R2
     __syncthreads();                                              // the x image is complete
     zero_all();
-    if (DBG != 2) gemm_phase<H, AP, RT>(acc, R1, H, a.wq, H, 0, r0, c0, tid);
+    if (DBG != 2) region_gemm<MB, H, AP, RT>(acc, R1, H, a.wq, a.wq_h, H, 0, r0, c0, tid);
     store_all(a.bq);
     __syncthreads();
     // ---- P2: attention, in place on R2 (a wave touches only the rows of its own nodes)
@@ -293,8 +366,8 @@ __global__ __launch_bounds__(256, (K <= 8 && TM * H <= 4096) ? 3 : 2) void local
     __syncthreads();                                              // the attention rows of every wave are in place
     zero_all();
     if (DBG != 2) {
-    gemm_phase<H, AP, RT>(acc, R2, H, a.wcat, 2 * H, 0, r0, c0, tid);
-    gemm_phase<H, AP, RT>(acc, R1, H, a.wcat, 2 * H, H, r0, c0, tid);
+    region_gemm<MB, H, AP, RT>(acc, R2, H, a.wcat, a.wcat_h, 2 * H, 0, r0, c0, tid);
+    region_gemm<MB, H, AP, RT>(acc, R1, H, a.wcat, a.wcat_h, 2 * H, H, r0, c0, tid);
     }
     __syncthreads();                                              // every wave is done reading R1 / R2
     store_all(a.bcat);
@@ -343,7 +416,7 @@ __global__ __launch_bounds__(256, (K <= 8 && TM * H <= 4096) ? 3 : 2) void local
     }
     __syncthreads();                                              // the y image is complete
     zero_all();
-    if (DBG != 2) gemm_phase<H, AP, RT>(acc, R1, H, a.wout, H, 0, r0, c0, tid);
+    if (DBG != 2) region_gemm<MB, H, AP, RT>(acc, R1, H, a.wout, a.wout_h, H, 0, r0, c0, tid);
     __syncthreads();                                              // every wave is done reading the y image
     store_all(a.bout);
     __syncthreads();
@@ -809,6 +882,12 @@ extern "C" int roitr_local_block(const RoitrLocalBlock* a, hipStream_t stream)
         roitr_set_error("roitr_local_block: operands must be 16-byte aligned", __FILE__, __LINE__);
         return ROITR_ERR_ARG;
     }
+    // bf16 matrix operands: all three bf16 weight copies (16-byte aligned), with bf16-stored k | v rows (the engine's bf16 operand mode)
+    const bool mb = a->wq_h || a->wcat_h || a->wout_h;
+    if (mb && (!a->wq_h || !a->wcat_h || !a->wout_h || !a->kv_bf16 || (((uintptr_t)a->wq_h | (uintptr_t)a->wcat_h | (uintptr_t)a->wout_h) & 15) != 0)) {
+        roitr_set_error("roitr_local_block: wq_h / wcat_h / wout_h go together (16-byte aligned) and with kv_bf16", __FILE__, __LINE__);
+        return ROITR_ERR_ARG;
+    }
     // algorithmic bytes: x in, out out, K gathered k | v rows, ppf + indices per node; FLOPs of the three on-chip GEMMs ride in aux
     const double H = a->H, K = a->K;
     roitr_prof_begin2(ROITR_PROF_LOCAL_BLOCK, (double)a->M * (2.0 * H * 4 + K * (2.0 * H * (a->kv_bf16 ? 2 : 4) + 20.0)), 2.0 * a->M * H * H * 4.0, stream);
@@ -821,9 +900,13 @@ extern "C" int roitr_local_block(const RoitrLocalBlock* a, hipStream_t stream)
     const bool big = div_up(a->M, 2 * tm_small) >= LB_BIG_MIN_TILES;
     const int grid = xcd_grid(div_up(a->M, big ? 2 * tm_small : tm_small));
 #define LB_GO(HH, KK, TT, KVH_) local_block_kernel<HH, KK, TT, 0, KVH_><<<grid, 256, 0, stream>>>(*a)
+#define LB_GO_MB(HH, KK, TT) local_block_kernel<HH, KK, TT, 0, true, true><<<grid, 256, 0, stream>>>(*a)
 #define LB_PICK(HH, TS)                                                                           \
     do {                                                                                          \
-        if (a->kv_bf16) {                                                                         \
+        if (mb) {                                                                                 \
+            if (a->K == 8) { if (big) LB_GO_MB(HH, 8, 2 * TS); else LB_GO_MB(HH, 8, TS); }            \
+            else { if (big) LB_GO_MB(HH, 16, 2 * TS); else LB_GO_MB(HH, 16, TS); }                    \
+        } else if (a->kv_bf16) {                                                                  \
             if (a->K == 8) { if (big) LB_GO(HH, 8, 2 * TS, true); else LB_GO(HH, 8, TS, true); }      \
             else { if (big) LB_GO(HH, 16, 2 * TS, true); else LB_GO(HH, 16, TS, true); }              \
         } else if (a->K == 8) { if (big) LB_GO(HH, 8, 2 * TS, false); else LB_GO(HH, 8, TS, false); } \
@@ -832,6 +915,7 @@ extern "C" int roitr_local_block(const RoitrLocalBlock* a, hipStream_t stream)
     if (a->H == 64) LB_PICK(64, 64);
     else LB_PICK(128, 32);
 #undef LB_PICK
+#undef LB_GO_MB
 #undef LB_GO
     roitr_prof_end(ROITR_PROF_LOCAL_BLOCK, stream);
     ROITR_LAUNCH_CHECK();

@@ -433,16 +433,18 @@ class _LocalBlock(ctypes.Structure):
                 ("wpe", ctypes.c_void_p), ("bpe", ctypes.c_void_p), ("wvpe", ctypes.c_void_p), ("bvpe", ctypes.c_void_p),
                 ("wcat", ctypes.c_void_p), ("bcat", ctypes.c_void_p), ("norm_w", ctypes.c_void_p), ("norm_b", ctypes.c_void_p),
                 ("wout", ctypes.c_void_p), ("bout", ctypes.c_void_p), ("bn2_w", ctypes.c_void_p), ("bn2_b", ctypes.c_void_p),
-                ("scale", ctypes.c_float), ("eps", ctypes.c_float), ("out", ctypes.c_void_p), ("kv_bf16", ctypes.c_int)]
+                ("scale", ctypes.c_float), ("eps", ctypes.c_float), ("out", ctypes.c_void_p), ("kv_bf16", ctypes.c_int),
+                ("wq_h", ctypes.c_void_p), ("wcat_h", ctypes.c_void_p), ("wout_h", ctypes.c_void_p)]
 
 
-def local_block(x, kv, group_idx, ppf, w, node_order=None, variant=None):
+def local_block(x, kv, group_idx, ppf, w, node_order=None, variant=None, bf16_weights=False):
     """The block form of the local PPF transformer in one launch (csrc/local_block.hip; model/model.py:131-142 around
     ppftransformer.py:227-253).  x (M, H), kv (M, 2H) = k | v rows of every point, group_idx (M, K) int32, ppf (M, K, 4);
     w: dict of the FOLDED weights (include/roitr_engine.h RoitrLocalBlock): wq (H,H) bq, wpe (H,4) bpe, wvpe (H,4) bvpe,
     wcat (H,2H) bcat, norm_w norm_b, wout (H,H) bout, bn2_w bn2_b.  node_order: optional (M, 4) float32 whose last column
     holds the node index bits (the grid's sorted-point array).  variant: tuning hook (1: no attention, 2: attention only).
-    A bfloat16 `kv` tensor is gathered as stored (RoitrLocalBlock::kv_bf16, the engine's bf16 operand mode)."""
+    A bfloat16 `kv` tensor is gathered as stored (RoitrLocalBlock::kv_bf16, the engine's bf16 operand mode); bf16_weights (with it):
+    the three on-chip GEMMs take bf16 matrix operands (RoitrLocalBlock::wq_h / wcat_h / wout_h; the copies are made here)."""
     M, H = int(x.shape[0]), int(x.shape[1])
     K = int(group_idx.shape[1])
     f = lambda t: t.contiguous().float()
@@ -460,6 +462,9 @@ def local_block(x, kv, group_idx, ppf, w, node_order=None, variant=None):
         setattr(a, k, L.ptr(keep[k]))
     a.scale, a.eps, a.out = 1.0 / float(H // 4) ** 0.5, 1e-5, L.ptr(out)
     a.kv_bf16 = int(kv_h)
+    if bf16_weights:
+        keep_h = {k: keep[k].to(torch.bfloat16).contiguous() for k in ("wq", "wcat", "wout")}
+        a.wq_h, a.wcat_h, a.wout_h = L.ptr(keep_h["wq"]), L.ptr(keep_h["wcat"]), L.ptr(keep_h["wout"])
     if variant is None:
         L.check(L.lib().roitr_local_block(ctypes.byref(a), L.stream_ptr()), "local_block")
     else:

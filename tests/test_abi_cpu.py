@@ -15,7 +15,7 @@ def test_library_exports_declared_symbols():
     assert len(names) >= 50
     missing = [n for n in names if not hasattr(lib, n)]
     assert not missing, missing
-    assert lib.roitr_abi_version() == 3   # bumped with every struct change of include/*.h (round 6: batch_live, the compacted patch layout)
+    assert lib.roitr_abi_version() == 4   # bumped with every struct change of include/*.h (round 6: batch_live, the compacted patch layout; RoitrLocalBlock::w*_h)
     # the reference's own launcher names are present verbatim (cpp_wrappers/pointops/src/*/*_cuda_kernel.h)
     for n in ("furthestsampling_cuda_launcher", "knnquery_cuda_launcher", "grouping_forward_cuda_launcher",
               "grouping_backward_cuda_launcher", "interpolation_forward_cuda_launcher", "interpolation_backward_cuda_launcher",

@@ -525,12 +525,17 @@ def test_gemm_k_concatenated_operand_with_its_own_gather_and_an_addend(N, K, Kc,
 
 
 @pytest.mark.parametrize("H,K,M,order,kv_bf16", [(64, 8, 1000, True, False), (64, 16, 333, False, False), (128, 16, 777, True, False), (128, 8, 65, False, False),
-                                                   (128, 8, 1000, True, True), (64, 16, 333, False, True), (128, 16, 130, False, True), (64, 8, 65, True, True)])
+                                                   (128, 8, 1000, True, True), (64, 16, 333, False, True), (128, 16, 130, False, True), (64, 8, 65, True, True),
+                                                   (128, 8, 1000, True, "mb"), (64, 16, 333, False, "mb"), (128, 16, 130, False, "mb"), (64, 8, 65, True, "mb")])
 def test_local_block_against_float64(H, K, M, order, kv_bf16):
     """csrc/local_block.hip (the fused block transformer of levels 1-2) against a float64 restatement of its formulas from the
     same folded weights: tiles that are not full (M % 64, M % 32 != 0), a visiting order, both widths and neighbour counts; round 6:
-    also with the k | v rows stored in bf16 (the engine's bf16 operand mode) -- same bound, the restatement reads the rounded rows."""
+    also with the k | v rows stored in bf16 (the engine's bf16 operand mode) -- same bound, the restatement reads the rounded rows -- and
+    ("mb") with bf16 matrix operands in the three on-chip GEMMs on top: the restatement reads the rounded weights, what is left is the
+    rounding of the activations on their way into the matrix cores (2^-9 relative per operand): bound 4e-2, mean 4e-3."""
     from roitr_amd import ops
+    mb = kv_bf16 == "mb"
+    kv_bf16 = bool(kv_bf16)
     rng = np.random.default_rng(H + K + M)
     f32 = np.float32
     r = lambda *s: (rng.standard_normal(s) / np.sqrt(s[-1])).astype(f32)
@@ -551,8 +556,11 @@ def test_local_block_against_float64(H, K, M, order, kv_bf16):
         kv_dev = kv_dev.to(torch.bfloat16)
         kv = kv_dev.float().cpu().numpy()
     got = ops.local_block(dev(x), kv_dev, dev(grp), dev(ppf), {k: dev(v) for k, v in w.items()},
-                          node_order=dev(node_order) if order else None).cpu().numpy()
+                          node_order=dev(node_order) if order else None, bf16_weights=mb).cpu().numpy()
     D = {k: v.astype(np.float64) for k, v in w.items()}
+    if mb:
+        for k in ("wq", "wcat", "wout"):
+            D[k] = torch.from_numpy(w[k]).to(torch.bfloat16).double().numpy()
     X, KV, P = x.astype(np.float64), kv.astype(np.float64), ppf.astype(np.float64)
     c = H // 4
     q = X @ D["wq"].T + D["bq"]
@@ -573,10 +581,13 @@ def test_local_block_against_float64(H, K, M, order, kv_bf16):
     y = ln(np.concatenate([att, X], 1) @ D["wcat"].T + D["bcat"], D["norm_w"], D["norm_b"])
     ref = np.maximum(ln(y @ D["wout"].T + D["bout"], D["bn2_w"], D["bn2_b"]) + X, 0.0)
     err = np.abs(got - ref).max()
-    assert err < 3e-5, err
+    if mb:
+        assert err < 4e-2 and np.abs(got - ref).mean() < 4e-3, (err, np.abs(got - ref).mean())
+    else:
+        assert err < 3e-5, err
 
 
-@pytest.mark.parametrize("H,K,kv_bf16", [(64, 8, False), (128, 16, False), (64, 16, True), (128, 8, True)])
+@pytest.mark.parametrize("H,K,kv_bf16", [(64, 8, False), (128, 16, False), (64, 16, True), (128, 8, True), (128, 8, "mb"), (64, 16, "mb")])
 def test_local_block_rows_do_not_depend_on_the_tile_shape(H, K, kv_bf16):
     """roitr_local_block takes tiles of twice the rows (two row regions per wave under the same weight fragments) from 1024 such tiles on
     (round 6): the same nodes computed in a call below that size -- the small tile shape -- give the same bits."""
@@ -592,9 +603,10 @@ def test_local_block_rows_do_not_depend_on_the_tile_shape(H, K, kv_bf16):
     r = lambda *s: torch.randn(s, device="cuda", generator=g) / (s[-1] ** 0.5)
     w = dict(wq=r(H, H), bq=r(H), wpe=r(H, 4), bpe=r(H), wvpe=r(H, 4), bvpe=r(H), wcat=r(H, 2 * H), bcat=r(H), norm_w=1 + 0.1 * r(H),
              norm_b=0.1 * r(H), wout=r(H, H), bout=r(H), bn2_w=1 + 0.1 * r(H), bn2_b=0.1 * r(H))
-    big = ops.local_block(x, kv, grp, ppf, w)
+    mb = kv_bf16 == "mb"
+    big = ops.local_block(x, kv, grp, ppf, w, bf16_weights=mb)
     for lo, hi in ((0, 50000), (M - 30011, M)):
-        small = ops.local_block(x[lo:hi], kv, grp[lo:hi], ppf[lo:hi], w)
+        small = ops.local_block(x[lo:hi], kv, grp[lo:hi], ppf[lo:hi], w, bf16_weights=mb)
         assert torch.equal(small, big[lo:hi]), (lo, hi)
 
 
