@@ -864,7 +864,7 @@ extern "C" int roitr_local_block_dbg(const RoitrLocalBlock* a, int variant, hipS
         else if (ph == 2) local_block_kernel<HH, KK, TT, 2><<<grid, 256, 0, stream>>>(*a); \
         else local_block_kernel<HH, KK, TT, 0><<<grid, 256, 0, stream>>>(*a);                  \
     } while (0)
-    if (a->H == 64 && a->K == 8) { if (big) LB_DBG(64, 8, 128); else LB_DBG(64, 8, 64); }
+    if (a->H == 64 && a->K == 8) { if (big) LB_DBG(64, 8, 128); else LB_DBG(64, 8, 64); }   // 128-row tiles at H = 64: this hook only
     else if (a->H == 128 && a->K == 16) { if (big) LB_DBG(128, 16, 64); else LB_DBG(128, 16, 32); }
     else return ROITR_ERR_UNSUPPORTED;
 #undef LB_DBG
@@ -891,29 +891,26 @@ extern "C" int roitr_local_block(const RoitrLocalBlock* a, hipStream_t stream)
     // algorithmic bytes: x in, out out, K gathered k | v rows, ppf + indices per node; FLOPs of the three on-chip GEMMs ride in aux
     const double H = a->H, K = a->K;
     roitr_prof_begin2(ROITR_PROF_LOCAL_BLOCK, (double)a->M * (2.0 * H * 4 + K * (2.0 * H * (a->kv_bf16 ? 2 : 4) + 20.0)), 2.0 * a->M * H * H * 4.0, stream);
-    // Rows per tile: twice as many (two row regions per wave under the same weight fragments: half the weight bytes streamed out of L2
-    // per node, half the tiles) once that still leaves >= LB_BIG_MIN_TILES tiles -- level 1 / 2 of a 512-pair step 3.32 -> 2.97 and
-    // 2.77 -> 2.48 ms per launch (scripts/bench_local_block.py).  A node's result is the same bits in either tile shape (one fixed
-    // sequence of operations per row), so the choice may depend on M.
+    // Rows per tile at H = 128: twice as many (64: two row regions per wave under the same weight fragments -- half the weight bytes
+    // streamed out of L2 per node, half the tiles) once that still leaves >= LB_BIG_MIN_TILES tiles: 2.77 -> 2.48 ms per level-2 launch
+    // of a 512-pair step alone (scripts/bench_local_block.py), 28.6 -> 27.7 ms of block kernels per step.  A node's result is the same
+    // bits in either tile shape (one fixed sequence of operations per row), so the choice may depend on M.  Measured and not taken: the
+    // same at H = 64 (128-row tiles: 3.32 -> 2.97 ms alone, but two workgroups per CU instead of three -- nothing left beside the
+    // geometry stream: 28.8 vs 28.6 ms per step).
     constexpr int LB_BIG_MIN_TILES = 1024;
-    const int tm_small = a->H == 64 ? 64 : 32;
-    const bool big = div_up(a->M, 2 * tm_small) >= LB_BIG_MIN_TILES;
-    const int grid = xcd_grid(div_up(a->M, big ? 2 * tm_small : tm_small));
+    const bool big = a->H == 128 && div_up(a->M, 64) >= LB_BIG_MIN_TILES;
+    const int grid = xcd_grid(div_up(a->M, a->H == 64 ? 64 : (big ? 64 : 32)));
 #define LB_GO(HH, KK, TT, KVH_) local_block_kernel<HH, KK, TT, 0, KVH_><<<grid, 256, 0, stream>>>(*a)
 #define LB_GO_MB(HH, KK, TT) local_block_kernel<HH, KK, TT, 0, true, true><<<grid, 256, 0, stream>>>(*a)
-#define LB_PICK(HH, TS)                                                                           \
-    do {                                                                                          \
-        if (mb) {                                                                                 \
-            if (a->K == 8) { if (big) LB_GO_MB(HH, 8, 2 * TS); else LB_GO_MB(HH, 8, TS); }            \
-            else { if (big) LB_GO_MB(HH, 16, 2 * TS); else LB_GO_MB(HH, 16, TS); }                    \
-        } else if (a->kv_bf16) {                                                                  \
-            if (a->K == 8) { if (big) LB_GO(HH, 8, 2 * TS, true); else LB_GO(HH, 8, TS, true); }      \
-            else { if (big) LB_GO(HH, 16, 2 * TS, true); else LB_GO(HH, 16, TS, true); }              \
-        } else if (a->K == 8) { if (big) LB_GO(HH, 8, 2 * TS, false); else LB_GO(HH, 8, TS, false); } \
-        else { if (big) LB_GO(HH, 16, 2 * TS, false); else LB_GO(HH, 16, TS, false); }                \
+#define LB_PICK(HH, KK, TT)                                   \
+    do {                                                      \
+        if (mb) LB_GO_MB(HH, KK, TT);                         \
+        else if (a->kv_bf16) LB_GO(HH, KK, TT, true);         \
+        else LB_GO(HH, KK, TT, false);                        \
     } while (0)
-    if (a->H == 64) LB_PICK(64, 64);
-    else LB_PICK(128, 32);
+    if (a->H == 64) { if (a->K == 8) LB_PICK(64, 8, 64); else LB_PICK(64, 16, 64); }
+    else if (big) { if (a->K == 8) LB_PICK(128, 8, 64); else LB_PICK(128, 16, 64); }
+    else { if (a->K == 8) LB_PICK(128, 8, 32); else LB_PICK(128, 16, 32); }
 #undef LB_PICK
 #undef LB_GO_MB
 #undef LB_GO

@@ -587,10 +587,10 @@ def test_local_block_against_float64(H, K, M, order, kv_bf16):
         assert err < 3e-5, err
 
 
-@pytest.mark.parametrize("H,K,kv_bf16", [(64, 8, False), (128, 16, False), (64, 16, True), (128, 8, True), (128, 8, "mb"), (64, 16, "mb")])
+@pytest.mark.parametrize("H,K,kv_bf16", [(128, 16, False), (128, 8, False), (128, 16, True), (128, 8, True), (128, 8, "mb"), (128, 16, "mb")])
 def test_local_block_rows_do_not_depend_on_the_tile_shape(H, K, kv_bf16):
-    """roitr_local_block takes tiles of twice the rows (two row regions per wave under the same weight fragments) from 1024 such tiles on
-    (round 6): the same nodes computed in a call below that size -- the small tile shape -- give the same bits."""
+    """roitr_local_block takes tiles of twice the rows at H = 128 (two row regions per wave under the same weight fragments) from 1024 such
+    tiles on (round 6): the same nodes computed in a call below that size -- the small tile shape -- give the same bits."""
     from roitr_amd import ops
     M = (2 * (64 if H == 64 else 32)) * 1024 + 77                  # big tiles, the last one not full
     g = torch.Generator(device="cuda").manual_seed(H + K)
