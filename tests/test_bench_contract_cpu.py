@@ -103,7 +103,7 @@ def test_committed_bench_lines_follow_the_contract():
             continue
         assert d["metric"] == "point-cloud pairs/s" and d["unit"] == "pairs/s" and d["higher_is_better"] is True
         assert d["scaling"] == "weak" and d["data"] == "synthetic" and d["vs_baseline"] is None
-        assert d["dtype"] in ("f32", "bf16") and "workload" in d["config"] and "model" not in d["config"]
+        assert d["dtype"] in ("f32", "bf16", "f32x3") and "workload" in d["config"] and "model" not in d["config"]
         r = d["roofline"]
         assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
         assert abs(d["value"] - d["config"]["pairs_per_step"] * d["n_gpus"] * 1e3 / d["ms_per_step"]) < 1e-2 * d["value"]
