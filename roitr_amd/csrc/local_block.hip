@@ -65,9 +65,9 @@ __device__ __forceinline__ void acc_zero(Acc& a)
 // MFMAs: no LDS staging, no barrier inside a phase (round 3: staging every slab through LDS with two barriers each held the
 // on-chip GEMMs at 58 TFLOP/s at H = 128, where a 32-row tile re-streams all 256 KB of weights).
 // RT (round 6): the wave computes RT regions of 32 rows each (rows r0 + 32 t) against the SAME 32 weight rows -- the B fragments of a
-// slab are fetched once and used RT times.  The on-chip GEMMs are bound by streaming the weights out of L2 (every tile re-reads all
-// of them: 2 KB per node at H = 64 / TM = 64, 8 KB at H = 128 / TM = 32 -- ~6 TB/s in both widths at the measured phase times), not by
-// the matrix pipe, so rows per weight pass is what counts.
+// slab are fetched once and used RT times.  The on-chip GEMMs are not bound by the matrix pipe (busy 0.61 / 0.66 of the time at
+// H = 64 / 128 without the attention phase, profiles/r06_local_block_sq.txt: every tile re-fetches all weight fragments, 4 loads per
+// 32 MFMAs of a slab), so MFMAs per fetched fragment is what counts.
 template <int H, int AP, int RT = 1>
 __device__ __forceinline__ void gemm_phase(Acc (&acc)[RT], const float* __restrict__ A, int Ka, const float* __restrict__ W, int ldw, int k_w0,
                                            int r0, int c0, int tid)
@@ -229,7 +229,7 @@ __global__ __launch_bounds__(256, (K <= 8 && TM * H <= 4096) ? 3 : 2) void local
     __shared__ __attribute__((aligned(16))) float R1[TM * AP];   // x image, later the LayerNorm-ed y image
     __shared__ __attribute__((aligned(16))) float R2[TM * AP];   // q rows -> attention rows -> row-major staging of the two epilogues
     __shared__ int ids[TM];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;   // re-derived after the attention phase (below)
     const int ntiles = (a.M + TM - 1) / TM;
     const int tile = xcd_block_id(ntiles);
     if (tile >= ntiles) return;
@@ -257,8 +257,8 @@ __global__ __launch_bounds__(256, (K <= 8 && TM * H <= 4096) ? 3 : 2) void local
     }
     // the TM x H output is (TM / 32) x (H / 32) regions of 32 x 32: a wave takes ONE 32-column strip and RT row regions under each other
     constexpr int NC = H / 32, RT = TM * H / (32 * 32 * 4);
-    const int r0 = (wave / NC) * 32 * RT;
-    const int c0 = (wave % NC) * 32;
+    int r0 = (wave / NC) * 32 * RT;
+    int c0 = (wave % NC) * 32;
     RegionAcc<MB, RT> acc;
     auto zero_all = [&]() { region_zero<MB, RT>(acc); };
     auto store_all = [&](const float* bias) { region_store<MB, AP, RT>(acc, bias, R2, r0, c0, lane); };
@@ -363,6 +363,14 @@ __global__ __launch_bounds__(256, (K <= 8 && TM * H <= 4096) ? 3 : 2) void local
         }
     }
     // ---- P3: y = LN([att | x] Wcat^T + bcat)
+    // The attention loop runs at the register limit of its occupancy; whatever the phases below need of the thread's coordinates is
+    // derived again from an opaque copy of the thread id, so that nothing of it lives (= is spilled) across that loop.
+    {
+        int t2 = tid;
+        asm volatile("" : "+v"(t2));
+        tid = t2; lane = t2 & 63; wave = t2 >> 6;
+        r0 = (wave / NC) * 32 * RT; c0 = (wave % NC) * 32;
+    }
     __syncthreads();                                              // the attention rows of every wave are in place
     zero_all();
     if (DBG != 2) {
@@ -751,15 +759,6 @@ __global__ __launch_bounds__(256, 3) void local_td_kernel(RoitrLocalTd a)
         }
     }
     __syncthreads();
-    float4 xn4[2];                                                 // the node rows again (L2-hot), for the K-concatenated linear
-    {
-        constexpr int F4 = I / 4;
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int e = tid + 256 * u;
-            xn4[u] = *reinterpret_cast<const float4*>(a.x + (size_t)a.node_idx[ids[e / F4]] * I + 4 * (e % F4));
-        }
-    }
     {   // ---- P2b: val_h = Wv'_h xbar_h (wave = head); att = vpart + val + bv' in place on R2
         Acc acc;
         acc_zero(acc);
@@ -777,15 +776,16 @@ __global__ __launch_bounds__(256, 3) void local_td_kernel(RoitrLocalTd a)
                 }
         }
     }
+    // the node rows again (L2-hot), for the K-concatenated linear; requested here, behind the value GEMM (as a two-element array
+    // requested in front of it they lived in scratch across it)
+    constexpr int F4n = I / 4;
+    int e0 = tid, e1 = tid + 256;
+    asm volatile("" : "+v"(e0), "+v"(e1));                          // keeps the requests below the value GEMM's epilogue
+    const float4 xn_a = *reinterpret_cast<const float4*>(a.x + (size_t)a.node_idx[ids[e0 / F4n]] * I + 4 * (e0 % F4n));
+    const float4 xn_b = *reinterpret_cast<const float4*>(a.x + (size_t)a.node_idx[ids[e1 / F4n]] * I + 4 * (e1 % F4n));
     __syncthreads();                                              // every wave is done with the xbar image: x_n takes its columns 128..191
-    {
-        constexpr int F4 = I / 4;
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int e = tid + 256 * u;
-            *reinterpret_cast<float4*>(R3 + (e / F4) * P3 + 2 * I + 4 * (e % F4)) = xn4[u];
-        }
-    }
+    *reinterpret_cast<float4*>(R3 + (e0 / F4n) * P3 + 2 * I + 4 * (e0 % F4n)) = xn_a;
+    *reinterpret_cast<float4*>(R3 + (e1 / F4n) * P3 + 2 * I + 4 * (e1 % F4n)) = xn_b;
     Acc acc;
     // ---- P3: y = LN([att | x_n] Wcat^T + bcat) -> R3 columns 0..127
     acc_zero(acc);
@@ -891,8 +891,8 @@ extern "C" int roitr_local_block(const RoitrLocalBlock* a, hipStream_t stream)
     // algorithmic bytes: x in, out out, K gathered k | v rows, ppf + indices per node; FLOPs of the three on-chip GEMMs ride in aux
     const double H = a->H, K = a->K;
     roitr_prof_begin2(ROITR_PROF_LOCAL_BLOCK, (double)a->M * (2.0 * H * 4 + K * (2.0 * H * (a->kv_bf16 ? 2 : 4) + 20.0)), 2.0 * a->M * H * H * 4.0, stream);
-    // Rows per tile at H = 128: twice as many (64: two row regions per wave under the same weight fragments -- half the weight bytes
-    // streamed out of L2 per node, half the tiles) once that still leaves >= LB_BIG_MIN_TILES tiles: 2.77 -> 2.48 ms per level-2 launch
+    // Rows per tile at H = 128: twice as many (64: two row regions per wave under the same weight fragments -- half the weight
+    // fetches per node, half the tiles) once that still leaves >= LB_BIG_MIN_TILES tiles: 2.77 -> 2.48 ms per level-2 launch
     // of a 512-pair step alone (scripts/bench_local_block.py), 28.6 -> 27.7 ms of block kernels per step.  A node's result is the same
     // bits in either tile shape (one fixed sequence of operations per row), so the choice may depend on M.  Measured and not taken: the
     // same at H = 64 (128-row tiles: 3.32 -> 2.97 ms alone, but two workgroups per CU instead of three -- nothing left beside the
