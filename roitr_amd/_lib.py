@@ -22,6 +22,10 @@ def lib():
             raise RoitrError(
                 f"{LIB_PATH} is missing: build it with `python -m roitr_amd.build` "
                 "(hipcc --offload-arch=gfx950).  roitr_amd has no CPU fallback.")
+        # torch first: the library must bind to the HIP runtime torch brings along.  Loaded before torch, it pulls in the system
+        # libamdhip64 and the process ends up with two runtimes -- the engine then sees "no ROCm-capable device" (build() followed by
+        # smoke() in one process did exactly that).  torch is the package's device-memory / stream plumbing anyway.
+        import torch  # noqa: F401
         _lib = ctypes.CDLL(LIB_PATH)
         _lib.roitr_last_error.restype = ctypes.c_char_p
         _lib.roitr_knn_workspace_bytes.restype = ctypes.c_size_t
