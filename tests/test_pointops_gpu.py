@@ -131,6 +131,8 @@ def test_fps_golden(golden_pair):
     ([5000], True, 9), ([5000], True, 17), ([1250], True, 17), ([312], True, 17), ([78], True, 17),
     ([16], True, 17), ([5000], False, 17), ([5000], False, 3), ([5000], False, 1), ([900, 1500, 40], True, 9),
     ([900, 1500, 40], False, 17), ([3000], True, 65), ([2000], True, 100), ([5], True, 3),
+    # round 6: more shapes through the cell kernel (self queries on a grid below 8192 queries): other k, two clouds, the largest such cloud
+    ([8000], True, 33), ([700, 3100], True, 49), ([8100], True, 65),
 ])
 def test_knn_bit_exact(case, kind, use_grid):
     from roitr_amd import pointops as P
